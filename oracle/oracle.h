@@ -1,0 +1,80 @@
+/*
+ * oracle/oracle.h -- TEST INFRASTRUCTURE. CPU restatement of edison's keyword-spotting hot path.
+ *
+ * This is the parity CHECKER and the timed CPU baseline ("port"); it is never the product path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it. The product
+ * (edison_amd/, include/edison_hip.h) must not link, import or call anything declared here.
+ *
+ * Pinning: the int8 CNN restatement is checked bit-for-bit against the reference itself
+ * (oracle/_ref/libnnom_ref.so = NNoM 0.3.0 + CMSIS-NN + weights.h compiled from /root/reference) and
+ * against tests/golden/cnn_golden.npz produced from it; the MFCC restatement is checked against
+ * tests/golden/mfcc_golden.npz produced by importing the reference's audio/edison/mfcc/mfcc_utils.py
+ * (tests/golden/gen_fixtures.py is the generating script).
+ */
+#ifndef EDISON_ORACLE_H
+#define EDISON_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- MFCC (float64, like the numpy reference) -------------------------------------------------- */
+
+#define ORACLE_MFCC_VARIANT_A 0 /* mfcc_utils.mfcc      (audio/edison/mfcc/mfcc_utils.py:134-199) */
+#define ORACLE_MFCC_VARIANT_B 1 /* mfcc_utils.mfcc_mcu  (audio/edison/mfcc/mfcc_utils.py:255-323) */
+
+/* gen_mel_weight_matrix (mfcc_utils.py:36-73): W is [num_spectrogram_bins][num_mel_bins] row-major. */
+void oracle_mel_weight_matrix(int num_mel_bins, int num_spectrogram_bins, double sample_rate,
+                              double lower_edge_hertz, double upper_edge_hertz, double *W);
+
+/*
+ * n_frames frames of frame_len (must be 1024-like power of two) samples taken every frame_step samples
+ * from x. variant A: fft[:N/2] -> |.| -> mel(N/2 bins) -> log(+1e-6) -> dct2/sqrt(2*nmel).
+ * variant B: fft/N -> |.|/sqrt2 -> [:N/2+1] . (scale*mel(N/2+1 bins)) / scale -> [log] -> dct2/64.
+ * Outputs (each may be NULL): spectrogram [n][nspec] (A: N/2, B: N), mel [n][nmel],
+ * logmel [n][nmel] (B without use_log: copy of mel), mfcc [n][nmel].
+ */
+int oracle_mfcc(const int16_t *x, int64_t n_frames, int frame_len, int64_t frame_step, int variant,
+                int num_mel_bins, double sample_rate, double lower_edge_hertz, double upper_edge_hertz,
+                double mel_mtx_scale, int use_log,
+                double *spectrogram, double *mel, double *logmel, double *mfcc, int n_threads);
+
+/* np.clip(x*scale, lo, hi) then np.round (half to even) -> int8  (kws_nnom.py:354-361 host mirror of
+ * firmware/src/app.c:675-695). in: [n][stride] doubles, first n_coef of each row are used. */
+void oracle_net_input(const double *mfcc, int64_t n_rows, int stride, int n_coef, double scale,
+                      double clip_lo, double clip_hi, int8_t *out);
+
+/* ---- int8 CNN (NNoM/CMSIS-NN arithmetic) -------------------------------------------------------- */
+
+#define ORACLE_L_CONV 1
+#define ORACLE_L_POOL 2
+#define ORACLE_L_DENSE 3
+#define ORACLE_L_SOFTMAX 4
+
+typedef struct {
+	int32_t type;
+	int32_t out_ch, kh, kw, sh, sw;  /* conv / pool geometry (VALID padding)          */
+	int32_t bias_lshift, out_rshift; /* conv / dense requantisation                   */
+	int32_t relu;                    /* conv: in-place ReLU tail activation           */
+	const int8_t *w;                 /* conv: OHWI; dense: row-major [out][in]        */
+	const int8_t *b;
+} oracle_layer_t;
+
+/*
+ * Run n utterances through the layer list. in: [n][in_h*in_w*in_c] int8 HWC.
+ * acts (may be NULL): every layer's output back to back per utterance, stride acts_stride bytes.
+ * logits = output of the last dense layer, softmax = output of the softmax layer, argmax = first-max
+ * index over the softmax output (nnom_predict, nnom_utils.c:275-284). Returns 0 or a negative code.
+ */
+int oracle_cnn_run(const oracle_layer_t *layers, int n_layers, int in_h, int in_w, int in_c,
+                   const int8_t *in, int64_t n, int8_t *acts, int64_t acts_stride,
+                   int8_t *logits, int8_t *softmax, int32_t *argmax, int n_threads);
+
+int oracle_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,246 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE: ctypes access to the CPU checker.
+
+Two libraries, both test-only (tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg are the only allowed callers; the product never imports this):
+
+  * ``oracle/_build/liboracle.so``  -- this repo's plain-C restatement
+    (mfcc_ref.c: reference audio/edison/mfcc/mfcc_utils.py:16-323;
+     kws_cnn_ref.c: NNoM 0.3.0 / CMSIS-NN portable branches)           -> kind "port"
+  * ``oracle/_ref/libnnom_ref.so``  -- the reference int8 CNN itself, built from
+    /root/reference by oracle/Makefile (prebuilt file on the GPU box)   -> kind "reference"
+
+The model blob reader below is deliberately independent of edison_amd/ so that a bug in
+the product's loader cannot hide behind a shared parser.
+"""
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_SO = os.path.join(_HERE, "_build", "liboracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libnnom_ref.so")
+DEFAULT_MODEL = os.path.join(os.path.dirname(_HERE), "edison_amd", "data", "kws_nnom.ednn")
+
+VARIANT_A, VARIANT_B = 0, 1
+L_CONV, L_POOL, L_DENSE, L_SOFTMAX = 1, 2, 3, 4
+
+# audio/config.py:11-32
+FS, FRAME_LEN, NUM_MEL, MEL_LO, MEL_HI, MEL_SCALE, NUM_MFCC = 16000, 1024, 32, 80.0, 7600.0, 128, 13
+
+
+def build(force=False):
+    """Compile the restatement (always possible: gcc only) and, when the reference is mounted, the reference."""
+    if force or not os.path.exists(PORT_SO) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(PORT_SO)
+            for f in ("mfcc_ref.c", "kws_cnn_ref.c", "oracle.h")):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "port"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/firmware") and (force or not os.path.exists(REF_SO)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+class _Layer(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_int32), ("out_ch", ctypes.c_int32), ("kh", ctypes.c_int32), ("kw", ctypes.c_int32),
+                ("sh", ctypes.c_int32), ("sw", ctypes.c_int32), ("bias_lshift", ctypes.c_int32),
+                ("out_rshift", ctypes.c_int32), ("relu", ctypes.c_int32),
+                ("w", ctypes.c_void_p), ("b", ctypes.c_void_p)]
+
+
+_port = None
+_ref = None
+
+
+def port():
+    global _port
+    if _port is None:
+        if not os.path.exists(PORT_SO):
+            build()
+        L = ctypes.CDLL(PORT_SO)
+        L.oracle_mfcc.restype = ctypes.c_int
+        L.oracle_mfcc.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_int]
+        L.oracle_mel_weight_matrix.restype = None
+        L.oracle_mel_weight_matrix.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                               ctypes.c_double, ctypes.c_void_p]
+        L.oracle_net_input.restype = None
+        L.oracle_net_input.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                       ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+        L.oracle_cnn_run.restype = ctypes.c_int
+        L.oracle_cnn_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.oracle_num_threads.restype = ctypes.c_int
+        _port = L
+    return _port
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    """The reference NNoM build; raises if oracle/_ref is absent (it cannot be rebuilt on the GPU box)."""
+    global _ref
+    if _ref is None:
+        if not os.path.exists(REF_SO):
+            build()
+        if not os.path.exists(REF_SO):
+            raise FileNotFoundError("oracle/_ref/libnnom_ref.so is absent and /root/reference is not mounted")
+        L = ctypes.CDLL(REF_SO)
+        L.nnom_ref_run_batch.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p]
+        L.nnom_ref_run_layers.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_int32]
+        if L.nnom_ref_init() != 0:
+            raise RuntimeError("nnom_ref_init failed")
+        _ref = L
+    return _ref
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ------------------------------------------------------------------------------------------- MFCC
+
+def mel_weight_matrix(num_mel_bins=NUM_MEL, num_spectrogram_bins=FRAME_LEN // 2 + 1, sample_rate=FS,
+                      lower_edge_hertz=MEL_LO, upper_edge_hertz=MEL_HI):
+    W = np.zeros((num_spectrogram_bins, num_mel_bins), np.float64)
+    port().oracle_mel_weight_matrix(num_mel_bins, num_spectrogram_bins, float(sample_rate), float(lower_edge_hertz),
+                                    float(upper_edge_hertz), _p(W))
+    return W
+
+
+def mfcc(x, variant, n_frames=None, frame_len=FRAME_LEN, frame_step=FRAME_LEN, use_log=False, stages=False,
+         n_threads=1, num_mel_bins=NUM_MEL, sample_rate=FS, lower_edge_hertz=MEL_LO, upper_edge_hertz=MEL_HI,
+         mel_mtx_scale=MEL_SCALE):
+    """x: 1-D int16 stream. Returns mfcc [n_frames, num_mel_bins] float64 (plus stage arrays if stages)."""
+    x = np.ascontiguousarray(x, dtype=np.int16).ravel()
+    if n_frames is None:
+        n_frames = 1 + (x.shape[0] - frame_len) // frame_step  # mfcc_utils.py:154-155
+    if n_frames <= 0:
+        return np.zeros((0, num_mel_bins))
+    assert (n_frames - 1) * frame_step + frame_len <= x.shape[0]
+    nspec = frame_len // 2 if variant == VARIANT_A else frame_len
+    out = np.zeros((n_frames, num_mel_bins), np.float64)
+    sp = np.zeros((n_frames, nspec), np.float64) if stages else None
+    me = np.zeros((n_frames, num_mel_bins), np.float64) if stages else None
+    lm = np.zeros((n_frames, num_mel_bins), np.float64) if stages else None
+    r = port().oracle_mfcc(_p(x), n_frames, frame_len, frame_step, variant, num_mel_bins, float(sample_rate),
+                           float(lower_edge_hertz), float(upper_edge_hertz), float(mel_mtx_scale), int(bool(use_log)),
+                           _p(sp), _p(me), _p(lm), _p(out), int(n_threads))
+    if r != 0:
+        raise RuntimeError("oracle_mfcc failed: %d" % r)
+    if stages:
+        return out, dict(spectrogram=sp, mel_spectrogram=me, log_mel_spectrogram=lm)
+    return out
+
+
+def net_input(mfcc_rows, n_coef=NUM_MFCC, scale=1.0, clip_lo=-128.0, clip_hi=127.0):
+    m = np.ascontiguousarray(mfcc_rows, dtype=np.float64)
+    n, stride = m.shape
+    out = np.zeros((n, n_coef), np.int8)
+    port().oracle_net_input(_p(m), n, stride, n_coef, float(scale), float(clip_lo), float(clip_hi), _p(out))
+    return out
+
+
+# -------------------------------------------------------------------------------------------- CNN
+
+class Model:
+    """Independent reader of the .ednn blob written by tools/import_weights_h.py."""
+
+    def __init__(self, path=DEFAULT_MODEL):
+        raw = open(path, "rb").read()
+        if raw[:8] != b"EDNNOM1\0":
+            raise ValueError("bad model magic")
+        self.in_h, self.in_w, self.in_c, n_layers, payload_bytes, flags, _, _ = struct.unpack("<8i", raw[8:40])
+        recs = [struct.unpack("<12i", raw[40 + 48 * i:88 + 48 * i]) for i in range(n_layers)]
+        payload = np.frombuffer(raw[40 + 48 * n_layers:40 + 48 * n_layers + payload_bytes], dtype=np.int8)
+        self.layers, self._keep = [], []
+        h, w, c = self.in_h, self.in_w, self.in_c
+        self.act_sizes = []
+        arr = (_Layer * n_layers)()
+        for i, r in enumerate(recs):
+            L = dict(type=r[0])
+            if r[0] == L_CONV:
+                L.update(out_ch=r[1], kh=r[2], kw=r[3], sh=r[4], sw=r[5], bias_lshift=r[6], out_rshift=r[7],
+                         relu=r[8], in_ch=r[11])
+                L["w"] = np.ascontiguousarray(payload[r[9]:r[9] + r[1] * r[2] * r[3] * c]).reshape(r[1], r[2], r[3], c)
+                L["b"] = np.ascontiguousarray(payload[r[10]:r[10] + r[1]])
+                h, w, c = (h - r[2]) // r[4] + 1, (w - r[3]) // r[5] + 1, r[1]
+            elif r[0] == L_POOL:
+                L.update(kh=r[2], kw=r[3], sh=r[4], sw=r[5])
+                h, w = (h - r[2]) // r[4] + 1, (w - r[3]) // r[5] + 1
+            elif r[0] == L_DENSE:
+                n_in = h * w * c
+                L.update(out_ch=r[1], bias_lshift=r[6], out_rshift=r[7])
+                L["w"] = np.ascontiguousarray(payload[r[9]:r[9] + r[1] * n_in]).reshape(r[1], n_in)
+                L["b"] = np.ascontiguousarray(payload[r[10]:r[10] + r[1]])
+                h, w, c = 1, 1, r[1]
+                self.n_logits = r[1]
+            elif r[0] == L_SOFTMAX:
+                pass
+            else:
+                raise ValueError("unknown layer type %d" % r[0])
+            self.layers.append(L)
+            self.act_sizes.append(h * w * c)
+            a = arr[i]
+            a.type = r[0]
+            a.out_ch, a.kh, a.kw, a.sh, a.sw = L.get("out_ch", 0), L.get("kh", 0), L.get("kw", 0), L.get("sh", 0), L.get("sw", 0)
+            a.bias_lshift, a.out_rshift, a.relu = L.get("bias_lshift", 0), L.get("out_rshift", 0), L.get("relu", 0)
+            a.w = L["w"].ctypes.data if "w" in L else None
+            a.b = L["b"].ctypes.data if "b" in L else None
+        self._arr = arr
+        self.n_out = h * w * c
+        self.in_size = self.in_h * self.in_w * self.in_c
+
+
+def cnn(model, feats, want_acts=False, n_threads=1):
+    """feats: [n, 403] int8. Returns dict(logits, softmax, argmax[, acts = list of per-layer arrays])."""
+    f = np.ascontiguousarray(feats, dtype=np.int8).reshape(-1, model.in_size)
+    n = f.shape[0]
+    logits = np.zeros((n, model.n_logits), np.int8)
+    soft = np.zeros((n, model.n_out), np.int8)
+    am = np.zeros(n, np.int32)
+    stride = int(sum(model.act_sizes))
+    acts = np.zeros((n, stride), np.int8) if want_acts else None
+    r = port().oracle_cnn_run(ctypes.cast(model._arr, ctypes.c_void_p), len(model.layers), model.in_h, model.in_w,
+                              model.in_c, _p(f), n, _p(acts), stride, _p(logits), _p(soft), _p(am), int(n_threads))
+    if r != 0:
+        raise RuntimeError("oracle_cnn_run failed: %d" % r)
+    out = dict(logits=logits, softmax=soft, argmax=am)
+    if want_acts:
+        offs = np.concatenate([[0], np.cumsum(model.act_sizes)])
+        out["acts"] = [acts[:, offs[i]:offs[i + 1]] for i in range(len(model.act_sizes))]
+    return out
+
+
+def nnom_ref_batch(feats):
+    """The reference itself (NNoM + CMSIS-NN + weights.h): logits, softmax, argmax for [n, 403] int8."""
+    f = np.ascontiguousarray(feats, dtype=np.int8).reshape(-1, 403)
+    n = f.shape[0]
+    logits = np.zeros((n, 10), np.int8)
+    soft = np.zeros((n, 10), np.int8)
+    am = np.zeros(n, np.int32)
+    r = ref().nnom_ref_run_batch(_p(f), n, _p(logits), _p(soft), _p(am))
+    if r != 0:
+        raise RuntimeError("nnom_ref_run_batch failed: %d" % r)
+    return dict(logits=logits, softmax=soft, argmax=am)
+
+
+def nnom_ref_layers(feat):
+    """Per-layer activations of ONE utterance from the reference: list of int8 arrays in execution order
+    (input, conv1, pool1, conv2, pool2, conv3, conv4, dense, softmax, output)."""
+    f = np.ascontiguousarray(feat, dtype=np.int8).reshape(403)
+    dump = np.zeros(16384, np.int8)
+    sizes = np.zeros(16, np.int32)
+    types = np.zeros(16, np.int32)
+    n = ref().nnom_ref_run_layers(_p(f), _p(dump), dump.size, _p(sizes), _p(types), 16)
+    if n < 0:
+        raise RuntimeError("nnom_ref_run_layers failed: %d" % n)
+    offs = np.concatenate([[0], np.cumsum(sizes[:n])])
+    return [dump[offs[i]:offs[i + 1]].copy() for i in range(n)]
