@@ -1,0 +1,92 @@
+"""ctypes binding of libedison_hip.so -- the same C-ABI (include/edison_hip.h) any other FFI would bind.
+
+There is no Python/NumPy/torch implementation behind these calls and no fallback: if the shared library is
+missing the import of the binding raises, and if no gfx950 device is visible ``Context()`` raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libedison_hip.so")
+DEFAULT_MODEL = os.path.join(_HERE, "data", "kws_nnom.ednn")
+
+OK = 0
+E_ARGUMENT, E_LENGTH, E_SIZE, E_NO_MEMORY, E_MORE_TODO = -1, -2, -3, -7, -8
+E_RUNTIME, E_NO_IMPL, E_NO_DEVICE, E_NO_MODEL = -16, -17, -18, -19
+MFCC_A, MFCC_B, MFCC_USE_LOG = 0, 1, 0x100
+
+FS, FRAME_LEN, NUM_MEL, NUM_MFCC, UTT_FRAMES, NET_IN, NET_OUT = 16000, 1024, 32, 13, 31, 403, 10
+CNN_ACT_BYTES = 10420
+
+c_void_p, c_int, c_int64, c_size_t, c_float, c_double, c_char_p = (
+    ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float, ctypes.c_double, ctypes.c_char_p)
+
+# name -> (restype, argtypes): every symbol include/edison_hip.h declares
+SIGNATURES = {
+    "edison_init": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
+    "edison_shutdown": (None, [c_void_p]),
+    "edison_last_error": (c_char_p, [c_void_p]),
+    "edison_set_stream": (c_int, [c_void_p, c_void_p]),
+    "edison_sync": (c_int, [c_void_p]),
+    "edison_device_info": (c_int, [c_void_p, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
+    "edison_mfcc_configure": (c_int, [c_void_p, c_double, c_double, c_double, c_double]),
+    "edison_gen_mel_weight_matrix": (c_int, [c_int, c_int, c_double, c_double, c_double, c_void_p]),
+    "edison_model_load": (c_int, [c_void_p, c_char_p]),
+    "edison_model_load_mem": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "edison_dev_alloc": (c_int, [c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
+    "edison_dev_free": (c_int, [c_void_p, c_void_p]),
+    "edison_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "edison_dev_download": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "edison_mfcc_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_float]),
+    "edison_mfcc_stages_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
+    "edison_cnn_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "edison_cnn_layers_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "edison_kws_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_mfcc_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_float]),
+    "edison_mfcc_stages": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
+    "edison_cnn_batch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "edison_cnn_layers": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "edison_kws_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    # legacy firmware call surface
+    "aiInitialize": (c_int, []),
+    "aiGetInputShape": (None, [ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint16)]),
+    "aiRunInference": (c_int, [c_void_p, c_void_p]),
+    "aiGetKeywordFromIndex": (c_char_p, [ctypes.c_uint32]),
+    "aiGetKeywordCount": (ctypes.c_uint32, []),
+    "aiNnomInit": (None, []),
+    "aiNnomRunInference": (c_int, [c_void_p, c_void_p]),
+    "aiNnomPredict": (c_int, [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(c_float)]),
+    "aiNnomGetInputBuffer": (c_void_p, []),
+    "aiNnomGetOutputBuffer": (c_void_p, []),
+    "mfccToNetInput": (None, [c_void_p, ctypes.c_uint16, ctypes.c_uint16, ctypes.c_uint32]),
+    "mfccToNetInputPush": (None, [c_void_p, ctypes.c_uint16, ctypes.c_uint16]),
+    "edison_mfcc_frame": (c_int, [c_void_p, c_int, c_void_p]),
+    "edison_global_ctx": (c_void_p, []),
+}
+
+_lib = None
+
+
+class EdisonError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libedison_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load libedison_hip.so (once). Raises if it has not been built: there is nothing to fall back to."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                "%s is missing -- build it with `python -m edison_amd.build` (hipcc, gfx950). "
+                "edison_amd has no CPU implementation." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

@@ -1,0 +1,67 @@
+"""Build libedison_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m edison_amd.build [--force]
+
+Host-side C (tables.c, model.c, legacy.c) is compiled as C, the shim and the kernels as HIP; everything is
+linked into edison_amd/csrc/libedison_hip.so, which is what ctypes (edison_amd/_lib.py), cgo or any other
+FFI binds. The .so is git-ignored but travels with the tree to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(CSRC, "libedison_hip.so")
+C_SOURCES = ["tables.c", "model.c", "legacy.c"]
+HIP_SOURCES = ["edison_hip.hip", "mfcc_kernels.hip", "cnn_kernels.hip"]
+HEADERS = ["edison_internal.h", os.path.join("..", "..", "include", "edison_hip.h")]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libedison_hip.so cannot be built (there is no CPU fallback)")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in C_SOURCES + HIP_SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    hipcc = _hipcc()
+    bdir = os.path.join(CSRC, "build")
+    os.makedirs(bdir, exist_ok=True)
+    objs = []
+    common = ["-O3", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter"]
+    for src in C_SOURCES:
+        obj = os.path.join(bdir, src + ".o")
+        cmd = [hipcc, "-x", "c", "-std=gnu11"] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    for src in HIP_SOURCES:
+        obj = os.path.join(bdir, src + ".o")
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17"] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", OUT, "-lm", "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

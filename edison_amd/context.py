@@ -1,0 +1,178 @@
+"""Python handle on one libedison_hip context (one per process per GPU).
+
+Host arrays (numpy) go through the synchronous host-pointer entry points; torch CUDA tensors go through the
+``*_dev`` entry points on torch's current stream (PyTorch supplies device memory and streams only -- every
+computation is a hand-written HIP kernel behind the C-ABI).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import (CNN_ACT_BYTES, FRAME_LEN, MFCC_A, MFCC_B, MFCC_USE_LOG, NET_IN, NET_OUT, NUM_MEL, NUM_MFCC,
+                   UTT_FRAMES, EdisonError)
+
+KEYWORDS = ["edison", "cinema", "bedroom", "office", "livingroom", "kitchen", "on", "off", "_cold", "_noise"]
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _t_ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class Context:
+    def __init__(self, device=0, model_path=_lib.DEFAULT_MODEL):
+        self._L = _lib.lib()
+        h = ctypes.c_void_p()
+        r = self._L.edison_init(int(device), ctypes.byref(h))
+        if r != _lib.OK:
+            raise EdisonError(r, (self._L.edison_last_error(None) or b"").decode())
+        self._h = h
+        self.device = int(device)
+        if model_path is not None:
+            self.load_model(model_path)
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, r):
+        if r != _lib.OK:
+            raise EdisonError(r, (self._L.edison_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.edison_shutdown(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_model(self, path):
+        self._check(self._L.edison_model_load(self._h, str(path).encode()))
+
+    def load_model_bytes(self, blob):
+        buf = ctypes.create_string_buffer(bytes(blob), len(blob))
+        self._check(self._L.edison_model_load_mem(self._h, ctypes.cast(buf, ctypes.c_void_p), len(blob)))
+
+    def configure_mfcc(self, sample_rate=16000, lower_edge_hertz=80.0, upper_edge_hertz=7600.0, mel_mtx_scale=128):
+        self._check(self._L.edison_mfcc_configure(self._h, float(sample_rate), float(lower_edge_hertz),
+                                                  float(upper_edge_hertz), float(mel_mtx_scale)))
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(128)
+        ncu, hbm = ctypes.c_int(), ctypes.c_int64()
+        self._check(self._L.edison_device_info(self._h, name, 128, ctypes.byref(ncu), ctypes.byref(hbm)))
+        return dict(name=name.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
+
+    def use_torch_stream(self):
+        """Enqueue on torch's current CUDA stream of this context's device (needed before any *_t call)."""
+        import torch
+        s = torch.cuda.current_stream(self.device)
+        self._check(self._L.edison_set_stream(self._h, ctypes.c_void_p(s.cuda_stream)))
+
+    def sync(self):
+        self._check(self._L.edison_sync(self._h))
+
+    # ------------------------------------------------------------------ host (numpy) entry points
+    def mfcc(self, audio, n_frames=None, frame_step=FRAME_LEN, variant=MFCC_B, n_coef=NUM_MEL, use_log=False,
+             want_feat=False, feat_scale=1.0):
+        """audio: 1-D int16 stream -> fp32 [n_frames, n_coef] (and int8 net input if want_feat)."""
+        x = np.ascontiguousarray(audio, dtype=np.int16).ravel()
+        if n_frames is None:
+            n_frames = 1 + (x.shape[0] - FRAME_LEN) // frame_step if x.shape[0] >= FRAME_LEN else 0
+        if n_frames > 0 and (n_frames - 1) * frame_step + FRAME_LEN > x.shape[0]:
+            raise ValueError("audio too short for %d frames" % n_frames)
+        out = np.zeros((max(n_frames, 0), n_coef), np.float32)
+        feat = np.zeros((max(n_frames, 0), n_coef), np.int8) if want_feat else None
+        v = variant | (MFCC_USE_LOG if use_log else 0)
+        self._check(self._L.edison_mfcc_batch(self._h, _np_ptr(x), n_frames, frame_step, v, n_coef, _np_ptr(out),
+                                              _np_ptr(feat), float(feat_scale)))
+        return (out, feat) if want_feat else out
+
+    def mfcc_stages(self, audio, n_frames=None, frame_step=FRAME_LEN, variant=MFCC_B, use_log=False):
+        x = np.ascontiguousarray(audio, dtype=np.int16).ravel()
+        if n_frames is None:
+            n_frames = 1 + (x.shape[0] - FRAME_LEN) // frame_step if x.shape[0] >= FRAME_LEN else 0
+        if n_frames > 0 and (n_frames - 1) * frame_step + FRAME_LEN > x.shape[0]:
+            raise ValueError("audio too short for %d frames" % n_frames)
+        n = max(n_frames, 0)
+        fft = np.zeros((n, 513, 2), np.float32)
+        spec = np.zeros((n, 513), np.float32)
+        mel = np.zeros((n, 32), np.float32)
+        logmel = np.zeros((n, 32), np.float32)
+        mfcc = np.zeros((n, 32), np.float32)
+        v = variant | (MFCC_USE_LOG if use_log else 0)
+        self._check(self._L.edison_mfcc_stages(self._h, _np_ptr(x), n_frames, frame_step, v, _np_ptr(fft),
+                                               _np_ptr(spec), _np_ptr(mel), _np_ptr(logmel), _np_ptr(mfcc)))
+        return dict(fft=fft[..., 0] + 1j * fft[..., 1], spectrogram=spec, mel_spectrogram=mel,
+                    log_mel_spectrogram=logmel, mfcc=mfcc)
+
+    def cnn(self, feat):
+        f = np.ascontiguousarray(feat, dtype=np.int8).reshape(-1, NET_IN)
+        n = f.shape[0]
+        logits = np.zeros((n, NET_OUT), np.int8)
+        soft = np.zeros((n, NET_OUT), np.int8)
+        am = np.zeros(n, np.int32)
+        self._check(self._L.edison_cnn_batch(self._h, _np_ptr(f), n, _np_ptr(logits), _np_ptr(soft), _np_ptr(am)))
+        return dict(logits=logits, softmax=soft, argmax=am)
+
+    def cnn_layers(self, feat):
+        f = np.ascontiguousarray(feat, dtype=np.int8).reshape(-1, NET_IN)
+        n = f.shape[0]
+        acts = np.zeros((n, CNN_ACT_BYTES), np.int8)
+        self._check(self._L.edison_cnn_layers(self._h, _np_ptr(f), n, _np_ptr(acts)))
+        names = [("conv1", 3888), ("pool1", 1872), ("conv2", 2464), ("pool2", 1120), ("conv3", 960), ("conv4", 96),
+                 ("dense", 10), ("softmax", 10)]
+        out, off = {}, 0
+        for k, sz in names:
+            out[k] = acts[:, off:off + sz]
+            off += sz
+        return out
+
+    def kws(self, audio, n_utt=None, utt_stride=32000):
+        """audio: int16, utterance u starts at u*utt_stride and uses 31*1024 samples."""
+        x = np.ascontiguousarray(audio, dtype=np.int16).ravel()
+        used = UTT_FRAMES * FRAME_LEN
+        if n_utt is None:
+            n_utt = 0 if x.shape[0] < used else 1 + (x.shape[0] - used) // utt_stride
+        if n_utt > 0 and (n_utt - 1) * utt_stride + used > x.shape[0]:
+            raise ValueError("audio too short for %d utterances" % n_utt)
+        feat = np.zeros((n_utt, NET_IN), np.int8)
+        logits = np.zeros((n_utt, NET_OUT), np.int8)
+        soft = np.zeros((n_utt, NET_OUT), np.int8)
+        am = np.zeros(n_utt, np.int32)
+        self._check(self._L.edison_kws_batch(self._h, _np_ptr(x), n_utt, utt_stride, _np_ptr(feat), _np_ptr(logits),
+                                             _np_ptr(soft), _np_ptr(am)))
+        return dict(feat=feat, logits=logits, softmax=soft, argmax=am)
+
+    # ------------------------------------------------------------------ device (torch tensor) entry points
+    def mfcc_t(self, audio, n_frames, frame_step=FRAME_LEN, variant=MFCC_B, n_coef=NUM_MFCC, out=None, feat=None,
+               feat_scale=1.0, use_log=False):
+        """audio: int16 CUDA tensor; out: fp32 [n_frames, n_coef] CUDA tensor or None; feat: int8 or None."""
+        v = variant | (MFCC_USE_LOG if use_log else 0)
+        self._check(self._L.edison_mfcc_batch_dev(self._h, _t_ptr(audio), int(n_frames), int(frame_step), v, int(n_coef),
+                                                  _t_ptr(out), _t_ptr(feat), float(feat_scale)))
+
+    def cnn_t(self, feat, n_utt, logits=None, softmax=None, argmax=None):
+        self._check(self._L.edison_cnn_batch_dev(self._h, _t_ptr(feat), int(n_utt), _t_ptr(logits), _t_ptr(softmax),
+                                                 _t_ptr(argmax)))
+
+    def kws_t(self, audio, n_utt, utt_stride, feat=None, logits=None, softmax=None, argmax=None):
+        self._check(self._L.edison_kws_batch_dev(self._h, _t_ptr(audio), int(n_utt), int(utt_stride), _t_ptr(feat),
+                                                 _t_ptr(logits), _t_ptr(softmax), _t_ptr(argmax)))
+
+
+_default = None
+
+
+def default_context():
+    """Process-wide context on cuda:LOCAL_RANK (or 0); created on first use."""
+    global _default
+    if _default is None:
+        import os
+        _default = Context(int(os.environ.get("EDISON_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    return _default

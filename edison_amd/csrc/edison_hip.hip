@@ -1,0 +1,481 @@
+/*
+ * edison_hip.hip -- the thin C-ABI shim between the host-side C (tables.c, model.c, legacy.c) and the HIP
+ * kernels (mfcc_kernels.hip, cnn_kernels.hip). Implements include/edison_hip.h; see that header for the
+ * reference interface each entry point replaces.
+ *
+ * No CPU fallback lives here: every compute entry point ends in a kernel launch on a gfx950 device, and
+ * edison_init fails with EDISON_E_NO_DEVICE when there is none.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/edison_hip.h"
+#include "edison_internal.h"
+
+extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
+                              hipStream_t stream);
+extern "C" int ed_launch_cnn(const ed_cnn_model_t *dev_model, const int8_t *feat, int64_t n_utt, int8_t *logits,
+                             int8_t *softmax, int32_t *argmax, int8_t *acts, int n_cu, hipStream_t stream);
+
+struct edison_ctx
+{
+	int device;
+	int n_cu;
+	size_t hbm_bytes;
+	char name[128];
+	hipStream_t own_stream;
+	hipStream_t stream;
+	ed_mfcc_tables_t *d_tab[2]; /* variant A, B */
+	ed_cnn_model_t *d_model;
+	int have_model;
+	/* growable device scratch for the host-pointer entry points and the fused KWS path */
+	void *scratch;
+	size_t scratch_bytes;
+	char err[512];
+};
+
+static char g_init_err[512] = "";
+
+#define ED_HIP(ctx, call)                                                                                     \
+	do {                                                                                                      \
+		hipError_t e_ = (call);                                                                               \
+		if (e_ != hipSuccess)                                                                                 \
+		{                                                                                                     \
+			snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+			         __FILE__, __LINE__);                                                                     \
+			return EDISON_E_RUNTIME;                                                                          \
+		}                                                                                                     \
+	} while (0)
+
+static int set_err(edison_ctx *ctx, int code, const char *msg)
+{
+	if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
+	return code;
+}
+
+static int upload_tables(edison_ctx *ctx, double fs, double lo, double hi, double scale)
+{
+	for (int v = 0; v < 2; v++)
+	{
+		ed_mfcc_tables_t *h = (ed_mfcc_tables_t *)malloc(sizeof(ed_mfcc_tables_t));
+		if (!h) return set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed");
+		int r = ed_build_mfcc_tables(v, fs, lo, hi, scale, h, ctx->err, sizeof(ctx->err));
+		if (r != EDISON_OK) { free(h); return r; }
+		if (!ctx->d_tab[v]) ED_HIP(ctx, hipMalloc((void **)&ctx->d_tab[v], sizeof(ed_mfcc_tables_t)));
+		/* synchronous w.r.t. the stream: a kernel in flight may still be reading the old tables */
+		ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		hipError_t e = hipMemcpy(ctx->d_tab[v], h, sizeof(ed_mfcc_tables_t), hipMemcpyHostToDevice);
+		free(h);
+		ED_HIP(ctx, e);
+	}
+	return EDISON_OK;
+}
+
+extern "C" int edison_init(int device, edison_ctx **out)
+{
+	if (!out) return EDISON_E_ARGUMENT;
+	*out = NULL;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0)
+	{
+		snprintf(g_init_err, sizeof(g_init_err), "no HIP device visible (%s); libedison_hip has no CPU path",
+		         e == hipSuccess ? "count 0" : hipGetErrorString(e));
+		return EDISON_E_NO_DEVICE;
+	}
+	if (device < 0 || device >= n)
+	{
+		snprintf(g_init_err, sizeof(g_init_err), "device %d out of range (0..%d)", device, n - 1);
+		return EDISON_E_ARGUMENT;
+	}
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+	{
+		snprintf(g_init_err, sizeof(g_init_err), "hipGetDeviceProperties failed");
+		return EDISON_E_RUNTIME;
+	}
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+	{
+		snprintf(g_init_err, sizeof(g_init_err), "device %d is %s; this library is built for gfx950 only", device,
+		         prop.gcnArchName);
+		return EDISON_E_NO_DEVICE;
+	}
+	edison_ctx *ctx = (edison_ctx *)calloc(1, sizeof(edison_ctx));
+	if (!ctx) return EDISON_E_NO_MEMORY;
+	ctx->device = device;
+	ctx->n_cu = prop.multiProcessorCount;
+	ctx->hbm_bytes = prop.totalGlobalMem;
+	snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+	int r = EDISON_OK;
+	do {
+		if (hipSetDevice(device) != hipSuccess) { r = EDISON_E_RUNTIME; break; }
+		if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { r = EDISON_E_RUNTIME; break; }
+		ctx->stream = ctx->own_stream;
+		r = upload_tables(ctx, EDISON_FS, 80.0, 7600.0, 128.0); /* audio/config.py:14-15 */
+	} while (0);
+	if (r != EDISON_OK)
+	{
+		snprintf(g_init_err, sizeof(g_init_err), "edison_init: %s", ctx->err[0] ? ctx->err : "HIP setup failed");
+		edison_shutdown(ctx);
+		return r;
+	}
+	*out = ctx;
+	return EDISON_OK;
+}
+
+extern "C" void edison_shutdown(edison_ctx *ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	for (int v = 0; v < 2; v++) if (ctx->d_tab[v]) (void)hipFree(ctx->d_tab[v]);
+	if (ctx->d_model) (void)hipFree(ctx->d_model);
+	if (ctx->scratch) (void)hipFree(ctx->scratch);
+	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+	free(ctx);
+}
+
+extern "C" const char *edison_last_error(const edison_ctx *ctx) { return ctx ? ctx->err : g_init_err; }
+
+extern "C" int edison_set_stream(edison_ctx *ctx, void *hip_stream)
+{
+	if (!ctx) return EDISON_E_ARGUMENT;
+	ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+	return EDISON_OK;
+}
+
+extern "C" int edison_sync(edison_ctx *ctx)
+{
+	if (!ctx) return EDISON_E_ARGUMENT;
+	ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return EDISON_OK;
+}
+
+extern "C" int edison_device_info(edison_ctx *ctx, char *name, int name_cap, int *n_cu, int64_t *hbm_bytes)
+{
+	if (!ctx) return EDISON_E_ARGUMENT;
+	if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", ctx->name);
+	if (n_cu) *n_cu = ctx->n_cu;
+	if (hbm_bytes) *hbm_bytes = (int64_t)ctx->hbm_bytes;
+	return EDISON_OK;
+}
+
+extern "C" int edison_mfcc_configure(edison_ctx *ctx, double sample_rate, double lower_edge_hertz,
+                                     double upper_edge_hertz, double mel_mtx_scale)
+{
+	if (!ctx) return EDISON_E_ARGUMENT;
+	if (!(sample_rate > 0) || !(lower_edge_hertz >= 0) || !(upper_edge_hertz > lower_edge_hertz) ||
+	    !(upper_edge_hertz <= sample_rate / 2.0) || !(mel_mtx_scale > 0))
+		return set_err(ctx, EDISON_E_ARGUMENT, "edison_mfcc_configure: bad filterbank edges");
+	ED_HIP(ctx, hipSetDevice(ctx->device));
+	return upload_tables(ctx, sample_rate, lower_edge_hertz, upper_edge_hertz, mel_mtx_scale);
+}
+
+extern "C" int edison_gen_mel_weight_matrix(int num_mel_bins, int num_spectrogram_bins, double sample_rate,
+                                            double lower_edge_hertz, double upper_edge_hertz, double *W)
+{
+	return ed_gen_mel_weight_matrix(num_mel_bins, num_spectrogram_bins, sample_rate, lower_edge_hertz,
+	                                upper_edge_hertz, W);
+}
+
+extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t blob_bytes)
+{
+	if (!ctx || !blob) return EDISON_E_ARGUMENT;
+	ed_cnn_model_t *h = (ed_cnn_model_t *)malloc(sizeof(ed_cnn_model_t));
+	if (!h) return set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed");
+	int r = ed_parse_model(blob, blob_bytes, h, ctx->err, sizeof(ctx->err));
+	if (r != EDISON_OK) { free(h); return r; }
+	hipError_t e = hipSetDevice(ctx->device);
+	if (e == hipSuccess && !ctx->d_model) e = hipMalloc((void **)&ctx->d_model, sizeof(ed_cnn_model_t));
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	if (e == hipSuccess) e = hipMemcpy(ctx->d_model, h, sizeof(ed_cnn_model_t), hipMemcpyHostToDevice);
+	free(h);
+	ED_HIP(ctx, e);
+	ctx->have_model = 1;
+	return EDISON_OK;
+}
+
+extern "C" int edison_model_load(edison_ctx *ctx, const char *ednn_path)
+{
+	if (!ctx || !ednn_path) return EDISON_E_ARGUMENT;
+	FILE *f = fopen(ednn_path, "rb");
+	if (!f)
+	{
+		snprintf(ctx->err, sizeof(ctx->err), "cannot open model file %s", ednn_path);
+		return EDISON_E_ARGUMENT;
+	}
+	fseek(f, 0, SEEK_END);
+	long n = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	if (n <= 0 || n > (16L << 20)) { fclose(f); return set_err(ctx, EDISON_E_LENGTH, "model file has an implausible size"); }
+	void *buf = malloc((size_t)n);
+	if (!buf) { fclose(f); return set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed"); }
+	size_t got = fread(buf, 1, (size_t)n, f);
+	fclose(f);
+	int r = got == (size_t)n ? edison_model_load_mem(ctx, buf, (size_t)n) : set_err(ctx, EDISON_E_LENGTH, "short read on model file");
+	free(buf);
+	return r;
+}
+
+/* ---------------------------------------------------------------------------------------- device memory */
+extern "C" int edison_dev_alloc(edison_ctx *ctx, size_t bytes, void **dptr)
+{
+	if (!ctx || !dptr) return EDISON_E_ARGUMENT;
+	ED_HIP(ctx, hipSetDevice(ctx->device));
+	hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+	if (e == hipErrorOutOfMemory) return set_err(ctx, EDISON_E_NO_MEMORY, "hipMalloc: out of HBM");
+	ED_HIP(ctx, e);
+	return EDISON_OK;
+}
+extern "C" int edison_dev_free(edison_ctx *ctx, void *dptr)
+{
+	if (!ctx) return EDISON_E_ARGUMENT;
+	ED_HIP(ctx, hipFree(dptr));
+	return EDISON_OK;
+}
+extern "C" int edison_dev_upload(edison_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+	if (!ctx) return EDISON_E_ARGUMENT;
+	ED_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+	ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return EDISON_OK;
+}
+extern "C" int edison_dev_download(edison_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+	if (!ctx) return EDISON_E_ARGUMENT;
+	ED_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return EDISON_OK;
+}
+
+static int ensure_scratch(edison_ctx *ctx, size_t bytes)
+{
+	if (bytes <= ctx->scratch_bytes) return EDISON_OK;
+	ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (ctx->scratch) ED_HIP(ctx, hipFree(ctx->scratch));
+	ctx->scratch = NULL; ctx->scratch_bytes = 0;
+	hipError_t e = hipMalloc(&ctx->scratch, bytes);
+	if (e == hipErrorOutOfMemory) return set_err(ctx, EDISON_E_NO_MEMORY, "scratch hipMalloc: out of HBM");
+	ED_HIP(ctx, e);
+	ctx->scratch_bytes = bytes;
+	return EDISON_OK;
+}
+
+/* ---------------------------------------------------------------------------------------- hot path, device */
+static int mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
+                       int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
+                       int stages, float *fft, float *spec, float *mel, float *logmel)
+{
+	const int v = variant & 0xff;
+	if (!ctx || (!audio && n_frames > 0)) return EDISON_E_ARGUMENT;
+	if (v != EDISON_MFCC_A && v != EDISON_MFCC_B) return set_err(ctx, EDISON_E_ARGUMENT, "unknown MFCC variant");
+	if (n_coef < 1 || n_coef > EDISON_NUM_MEL) return set_err(ctx, EDISON_E_ARGUMENT, "n_coef must be 1..32");
+	if (n_frames < 0 || n_frames >= ((int64_t)1 << 31) || frame_step < 0 || fpg < 1)
+		return set_err(ctx, EDISON_E_ARGUMENT, "bad frame count / step");
+	if (n_frames == 0) return EDISON_OK;
+	ed_mfcc_args_t a;
+	memset(&a, 0, sizeof(a));
+	a.audio = audio; a.n_frames = n_frames; a.frames_per_group = fpg; a.group_stride = group_stride;
+	a.frame_step = frame_step; a.n_coef = n_coef; a.use_log = (variant & EDISON_MFCC_USE_LOG) ? 1 : 0;
+	a.mfcc = mfcc; a.feat = feat; a.feat_scale = feat_scale;
+	a.fft = fft; a.spec = spec; a.mel = mel; a.logmel = logmel;
+	int e = ed_launch_mfcc(&a, ctx->d_tab[v], stages, ctx->n_cu, ctx->stream);
+	if (e != 0)
+	{
+		snprintf(ctx->err, sizeof(ctx->err), "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+		return EDISON_E_RUNTIME;
+	}
+	return EDISON_OK;
+}
+
+extern "C" int edison_mfcc_batch_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step,
+                                     int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale)
+{
+	return mfcc_launch(ctx, audio, n_frames, n_frames > 0 ? n_frames : 1, 0, frame_step, variant, n_coef, mfcc, feat,
+	                   feat_scale, 0, NULL, NULL, NULL, NULL);
+}
+
+extern "C" int edison_mfcc_stages_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step,
+                                      int variant, float *fft, float *spec, float *mel, float *logmel, float *mfcc32)
+{
+	return mfcc_launch(ctx, audio, n_frames, n_frames > 0 ? n_frames : 1, 0, frame_step, variant, EDISON_NUM_MEL,
+	                   mfcc32, NULL, 1.0f, 1, fft, spec, mel, logmel);
+}
+
+static int cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *logits, int8_t *softmax,
+                      int32_t *argmax, int8_t *acts)
+{
+	if (!ctx || n_utt < 0 || (!feat && n_utt > 0)) return EDISON_E_ARGUMENT;
+	if (!ctx->have_model) return set_err(ctx, EDISON_E_NO_MODEL, "no CNN model loaded (edison_model_load)");
+	if (n_utt == 0) return EDISON_OK;
+	int e = ed_launch_cnn(ctx->d_model, feat, n_utt, logits, softmax, argmax, acts, ctx->n_cu, ctx->stream);
+	if (e != 0)
+	{
+		snprintf(ctx->err, sizeof(ctx->err), "CNN kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+		return EDISON_E_RUNTIME;
+	}
+	return EDISON_OK;
+}
+
+extern "C" int edison_cnn_batch_dev(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *logits,
+                                    int8_t *softmax, int32_t *argmax)
+{
+	return cnn_launch(ctx, feat, n_utt, logits, softmax, argmax, NULL);
+}
+
+extern "C" int edison_cnn_layers_dev(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *acts)
+{
+	if (!acts && n_utt > 0) return EDISON_E_ARGUMENT;
+	return cnn_launch(ctx, feat, n_utt, NULL, NULL, NULL, acts);
+}
+
+extern "C" int edison_kws_batch_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride,
+                                    int8_t *feat, int8_t *logits, int8_t *softmax, int32_t *argmax)
+{
+	if (!ctx || n_utt < 0 || (!audio && n_utt > 0)) return EDISON_E_ARGUMENT;
+	if (!ctx->have_model) return set_err(ctx, EDISON_E_NO_MODEL, "no CNN model loaded (edison_model_load)");
+	if (utt_stride < 0) return set_err(ctx, EDISON_E_ARGUMENT, "negative utterance stride");
+	if (n_utt == 0) return EDISON_OK;
+	if (n_utt * EDISON_UTT_FRAMES >= ((int64_t)1 << 31)) return set_err(ctx, EDISON_E_ARGUMENT, "too many utterances per call");
+	int8_t *f = feat;
+	if (!f)
+	{
+		int r = ensure_scratch(ctx, (size_t)n_utt * EDISON_NET_IN);
+		if (r != EDISON_OK) return r;
+		f = (int8_t *)ctx->scratch;
+	}
+	/* variant B, first 13 coefficients, scale 1 (nnom_net_input_scale, audio/config.py:41) */
+	int r = mfcc_launch(ctx, audio, n_utt * EDISON_UTT_FRAMES, EDISON_UTT_FRAMES, utt_stride, EDISON_FRAME_LEN,
+	                    EDISON_MFCC_B, EDISON_NUM_MFCC, NULL, f, 1.0f, 0, NULL, NULL, NULL, NULL);
+	if (r != EDISON_OK) return r;
+	return cnn_launch(ctx, f, n_utt, logits, softmax, argmax, NULL);
+}
+
+/* ---------------------------------------------------------------------------------------- hot path, host  */
+struct dev_buf
+{
+	void *p;
+	dev_buf() : p(NULL) {}
+	~dev_buf() { if (p) (void)hipFree(p); }
+	hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+
+#define ED_UP(ctx, dst, src, n) ED_HIP(ctx, hipMemcpyAsync((dst), (src), (n), hipMemcpyHostToDevice, (ctx)->stream))
+#define ED_DOWN(ctx, dst, src, n) \
+	do { if (dst) ED_HIP(ctx, hipMemcpyAsync((dst), (src), (n), hipMemcpyDeviceToHost, (ctx)->stream)); } while (0)
+
+static size_t audio_span(int64_t n_frames, int64_t frame_step) { return (size_t)((n_frames - 1) * frame_step + EDISON_FRAME_LEN); }
+
+extern "C" int edison_mfcc_batch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step,
+                                 int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale)
+{
+	if (!ctx || n_frames < 0 || (!audio && n_frames > 0) || frame_step < 0) return EDISON_E_ARGUMENT;
+	if (n_frames == 0) return EDISON_OK;
+	if (n_coef < 1 || n_coef > EDISON_NUM_MEL) return set_err(ctx, EDISON_E_ARGUMENT, "n_coef must be 1..32");
+	ED_HIP(ctx, hipSetDevice(ctx->device));
+	dev_buf a, m, q;
+	const size_t na = audio_span(n_frames, frame_step) * sizeof(int16_t);
+	ED_HIP(ctx, a.alloc(na));
+	if (mfcc) ED_HIP(ctx, m.alloc((size_t)n_frames * n_coef * sizeof(float)));
+	if (feat) ED_HIP(ctx, q.alloc((size_t)n_frames * n_coef));
+	ED_UP(ctx, a.p, audio, na);
+	int r = edison_mfcc_batch_dev(ctx, (const int16_t *)a.p, n_frames, frame_step, variant, n_coef, (float *)m.p,
+	                              (int8_t *)q.p, feat_scale);
+	if (r != EDISON_OK) return r;
+	ED_DOWN(ctx, mfcc, m.p, (size_t)n_frames * n_coef * sizeof(float));
+	ED_DOWN(ctx, feat, q.p, (size_t)n_frames * n_coef);
+	ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return EDISON_OK;
+}
+
+extern "C" int edison_mfcc_stages(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step,
+                                  int variant, float *fft, float *spec, float *mel, float *logmel, float *mfcc32)
+{
+	if (!ctx || n_frames < 0 || (!audio && n_frames > 0) || frame_step < 0) return EDISON_E_ARGUMENT;
+	if (n_frames == 0) return EDISON_OK;
+	ED_HIP(ctx, hipSetDevice(ctx->device));
+	dev_buf a, f, s, m, l, c;
+	const size_t na = audio_span(n_frames, frame_step) * sizeof(int16_t), n = (size_t)n_frames;
+	ED_HIP(ctx, a.alloc(na));
+	if (fft) ED_HIP(ctx, f.alloc(n * 513 * 2 * sizeof(float)));
+	if (spec) ED_HIP(ctx, s.alloc(n * 513 * sizeof(float)));
+	if (mel) ED_HIP(ctx, m.alloc(n * 32 * sizeof(float)));
+	if (logmel) ED_HIP(ctx, l.alloc(n * 32 * sizeof(float)));
+	if (mfcc32) ED_HIP(ctx, c.alloc(n * 32 * sizeof(float)));
+	ED_UP(ctx, a.p, audio, na);
+	int r = edison_mfcc_stages_dev(ctx, (const int16_t *)a.p, n_frames, frame_step, variant, (float *)f.p, (float *)s.p,
+	                               (float *)m.p, (float *)l.p, (float *)c.p);
+	if (r != EDISON_OK) return r;
+	ED_DOWN(ctx, fft, f.p, n * 513 * 2 * sizeof(float));
+	ED_DOWN(ctx, spec, s.p, n * 513 * sizeof(float));
+	ED_DOWN(ctx, mel, m.p, n * 32 * sizeof(float));
+	ED_DOWN(ctx, logmel, l.p, n * 32 * sizeof(float));
+	ED_DOWN(ctx, mfcc32, c.p, n * 32 * sizeof(float));
+	ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return EDISON_OK;
+}
+
+static int cnn_host(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *logits, int8_t *softmax,
+                    int32_t *argmax, int8_t *acts)
+{
+	if (!ctx || n_utt < 0 || (!feat && n_utt > 0)) return EDISON_E_ARGUMENT;
+	if (!ctx->have_model) return set_err(ctx, EDISON_E_NO_MODEL, "no CNN model loaded (edison_model_load)");
+	if (n_utt == 0) return EDISON_OK;
+	ED_HIP(ctx, hipSetDevice(ctx->device));
+	dev_buf f, l, s, a, t;
+	const size_t n = (size_t)n_utt;
+	ED_HIP(ctx, f.alloc(n * EDISON_NET_IN));
+	if (logits) ED_HIP(ctx, l.alloc(n * EDISON_NET_OUT));
+	if (softmax) ED_HIP(ctx, s.alloc(n * EDISON_NET_OUT));
+	if (argmax) ED_HIP(ctx, a.alloc(n * sizeof(int32_t)));
+	if (acts) ED_HIP(ctx, t.alloc(n * EDISON_CNN_ACT_BYTES));
+	ED_UP(ctx, f.p, feat, n * EDISON_NET_IN);
+	int r = cnn_launch(ctx, (const int8_t *)f.p, n_utt, (int8_t *)l.p, (int8_t *)s.p, (int32_t *)a.p, (int8_t *)t.p);
+	if (r != EDISON_OK) return r;
+	ED_DOWN(ctx, logits, l.p, n * EDISON_NET_OUT);
+	ED_DOWN(ctx, softmax, s.p, n * EDISON_NET_OUT);
+	ED_DOWN(ctx, argmax, a.p, n * sizeof(int32_t));
+	ED_DOWN(ctx, acts, t.p, n * EDISON_CNN_ACT_BYTES);
+	ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return EDISON_OK;
+}
+
+extern "C" int edison_cnn_batch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *logits, int8_t *softmax,
+                                int32_t *argmax)
+{
+	return cnn_host(ctx, feat, n_utt, logits, softmax, argmax, NULL);
+}
+
+extern "C" int edison_cnn_layers(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *acts)
+{
+	if (!acts && n_utt > 0) return EDISON_E_ARGUMENT;
+	return cnn_host(ctx, feat, n_utt, NULL, NULL, NULL, acts);
+}
+
+extern "C" int edison_kws_batch(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride,
+                                int8_t *feat, int8_t *logits, int8_t *softmax, int32_t *argmax)
+{
+	if (!ctx || n_utt < 0 || (!audio && n_utt > 0) || utt_stride < 0) return EDISON_E_ARGUMENT;
+	if (n_utt == 0) return EDISON_OK;
+	ED_HIP(ctx, hipSetDevice(ctx->device));
+	dev_buf au, f, l, s, a;
+	const size_t n = (size_t)n_utt;
+	const size_t na = ((size_t)(n_utt - 1) * (size_t)utt_stride + (size_t)EDISON_UTT_FRAMES * EDISON_FRAME_LEN) * sizeof(int16_t);
+	ED_HIP(ctx, au.alloc(na));
+	ED_HIP(ctx, f.alloc(n * EDISON_NET_IN));
+	if (logits) ED_HIP(ctx, l.alloc(n * EDISON_NET_OUT));
+	if (softmax) ED_HIP(ctx, s.alloc(n * EDISON_NET_OUT));
+	if (argmax) ED_HIP(ctx, a.alloc(n * sizeof(int32_t)));
+	ED_UP(ctx, au.p, audio, na);
+	int r = edison_kws_batch_dev(ctx, (const int16_t *)au.p, n_utt, utt_stride, (int8_t *)f.p, (int8_t *)l.p,
+	                             (int8_t *)s.p, (int32_t *)a.p);
+	if (r != EDISON_OK) return r;
+	ED_DOWN(ctx, feat, f.p, n * EDISON_NET_IN);
+	ED_DOWN(ctx, logits, l.p, n * EDISON_NET_OUT);
+	ED_DOWN(ctx, softmax, s.p, n * EDISON_NET_OUT);
+	ED_DOWN(ctx, argmax, a.p, n * sizeof(int32_t));
+	ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return EDISON_OK;
+}

@@ -1,0 +1,90 @@
+/*
+ * edison_internal.h -- shared between the host-side C (tables.c, model.c, legacy.c) and the HIP shim
+ * (edison_hip.hip, mfcc_kernels.hip, cnn_kernels.hip). Not part of the public C-ABI (include/edison_hip.h).
+ */
+#ifndef EDISON_INTERNAL_H
+#define EDISON_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ MFCC device tables (one per variant) */
+#define ED_MEL_T_MAX 40 /* tap-loop iterations per lane; the shipped filterbank needs 36 (widest band = 71 bins) */
+
+typedef struct {
+	/* 512-point complex FFT of the packed real frame, 3 radix-8 passes (see mfcc_kernels.hip) */
+	float tw1[64][8][2]; /* [lane][p]   W512^(lane*p), p = 0..7 (p = 0 unused)                               */
+	float tw2[8][8][2];  /* [c][q]      W64^(c*q)                                                            */
+	float twp[4][64][2]; /* [m][lane]   W1024^(lane+64m): real-FFT split twiddles                            */
+	/* mel filterbank, per-lane tap loop: lane = (j = lane&31, h = lane>>5) sums taps t of band j's half h   */
+	int32_t mel_start[64];
+	float mel_w[ED_MEL_T_MAX][64];
+	int32_t mel_T;
+	/* DCT-II with the variant's normalisation folded in: lane (c = lane&31, h) holds dct[n][lane], n<16,
+	 * = scale * 2*cos(pi*c*(2*(n+16h)+1)/64)                                                                */
+	float dct[16][64];
+	float spec_scale; /* applied to 2|X[k]|: A 0.5, B 0.5/1024/sqrt(2)                                       */
+	float log_offset; /* 1e-6                                                                                */
+	int32_t always_log; /* variant A                                                                         */
+	int32_t pad_;
+} ed_mfcc_tables_t;
+
+/* mfcc_utils.gen_mel_weight_matrix in float64 (W[nbins][nmel]); returns 0 or a negative EDISON_E_* code.   */
+int ed_gen_mel_weight_matrix(int num_mel_bins, int num_spectrogram_bins, double sample_rate,
+                             double lower_edge_hertz, double upper_edge_hertz, double *W);
+/* Build the device tables of one variant (0 = A, 1 = B). */
+int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hertz, double upper_edge_hertz,
+                         double mel_mtx_scale, ed_mfcc_tables_t *out, char *err, size_t err_cap);
+
+/* ------------------------------------------------------------------ int8 CNN model (kws_conv topology)   */
+/* Geometry of the one network this path accelerates (weights.h:138-161).                    */
+#define ED_IN_H 31
+#define ED_IN_W 13
+#define ED_C1_O 16  /* conv1 5x5x1  -> 27x9x16, pooled 13x9x16  */
+#define ED_C2_O 32  /* conv2 3x3x16 -> 11x7x32, pooled 5x7x32   */
+#define ED_C3_O 64  /* conv3 3x3x32 -> 3x5x64                   */
+#define ED_C4_O 32  /* conv4 3x3x64 -> 1x3x32                   */
+#define ED_FC_I 96
+#define ED_FC_O 10
+#define ED_CNN_ACT_BYTES 10420 /* == EDISON_CNN_ACT_BYTES */
+
+typedef struct {
+	/* weights re-laid for conflict-free LDS reads: dword (k4, o) = 4 consecutive k of output channel o,
+	 * k = (ky*KW + kx)*Cin + ci in OHWI order; conv1's K = 25 is zero-padded to 28                           */
+	int32_t w1[7][ED_C1_O];
+	int32_t w2[36][ED_C2_O];
+	int32_t w3[72][ED_C3_O];
+	int32_t w4[144][ED_C4_O];
+	int32_t wfc[24][16];      /* dense, rows 10..15 zero */
+	/* (bias << bias_lshift) + NN_ROUND(out_rshift), ready to seed the accumulator */
+	int32_t b1[ED_C1_O], b2[ED_C2_O], b3[ED_C3_O], b4[ED_C4_O], bfc[16];
+	int32_t rs1, rs2, rs3, rs4, rsfc; /* output right shifts */
+	int32_t pad_[3];
+} ed_cnn_model_t;
+
+int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, char *err, size_t err_cap);
+
+/* ------------------------------------------------------------------ kernel launchers (HIP side)           */
+typedef struct {
+	const int16_t *audio;
+	int64_t n_frames;
+	int64_t frames_per_group; /* frame f starts at (f / fpg) * group_stride + (f % fpg) * frame_step        */
+	int64_t group_stride;
+	int64_t frame_step;
+	int n_coef;
+	int use_log;
+	float *mfcc;      /* [n_frames][n_coef] or NULL */
+	int8_t *feat;     /* [n_frames][n_coef] or NULL */
+	float feat_scale;
+	/* stage dumps (diagnostic kernel only) */
+	float *fft, *spec, *mel, *logmel;
+} ed_mfcc_args_t;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

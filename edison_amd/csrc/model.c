@@ -1,0 +1,99 @@
+/*
+ * model.c -- host-side (plain C) loader of the int8 CNN parameters.
+ *
+ * Input: an .ednn blob (tools/import_weights_h.py) holding the numbers of an NNoM weights.h -- for the
+ * reference that is firmware/src/ai/nnom/kws_nnom/weights.h (arrays :3-45, shifts :50-105, graph :138-161).
+ * The GPU kernels are specialised for that graph (kws_conv: conv5x5x16 / pool(2,1) / conv3x3x32 / pool(2,1) /
+ * conv3x3x64 / conv3x3x32 / dense10 / softmax on a 31x13x1 input); a blob with any other topology is refused
+ * with EDISON_E_SIZE rather than run wrongly. Weight VALUES and all shifts are free (a retrained model loads).
+ *
+ * Output: ed_cnn_model_t -- weights as dwords [K/4][out_channel] (OHWI order inside K), accumulator seeds
+ * (bias << bias_lshift) + NN_ROUND(out_rshift) precomputed (arm_convolve_HWC_q7_basic_nonsquare.c:196).
+ */
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/edison_hip.h"
+#include "edison_internal.h"
+
+enum { T_CONV = 1, T_POOL = 2, T_DENSE = 3, T_SOFTMAX = 4 };
+
+typedef struct { int32_t v[12]; } rec_t;
+
+static int fail(char *err, size_t cap, const char *msg)
+{
+	if (err && cap) snprintf(err, cap, "%s", msg);
+	return EDISON_E_SIZE;
+}
+
+static int32_t seed(int8_t b, int bl, int rs) { return (int32_t)((uint32_t)(int32_t)b << bl) + (int32_t)((1u << rs) >> 1); }
+
+/* pack int8 weights w[O][K] (K padded to K4*4) into dwords out[K4][OS] (OS >= O, extra columns zero) */
+static void pack(const int8_t *w, int O, int K, int K4, int OS, int32_t *out)
+{
+	memset(out, 0, sizeof(int32_t) * (size_t)K4 * OS);
+	for (int o = 0; o < O; o++)
+		for (int k = 0; k < K; k++)
+		{
+			uint32_t byte = (uint32_t)(uint8_t)w[(size_t)o * K + k];
+			out[(size_t)(k / 4) * OS + o] |= (int32_t)(byte << (8 * (k % 4)));
+		}
+}
+
+int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, char *err, size_t err_cap)
+{
+	const unsigned char *p = (const unsigned char *)blob;
+	if (blob == NULL || blob_bytes < 40 || memcmp(p, "EDNNOM1\0", 8) != 0) return fail(err, err_cap, "not an .ednn model blob");
+	int32_t head[8];
+	memcpy(head, p + 8, sizeof(head));
+	const int in_h = head[0], in_w = head[1], in_c = head[2], n_layers = head[3], payload_bytes = head[4];
+	if (n_layers < 1 || n_layers > 64 || payload_bytes < 0 ||
+	    blob_bytes < 40 + (size_t)n_layers * 48 + (size_t)payload_bytes)
+		return fail(err, err_cap, "truncated .ednn model blob");
+	const int8_t *payload = (const int8_t *)(p + 40 + (size_t)n_layers * 48);
+
+	/* expected topology: type, out_ch, kh, kw, (stride 1 conv / stride == kernel pool), in_ch */
+	static const int expect[8][6] = {
+		{T_CONV, ED_C1_O, 5, 5, 1, 1}, {T_POOL, 0, 2, 1, 2, 1}, {T_CONV, ED_C2_O, 3, 3, 1, 1}, {T_POOL, 0, 2, 1, 2, 1},
+		{T_CONV, ED_C3_O, 3, 3, 1, 1}, {T_CONV, ED_C4_O, 3, 3, 1, 1}, {T_DENSE, ED_FC_O, 0, 0, 0, 0}, {T_SOFTMAX, 0, 0, 0, 0, 0}};
+	if (in_h != ED_IN_H || in_w != ED_IN_W || in_c != 1 || n_layers != 8)
+		return fail(err, err_cap, "model is not the 31x13x1 kws_conv graph this path accelerates");
+	rec_t r[8];
+	memcpy(r, p + 40, sizeof(r));
+	for (int i = 0; i < 8; i++)
+	{
+		const int32_t *v = r[i].v;
+		int ok = v[0] == expect[i][0];
+		if (ok && v[0] == T_CONV) ok = v[1] == expect[i][1] && v[2] == expect[i][2] && v[3] == expect[i][3] && v[4] == 1 && v[5] == 1 && v[8] == 1;
+		if (ok && v[0] == T_POOL) ok = v[2] == 2 && v[3] == 1 && v[4] == 2 && v[5] == 1;
+		if (ok && v[0] == T_DENSE) ok = v[1] == ED_FC_O && v[11] == ED_FC_I;
+		if (ok && (v[0] == T_CONV || v[0] == T_DENSE))
+			ok = v[6] >= 0 && v[6] < 24 && v[7] >= 0 && v[7] < 31 && v[9] >= 0 && v[10] >= 0 && v[9] < payload_bytes && v[10] < payload_bytes;
+		if (!ok) return fail(err, err_cap, "model layer list does not match the kws_conv graph (weights.h:138-161)");
+	}
+	static const int cin[8] = {1, 0, ED_C1_O, 0, ED_C2_O, ED_C3_O, 0, 0};
+	for (int i = 0; i < 8; i++)
+		if (r[i].v[0] == T_CONV)
+		{
+			if (r[i].v[11] != cin[i]) return fail(err, err_cap, "conv input channel count mismatch");
+			size_t need = (size_t)r[i].v[1] * r[i].v[2] * r[i].v[3] * cin[i];
+			if ((size_t)r[i].v[9] + need > (size_t)payload_bytes || (size_t)r[i].v[10] + (size_t)r[i].v[1] > (size_t)payload_bytes)
+				return fail(err, err_cap, "weight tensor outside the payload");
+		}
+	if ((size_t)r[6].v[9] + ED_FC_O * ED_FC_I > (size_t)payload_bytes || (size_t)r[6].v[10] + ED_FC_O > (size_t)payload_bytes)
+		return fail(err, err_cap, "dense tensor outside the payload");
+
+	memset(out, 0, sizeof(*out));
+	pack(payload + r[0].v[9], ED_C1_O, 25, 7, ED_C1_O, &out->w1[0][0]);
+	pack(payload + r[2].v[9], ED_C2_O, 144, 36, ED_C2_O, &out->w2[0][0]);
+	pack(payload + r[4].v[9], ED_C3_O, 288, 72, ED_C3_O, &out->w3[0][0]);
+	pack(payload + r[5].v[9], ED_C4_O, 576, 144, ED_C4_O, &out->w4[0][0]);
+	pack(payload + r[6].v[9], ED_FC_O, ED_FC_I, 24, 16, &out->wfc[0][0]);
+	for (int o = 0; o < ED_C1_O; o++) out->b1[o] = seed(payload[r[0].v[10] + o], r[0].v[6], r[0].v[7]);
+	for (int o = 0; o < ED_C2_O; o++) out->b2[o] = seed(payload[r[2].v[10] + o], r[2].v[6], r[2].v[7]);
+	for (int o = 0; o < ED_C3_O; o++) out->b3[o] = seed(payload[r[4].v[10] + o], r[4].v[6], r[4].v[7]);
+	for (int o = 0; o < ED_C4_O; o++) out->b4[o] = seed(payload[r[5].v[10] + o], r[5].v[6], r[5].v[7]);
+	for (int o = 0; o < ED_FC_O; o++) out->bfc[o] = seed(payload[r[6].v[10] + o], r[6].v[6], r[6].v[7]);
+	out->rs1 = r[0].v[7]; out->rs2 = r[2].v[7]; out->rs3 = r[4].v[7]; out->rs4 = r[5].v[7]; out->rsfc = r[6].v[7];
+	return EDISON_OK;
+}

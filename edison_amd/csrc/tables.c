@@ -1,0 +1,152 @@
+/*
+ * tables.c -- host-side (plain C) construction of the constant tables the MFCC kernel reads.
+ *
+ * Mirrors, for the two host MFCC variants of the reference:
+ *   gen_mel_weight_matrix   audio/edison/mfcc/mfcc_utils.py:36-73  (TF-style triangular weights, DC row zero)
+ *   hertz_to_mel            audio/edison/mfcc/mfcc_utils.py:30-34, constants audio/config.py:35-36
+ *   variant A scaling       mfcc_utils.py:171-193  (|fft|[:512], 512-bin matrix, ln(x+1e-6), dct2/sqrt(2*32))
+ *   variant B scaling       mfcc_utils.py:282-318  (fft/1024, |.|/sqrt2, 513-bin matrix, dct2 * 1/64)
+ *
+ * The device works on Z = FFT512(x[2n] + i*x[2n+1]) and on 2*X[k] (see mfcc_kernels.hip), so the factor 1/2
+ * of the real-FFT split is folded into spec_scale together with the variant's own normalisation.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/edison_hip.h"
+#include "edison_internal.h"
+
+#define MEL_HIGH_FREQUENCY_Q 1127.0
+#define MEL_BREAK_FREQUENCY_HERTZ 700.0
+
+static double hz2mel(double hz) { return MEL_HIGH_FREQUENCY_Q * log(1.0 + hz / MEL_BREAK_FREQUENCY_HERTZ); }
+
+/* np.linspace(a, b, n): a + i*step with step = (b-a)/(n-1); the endpoint is returned exactly */
+static void linspace(double a, double b, int n, double *out)
+{
+	double step = n > 1 ? (b - a) / (double)(n - 1) : 0.0;
+	for (int i = 0; i < n; i++) out[i] = (double)i * step + a;
+	if (n > 1) out[n - 1] = b;
+}
+
+int ed_gen_mel_weight_matrix(int num_mel_bins, int num_spectrogram_bins, double sample_rate,
+                             double lower_edge_hertz, double upper_edge_hertz, double *W)
+{
+	if (num_mel_bins < 1 || num_spectrogram_bins < 2 || W == NULL) return EDISON_E_ARGUMENT;
+	double *lin = (double *)malloc(sizeof(double) * (size_t)num_spectrogram_bins);
+	double *edge = (double *)malloc(sizeof(double) * (size_t)(num_mel_bins + 2));
+	if (!lin || !edge) { free(lin); free(edge); return EDISON_E_NO_MEMORY; }
+	linspace(0.0, sample_rate / 2.0, num_spectrogram_bins, lin);
+	linspace(hz2mel(lower_edge_hertz), hz2mel(upper_edge_hertz), num_mel_bins + 2, edge);
+	memset(W, 0, sizeof(double) * (size_t)num_mel_bins); /* the DC bin is excluded, then padded back as zeros */
+	for (int k = 1; k < num_spectrogram_bins; k++)
+	{
+		double m = hz2mel(lin[k]);
+		double *row = W + (size_t)k * num_mel_bins;
+		for (int j = 0; j < num_mel_bins; j++)
+		{
+			double up = (m - edge[j]) / (edge[j + 1] - edge[j]);
+			double dn = (edge[j + 2] - m) / (edge[j + 2] - edge[j + 1]);
+			double w = up < dn ? up : dn;
+			row[j] = w > 0.0 ? w : 0.0;
+		}
+	}
+	free(lin); free(edge);
+	return EDISON_OK;
+}
+
+int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hertz, double upper_edge_hertz,
+                         double mel_mtx_scale, ed_mfcc_tables_t *out, char *err, size_t err_cap)
+{
+	const int NMEL = EDISON_NUM_MEL;
+	const int nbins = (variant == EDISON_MFCC_A) ? EDISON_FRAME_LEN / 2 : EDISON_FRAME_LEN / 2 + 1;
+	if (variant != EDISON_MFCC_A && variant != EDISON_MFCC_B) return EDISON_E_ARGUMENT;
+	memset(out, 0, sizeof(*out));
+
+	/* --- FFT twiddles, rounded once from float64 */
+	for (int l = 0; l < 64; l++)
+		for (int p = 0; p < 8; p++)
+		{
+			double a = -2.0 * M_PI * (double)(l * p) / 512.0;
+			out->tw1[l][p][0] = (float)cos(a); out->tw1[l][p][1] = (float)sin(a);
+		}
+	for (int c = 0; c < 8; c++)
+		for (int q = 0; q < 8; q++)
+		{
+			double a = -2.0 * M_PI * (double)(c * q) / 64.0;
+			out->tw2[c][q][0] = (float)cos(a); out->tw2[c][q][1] = (float)sin(a);
+		}
+	for (int m = 0; m < 4; m++)
+		for (int l = 0; l < 64; l++)
+		{
+			double a = -2.0 * M_PI * (double)(l + 64 * m) / 1024.0;
+			out->twp[m][l][0] = (float)cos(a); out->twp[m][l][1] = (float)sin(a);
+		}
+
+	/* --- mel filterbank -> per-lane tap lists */
+	double *W = (double *)malloc(sizeof(double) * (size_t)nbins * NMEL);
+	if (!W) return EDISON_E_NO_MEMORY;
+	int r = ed_gen_mel_weight_matrix(NMEL, nbins, sample_rate, lower_edge_hertz, upper_edge_hertz, W);
+	if (r != EDISON_OK) { free(W); return r; }
+	/* variant B multiplies the matrix by mel_mtx_scale and divides the product by it again
+	 * (mfcc_utils.py:282,309); in float arithmetic that is the identity up to rounding, so the device
+	 * uses the unscaled matrix. mel_mtx_scale is accepted for signature compatibility. */
+	(void)mel_mtx_scale;
+	int T = 0;
+	int ks[EDISON_NUM_MEL], ke[EDISON_NUM_MEL];
+	for (int j = 0; j < NMEL; j++)
+	{
+		int first = -1, last = -1;
+		for (int k = 0; k < nbins; k++)
+			if (W[(size_t)k * NMEL + j] != 0.0) { if (first < 0) first = k; last = k; }
+		if (first < 0) { first = 0; last = -1; } /* empty band (degenerate edges) */
+		ks[j] = first; ke[j] = last + 1;
+		int half = (ke[j] - ks[j] + 1) / 2;
+		if (half > T) T = half;
+	}
+	if (T < 1) T = 1;
+	if (T > ED_MEL_T_MAX)
+	{
+		if (err) snprintf(err, err_cap, "mel band of %d bins exceeds the kernel's tap budget (%d per half)", 2 * T,
+		                  ED_MEL_T_MAX);
+		free(W);
+		return EDISON_E_NO_IMPL;
+	}
+	out->mel_T = T;
+	for (int l = 0; l < 64; l++)
+	{
+		int j = l & 31, h = l >> 5;
+		int half = (ke[j] - ks[j] + 1) / 2;
+		int a = h == 0 ? ks[j] : ks[j] + half;          /* this lane's taps: [a, b) */
+		int b = h == 0 ? ks[j] + half : ke[j];
+		if (b > ke[j]) b = ke[j];
+		int start = a;
+		if (start > 513 - T) start = 513 - T;             /* keep start + T - 1 <= 512 (the S buffer has 513) */
+		if (start < 0) start = 0;
+		out->mel_start[l] = start;
+		for (int t = 0; t < T; t++)
+		{
+			int k = start + t;
+			out->mel_w[t][l] = (k >= a && k < b && k < nbins) ? (float)W[(size_t)k * NMEL + j] : 0.0f;
+		}
+	}
+	free(W);
+
+	/* --- DCT-II (scipy.fftpack.dct type 2, norm=None: y[c] = 2*sum x[n] cos(pi*c*(2n+1)/(2N))) + scaling */
+	double dscale = (variant == EDISON_MFCC_A) ? 1.0 / sqrt(2.0 * (double)NMEL) : 1.0 / 64.0;
+	for (int l = 0; l < 64; l++)
+	{
+		int c = l & 31, h = l >> 5;
+		for (int n = 0; n < 16; n++)
+		{
+			int nn = n + 16 * h;
+			out->dct[n][l] = (float)(dscale * 2.0 * cos(M_PI * (double)c * (double)(2 * nn + 1) / (double)(2 * NMEL)));
+		}
+	}
+	out->spec_scale = (variant == EDISON_MFCC_A) ? 0.5f : (float)(0.5 / 1024.0 / sqrt(2.0));
+	out->log_offset = 1e-6f;
+	out->always_log = (variant == EDISON_MFCC_A) ? 1 : 0;
+	return EDISON_OK;
+}

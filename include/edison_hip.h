@@ -1,0 +1,176 @@
+/*
+ * include/edison_hip.h -- C-ABI of libedison_hip.so: edison's keyword-spotting hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary. Plain C, plain pointers and sizes, int return codes; no torch types.
+ * Every entry point names the reference interface it replaces (paths relative to the reference repo):
+ *
+ *   per-frame MFCC   audio/edison/mfcc/mfcc_utils.py:134 `mfcc` (variant A), :255 `mfcc_mcu` (variant B),
+ *                    :75 `batch_mfcc`; C call surface firmware/src/audioprocessing.h:21-22
+ *                    (`audioInit`, `audioCalcMFCCs`) and firmware/src/audio/mfcc.h:64-67 (`mfcc_compute`)
+ *   net-input glue   firmware/src/app.c:675-695 `mfccToNetInput`, :706-719 `mfccToNetInputPush`
+ *   int8 CNN         firmware/src/ai/ai.h:74-80 (`aiInitialize`, `aiGetInputShape`, `aiRunInference`,
+ *                    `aiGetKeywordFromIndex`, `aiGetKeywordCount`), firmware/src/ai/ai_nnom.c:64-132
+ *                    (`aiNnomInit`, `aiNnomRunInference`, `aiNnomPredict`, `aiNnomGet{Input,Output}Buffer`),
+ *                    model = firmware/src/ai/nnom/kws_nnom/weights.h
+ *
+ * The reference processes ONE frame / ONE utterance per call on a Cortex-M4 (or in a Python loop). The
+ * batched `edison_*_batch*` calls are the MI355X-native form of the same computation; the legacy names at
+ * the bottom are batch=1 wrappers with the reference's own signatures and ownership rules.
+ *
+ * Conventions
+ *   - return 0 (EDISON_OK == NNoM's NN_SUCCESS) or a negative code; edison_last_error() gives text.
+ *   - `_dev` calls take DEVICE pointers (hipMalloc / torch CUDA tensors) and enqueue on the context's
+ *     stream without synchronising; the others take HOST pointers and are synchronous.
+ *   - one context per process per GPU; calls on one context are serialised by the caller.
+ *   - there is NO CPU fallback: without a gfx950 device edison_init fails.
+ */
+#ifndef EDISON_HIP_H
+#define EDISON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants of the hot path (audio/config.py:11-32, firmware/src/ai/ai.h:55-60) ------------------ */
+#define EDISON_FS 16000
+#define EDISON_FRAME_LEN 1024          /* frame_length = fft_len = frame_step                            */
+#define EDISON_NUM_MEL 32              /* num_mel_bins                                                   */
+#define EDISON_NUM_MFCC 13             /* num_mfcc (first_mfcc = 0)                                      */
+#define EDISON_UTT_FRAMES 31           /* n_frames of a 2 s / 32000-sample utterance                     */
+#define EDISON_NET_IN (EDISON_UTT_FRAMES * EDISON_NUM_MFCC) /* 403 int8, HWC [31][13][1]                 */
+#define EDISON_NET_OUT 10
+
+/* ---- status codes: 0 and the negatives mirror nnom_status_t (firmware/src/ai/nnom/inc/nnom.h:34-45) -- */
+#define EDISON_OK 0                     /* NN_SUCCESS                                                    */
+#define EDISON_E_ARGUMENT (-1)          /* NN_ARGUMENT_ERROR                                             */
+#define EDISON_E_LENGTH (-2)            /* NN_LENGTH_ERROR                                               */
+#define EDISON_E_SIZE (-3)              /* NN_SIZE_MISMATCH: model blob does not have the kws_conv shape  */
+#define EDISON_E_NO_MEMORY (-7)         /* NN_NO_MEMORY (host or HBM allocation failed)                  */
+#define EDISON_E_MORE_TODO (-8)         /* NN_MORE_TODO                                                  */
+/* codes below have no NNoM counterpart */
+#define EDISON_E_RUNTIME (-16)          /* HIP error, text in edison_last_error()                        */
+#define EDISON_E_NO_IMPL (-17)          /* valid for the reference, not built on this path yet           */
+#define EDISON_E_NO_DEVICE (-18)        /* no gfx950 GPU visible: the product has no CPU path            */
+#define EDISON_E_NO_MODEL (-19)         /* CNN call before edison_model_load                             */
+
+/* ---- MFCC variants ----------------------------------------------------------- */
+#define EDISON_MFCC_A 0 /* mfcc_utils.mfcc    : fft[:512] -> |.| -> mel(512x32) -> ln(x+1e-6) -> dct2/sqrt(64) */
+#define EDISON_MFCC_B 1 /* mfcc_utils.mfcc_mcu: fft/1024 -> |.|/sqrt2 -> mel(513x32) -> [ln] -> dct2/64        */
+#define EDISON_MFCC_USE_LOG 0x100 /* OR into variant: mfcc_mcu(..., use_log=True)                       */
+
+typedef struct edison_ctx edison_ctx;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------------- */
+int edison_init(int device, edison_ctx **out);
+void edison_shutdown(edison_ctx *ctx);
+const char *edison_last_error(const edison_ctx *ctx); /* ctx may be NULL: last init error                */
+/* Use a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own. */
+int edison_set_stream(edison_ctx *ctx, void *hip_stream);
+int edison_sync(edison_ctx *ctx);
+int edison_device_info(edison_ctx *ctx, char *name, int name_cap, int *n_cu, int64_t *hbm_bytes);
+
+/* Mel filterbank parameters (defaults = audio/config.py). Rebuilds the device tables of both variants.
+ * num_mel_bins must be 32 and the frame length 1024 on this path (EDISON_E_NO_IMPL otherwise).          */
+int edison_mfcc_configure(edison_ctx *ctx, double sample_rate, double lower_edge_hertz, double upper_edge_hertz,
+                          double mel_mtx_scale);
+
+/* gen_mel_weight_matrix (mfcc_utils.py:36-73), host-side, float64: W[num_spectrogram_bins][num_mel_bins]. */
+int edison_gen_mel_weight_matrix(int num_mel_bins, int num_spectrogram_bins, double sample_rate,
+                                 double lower_edge_hertz, double upper_edge_hertz, double *W);
+
+/* Load the int8 CNN (an .ednn blob written by tools/import_weights_h.py from an NNoM weights.h).          */
+int edison_model_load(edison_ctx *ctx, const char *ednn_path);
+int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t blob_bytes);
+
+/* ---- device memory helpers (so a C caller needs nothing but this library) ---------------------------- */
+int edison_dev_alloc(edison_ctx *ctx, size_t bytes, void **dptr);
+int edison_dev_free(edison_ctx *ctx, void *dptr);
+int edison_dev_upload(edison_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int edison_dev_download(edison_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- the hot path, batched, device pointers ----------------------------------------------------------- */
+
+/*
+ * n_frames frames of 1024 int16 samples; frame i starts at audio + i*frame_step (samples; 1024 = the
+ * reference's hop, 512 = 50 % overlap). Writes the first n_coef (1..32) coefficients of every frame:
+ *   mfcc  [n_frames][n_coef] fp32            (may be NULL)
+ *   feat  [n_frames][n_coef] int8 net input  (may be NULL) = round_half_even(clip(mfcc*feat_scale,-128,127)),
+ *         the reference's np.clip(x*scale,-128,127).round().astype(int8) (kws_nnom.py:359-361)
+ * Replaces the per-frame loops mfcc_utils.py:160-197 (A) and :287-322 (B).
+ */
+int edison_mfcc_batch_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step,
+                          int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale);
+
+/*
+ * Same, plus every intermediate the reference returns in its per-frame dict (mfcc_utils.py:161-197):
+ *   fft   [n][513][2] fp32  un-normalised X[k], k=0..512 (re,im)      spec   [n][513] fp32 |X[k]| (A) or |X[k]|/1024/sqrt2 (B)
+ *   mel   [n][32] fp32 mel_spectrogram                                 logmel [n][32] fp32 log_mel_spectrogram
+ * Any of them may be NULL. This is the diagnostic path (parity tests, `main.py mfcc host`), not the fast one.
+ */
+int edison_mfcc_stages_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step,
+                           int variant, float *fft, float *spec, float *mel, float *logmel, float *mfcc32);
+
+/*
+ * n_utt feature maps [31][13] int8 (403 B each, HWC, as aiRunInference's in_data) ->
+ *   logits  [n_utt][10] int8 dense output      softmax [n_utt][10] int8 (= aiRunInference's out_data)
+ *   argmax  [n_utt] int32 first maximum of the softmax output (nnom_predict, nnom_utils.c:275-284)
+ * Each output may be NULL. Replaces model_run() (nnom.c:1037) over the graph of weights.h:138-161.
+ */
+int edison_cnn_batch_dev(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *logits, int8_t *softmax,
+                         int32_t *argmax);
+
+/* Per-layer activations of the CNN for parity tests: acts[n_utt][6496] = conv1+relu(3888) | pool1(1872) is
+ * not kept separately on the fast path, so this diagnostic entry runs the unfused kernels:
+ * conv1 3888 | pool1 1872 | conv2 2464 | pool2 1120 | conv3 960 | conv4 96 | dense 10 | softmax 10 = 10420 B. */
+#define EDISON_CNN_ACT_BYTES 10420
+int edison_cnn_layers_dev(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *acts);
+
+/*
+ * Full keyword spotting: utterance u = 31 frames of 1024 samples starting at audio + u*utt_stride (samples;
+ * the reference's utterances are 32000 samples of which 31*1024 are used, audio/config.py:12,25,31).
+ * Variant B features (the ones the net was trained on, kws_keras.py:47) -> int8 -> CNN.
+ * feat [n_utt][403] (may be NULL) receives the int8 net input.
+ */
+int edison_kws_batch_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride,
+                         int8_t *feat, int8_t *logits, int8_t *softmax, int32_t *argmax);
+
+/* ---- the same with HOST pointers (upload, run, download, synchronise) -------------------------------- */
+int edison_mfcc_batch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step, int variant,
+                      int n_coef, float *mfcc, int8_t *feat, float feat_scale);
+int edison_mfcc_stages(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step, int variant,
+                       float *fft, float *spec, float *mel, float *logmel, float *mfcc32);
+int edison_cnn_batch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *logits, int8_t *softmax,
+                     int32_t *argmax);
+int edison_cnn_layers(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *acts);
+int edison_kws_batch(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride, int8_t *feat,
+                     int8_t *logits, int8_t *softmax, int32_t *argmax);
+
+/* ---- legacy call surface of the reference firmware (batch = 1, process-global context) --------------- */
+/* firmware/src/ai/ai.h:74-80. aiInitialize() creates the global context on device $EDISON_DEVICE (default 0)
+ * and loads $EDISON_MODEL (default: kws_nnom.ednn next to the library). in_data: 403 int8, out_data: 10 int8. */
+int aiInitialize(void);
+void aiGetInputShape(uint16_t *x, uint16_t *y);
+int aiRunInference(void *in_data, void *out_data);
+const char *aiGetKeywordFromIndex(uint32_t idx);
+uint32_t aiGetKeywordCount(void);
+/* firmware/src/ai/ai_nnom.c:64-132 */
+void aiNnomInit(void);
+int aiNnomRunInference(void *in_data, void *out_data);
+int aiNnomPredict(uint32_t *label, float *prob);
+int8_t *aiNnomGetInputBuffer(void);
+int8_t *aiNnomGetOutputBuffer(void);
+/* firmware/src/app.c:152-153: write / push one frame's MFCCs into the process-global 403-byte net input
+ * (clip to [-128,127] after integer division by NNOM_INPUT_SCALE = 1, app.c:685-693).                    */
+void mfccToNetInput(int16_t *mfcc, uint16_t in_x, uint16_t in_y, uint32_t xoffset);
+void mfccToNetInputPush(int16_t *mfcc, uint16_t in_x, uint16_t in_y);
+/* One 1024-sample frame through the GPU MFCC (variant B float model of the firmware's Q15 path); out32 fp32. */
+int edison_mfcc_frame(const int16_t *frame1024, int variant, float *out32);
+edison_ctx *edison_global_ctx(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
