@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of edison's keyword-spotting hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One rank per GPU; every rank works on its own shard (weak scaling: per-GPU work is fixed as N grows).
+Two workloads of BASELINE.json are timed in the same run and reported on ONE JSON line:
+
+  * primary (`value`, `ms_per_step`, `roofline`): BASELINE configs[1] -- batched MFCC only, 65 536 x 1024-sample
+    synthetic int16 frames per GPU, variant B, 13 fp32 coefficients out. A step = one pass over the batch.
+    No collective (frames are independent).
+  * `kws`: BASELINE configs[2]/[3] -- full KWS, 262 144 utterances per GPU (31 frames each -> MFCC B -> int8
+    -> int8 CNN -> logits/softmax/argmax) followed, for N > 1, by the single RCCL all-gather of the int8 logits.
+
+Inputs are resident in HBM before the timed region. The MFCC batch (134 MB) would fit the 256 MiB Infinity
+Cache, so the bench rotates over several distinct batches to make every step read from HBM.
+Kernel time is taken with HIP events on the stream the kernels are launched on (torch's current stream, which
+the context is told to use); `roofline.achieved` = algorithmic bytes per launch / average launch duration.
+`cpu_baseline` times the oracle's C restatement (kind "port") on a bounded sample on rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch        # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFCC_BYTES_PER_FRAME = 2048 + 52  # 1024 int16 in + 13 fp32 out
+KWS_BYTES_PER_UTT = 63488 + 10 + 10 + 4  # 31*1024 int16 in + logits + softmax + argmax out
+
+
+def synth_frames(n_frames, seed, device, chunk=16384):
+    """clip(N(0, 3000^2)) + the two-tone of mfcc_on_mcu.py:314-315 with a random phase per frame -> int16."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty((n_frames, 1024), dtype=torch.int16, device=device)
+    t = torch.arange(1024, device=device, dtype=torch.float32) / 16000.0
+    for lo in range(0, n_frames, chunk):
+        n = min(chunk, n_frames - lo)
+        x = torch.randn((n, 1024), generator=g, device=device) * 3000.0
+        ph = torch.rand((n, 2), generator=g, device=device) * (2 * np.pi)
+        x += 1000.0 * torch.cos(2 * np.pi * 1000.0 * t[None, :] + ph[:, 0:1])
+        x += 500.0 * torch.cos(2 * np.pi * 125.0 * t[None, :] + ph[:, 1:2])
+        out[lo:lo + n] = x.clamp_(-32768, 32767).to(torch.int16)
+    return out
+
+
+def synth_utterances(n_utt, seed, device, chunk=4096):
+    """Mix of the three regimes of SURVEY.md 8(d): speech-level noise + two-tone (80 %), 1 %-FS noise (15 %),
+    silence (5 %); 31*1024 samples per utterance (the part of the 32000 the reference uses)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    L = 31 * 1024
+    out = torch.empty((n_utt, L), dtype=torch.int16, device=device)
+    t = torch.arange(L, device=device, dtype=torch.float32) / 16000.0
+    for lo in range(0, n_utt, chunk):
+        n = min(chunk, n_utt - lo)
+        kind = torch.rand((n, 1), generator=g, device=device)
+        amp = torch.where(kind < 0.80, 3000.0, torch.where(kind < 0.95, 327.67, 0.0))
+        x = torch.randn((n, L), generator=g, device=device) * amp
+        ph = torch.rand((n, 2), generator=g, device=device) * (2 * np.pi)
+        tone = 1000.0 * torch.cos(2 * np.pi * 1000.0 * t[None, :] + ph[:, 0:1]) + 500.0 * torch.cos(2 * np.pi * 125.0 * t[None, :] + ph[:, 1:2])
+        x += tone * (kind < 0.80)
+        out[lo:lo + n] = x.clamp_(-32768, 32767).to(torch.int16)
+    return out
+
+
+def timed_region(step_fn, steps, warmup, world):
+    """W untimed + exactly K timed steps, barrier + synchronize on both sides; returns (wall ms/step, event ms/step)."""
+    for i in range(warmup):
+        step_fn(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(steps):
+        step_fn(warmup + i)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3 / steps
+    ev = e0.elapsed_time(e1) / steps
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+    return wall, ev
+
+
+def cpu_baseline(n_threads):
+    """The oracle's C restatement (checker code, timed here only as the reported CPU baseline)."""
+    from oracle import oracle
+    oracle.build()
+    rng = np.random.default_rng(20)
+    res = {}
+    # MFCC variant B, float64 like the reference's numpy path; sample sized for ~10 s
+    n = 4096
+    x = np.clip(rng.normal(0, 3000, n * 1024), -32768, 32767).astype(np.int16)
+    t0 = time.perf_counter(); oracle.mfcc(x, oracle.VARIANT_B, n_threads=n_threads); dt = time.perf_counter() - t0
+    reps = max(1, min(64, int(8.0 / max(dt, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        oracle.mfcc(x, oracle.VARIANT_B, n_threads=n_threads)
+    dt = (time.perf_counter() - t0) / reps
+    res["mfcc"] = dict(value=n / dt, unit="frames/s", cores=n_threads, kind="port",
+                       sample="%d frames x %d passes, oracle/mfcc_ref.c variant B float64, %d OpenMP threads" % (n, reps, n_threads))
+    # full KWS: MFCC B + int8 CNN restatement, all threads
+    nu = 256
+    a = np.clip(rng.normal(0, 3000, nu * 31744), -32768, 32767).astype(np.int16)
+    model = oracle.Model()
+
+    def kws_once():
+        m = oracle.mfcc(a, oracle.VARIANT_B, n_threads=n_threads)[:, :13]
+        f = oracle.net_input(m).reshape(nu, 403)
+        return oracle.cnn(model, f, n_threads=n_threads)
+    t0 = time.perf_counter(); kws_once(); dt = time.perf_counter() - t0
+    reps = max(1, min(32, int(8.0 / max(dt, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        kws_once()
+    dt = (time.perf_counter() - t0) / reps
+    res["kws"] = dict(value=nu / dt, unit="inferences/s", cores=n_threads, kind="port",
+                      sample="%d utterances x %d passes, oracle MFCC B + int8 CNN restatement, %d OpenMP threads" % (nu, reps, n_threads))
+    if oracle.have_ref():
+        f = rng.integers(-128, 128, (2000, 403)).astype(np.int8)
+        t0 = time.perf_counter(); oracle.nnom_ref_batch(f); dt = time.perf_counter() - t0
+        res["cnn_reference"] = dict(value=2000 / dt, unit="inferences/s", cores=1, kind="reference",
+                                    sample="2000 random inputs, reference NNoM 0.3.0 + CMSIS-NN + weights.h (oracle/_ref), CNN only, 1 thread")
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=65536, help="MFCC frames per GPU per step (BASELINE configs[1])")
+    ap.add_argument("--utts", type=int, default=262144, help="KWS utterances per GPU per step (BASELINE configs[2])")
+    ap.add_argument("--rotate", type=int, default=3, help="distinct MFCC input batches cycled through (defeats the 256 MiB L3)")
+    ap.add_argument("--skip-kws", action="store_true")
+    ap.add_argument("--skip-cpu", action="store_true")
+    args = ap.parse_args()
+
+    from edison_amd import parallel, _lib
+    from edison_amd.context import Context
+    rank, world, local_rank = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ctx = Context(local_rank)
+    # one explicit stream for everything: torch fills, the HIP kernels behind the C-ABI, the HIP events, RCCL
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx.use_torch_stream(stream)
+    info = ctx.device_info()
+
+    # ------------------------------------------------------------------ primary: MFCC only (configs[1])
+    nf = args.frames
+    bufs = [synth_frames(nf, 20 + 1000 * r + rank, dev) for r in range(max(1, args.rotate))]
+    out = torch.empty((nf, 13), dtype=torch.float32, device=dev)
+
+    def mfcc_step(i):
+        ctx.mfcc_t(bufs[i % len(bufs)], nf, 1024, _lib.MFCC_B, 13, out=out)
+    wall_ms, ev_ms = timed_region(mfcc_step, args.steps, args.warmup, world)
+    frames_per_s = world * nf / (wall_ms * 1e-3)
+    ach = MFCC_BYTES_PER_FRAME * nf / (ev_ms * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel="ed_mfcc_kernel<false>", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, bytes_per_unit=MFCC_BYTES_PER_FRAME,
+                    units_per_launch=nf, kernel_ms=round(ev_ms, 4))
+    checksum = float(out.double().sum().item())
+    del bufs
+
+    # ------------------------------------------------------------------ kws: MFCC + int8 CNN (+ all-gather) (configs[2]/[3])
+    kws = None
+    if not args.skip_kws:
+        nu = args.utts
+        audio = synth_utterances(nu, 21 + rank, dev)
+        logits = torch.empty((nu, 10), dtype=torch.int8, device=dev)
+        soft = torch.empty((nu, 10), dtype=torch.int8, device=dev)
+        am = torch.empty((nu,), dtype=torch.int32, device=dev)
+        feat = torch.empty((nu, 403), dtype=torch.int8, device=dev)
+        gather = parallel.LogitsGatherer(nu, 10, device=dev) if world > 1 else None
+
+        def kws_step(i):
+            ctx.kws_t(audio, nu, 31 * 1024, feat=feat, logits=logits, softmax=soft, argmax=am)
+            if gather is not None:
+                gather(logits)
+        kw_ms, kev_ms = timed_region(kws_step, args.steps, args.warmup, world)
+        inf_per_s = world * nu / (kw_ms * 1e-3)
+        kach = KWS_BYTES_PER_UTT * nu / (kev_ms * 1e-3) / 1e9
+        hist = torch.bincount(am.to(torch.int64), minlength=10).tolist()
+        kws = dict(metric="KWS inferences/sec (whole node)", value=round(inf_per_s, 1), unit="inferences/s",
+                   mfcc_frames_per_s=round(inf_per_s * 31, 1), ms_per_step=round(kw_ms, 4),
+                   config=dict(workload="kws_full_%d_utt_per_gpu_x31_frames_mfccB_int8cnn" % nu, global_batch=world * nu,
+                               collective="all_gather int8 logits (RCCL)" if world > 1 else "none"),
+                   roofline=dict(bound="hbm", kernel="ed_mfcc_kernel<false> + ed_cnn_kernel<false>", achieved=round(kach, 1),
+                                 peak=HBM_PEAK_GBS, unit="GB/s", frac=round(kach / HBM_PEAK_GBS, 4), traffic=None,
+                                 bytes_per_unit=KWS_BYTES_PER_UTT, units_per_launch=nu, kernel_ms=round(kev_ms, 4)),
+                   class_histogram=hist)
+        del audio
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        try:
+            n_threads = min(len(os.sched_getaffinity(0)), 16)
+            cpu = cpu_baseline(n_threads)
+        except Exception as e:  # the baseline is a report, never a reason to lose the GPU numbers
+            cpu = dict(error=repr(e))
+
+    if rank == 0:
+        line = dict(metric="MFCC frames/sec + KWS inferences/sec (whole node) at 1/2/4/8 MI355X",
+                    value=round(frames_per_s, 1), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                    ms_per_step=round(wall_ms, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+                    dtype="f32", data="synthetic",
+                    config=dict(workload="mfcc_batch_%dx1024_int16_per_gpu_variantB_13coef" % nf, global_batch=world * nf,
+                                frame_len=1024, parallelism="dp%d" % world, rotate_buffers=args.rotate),
+                    roofline=roofline, device=info["name"], checksum=checksum)
+        if kws is not None:
+            line["kws"] = kws
+        if cpu is not None:
+            if "mfcc" in cpu:
+                line["cpu_baseline"] = cpu["mfcc"]
+                line["cpu_baseline_kws"] = cpu.get("kws")
+                if "cnn_reference" in cpu:
+                    line["cpu_baseline_cnn_reference"] = cpu["cnn_reference"]
+            else:
+                line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,7 @@ SIGNATURES = {
     "edison_shutdown": (None, [c_void_p]),
     "edison_last_error": (c_char_p, [c_void_p]),
     "edison_set_stream": (c_int, [c_void_p, c_void_p]),
+    "edison_reset_stream": (c_int, [c_void_p]),
     "edison_sync": (c_int, [c_void_p]),
     "edison_device_info": (c_int, [c_void_p, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
     "edison_mfcc_configure": (c_int, [c_void_p, c_double, c_double, c_double, c_double]),

@@ -68,11 +68,15 @@ class Context:
         self._check(self._L.edison_device_info(self._h, name, 128, ctypes.byref(ncu), ctypes.byref(hbm)))
         return dict(name=name.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
 
-    def use_torch_stream(self):
-        """Enqueue on torch's current CUDA stream of this context's device (needed before any *_t call)."""
+    def use_torch_stream(self, stream=None):
+        """Enqueue on a torch CUDA stream (default: torch's current stream of this device). Call it before the
+        *_t entry points so the kernels are ordered with the torch ops that produce / consume the tensors."""
         import torch
-        s = torch.cuda.current_stream(self.device)
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
         self._check(self._L.edison_set_stream(self._h, ctypes.c_void_p(s.cuda_stream)))
+
+    def use_own_stream(self):
+        self._check(self._L.edison_reset_stream(self._h))
 
     def sync(self):
         self._check(self._L.edison_sync(self._h))

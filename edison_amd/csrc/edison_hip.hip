@@ -129,7 +129,7 @@ extern "C" void edison_shutdown(edison_ctx *ctx)
 {
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
-	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	(void)hipDeviceSynchronize();
 	for (int v = 0; v < 2; v++) if (ctx->d_tab[v]) (void)hipFree(ctx->d_tab[v]);
 	if (ctx->d_model) (void)hipFree(ctx->d_model);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -142,7 +142,14 @@ extern "C" const char *edison_last_error(const edison_ctx *ctx) { return ctx ? c
 extern "C" int edison_set_stream(edison_ctx *ctx, void *hip_stream)
 {
 	if (!ctx) return EDISON_E_ARGUMENT;
-	ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+	ctx->stream = (hipStream_t)hip_stream; /* NULL = HIP's default stream */
+	return EDISON_OK;
+}
+
+extern "C" int edison_reset_stream(edison_ctx *ctx)
+{
+	if (!ctx) return EDISON_E_ARGUMENT;
+	ctx->stream = ctx->own_stream;
 	return EDISON_OK;
 }
 

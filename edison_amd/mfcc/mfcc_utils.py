@@ -1,0 +1,155 @@
+"""Host-side mirror of the reference's ``audio/edison/mfcc/mfcc_utils.py`` -- same function names, positional
+arguments, return structures and quirks, with the per-frame arithmetic done by the HIP kernels behind the
+C-ABI (``libedison_hip.so``) instead of numpy/scipy. Callers of the reference (mfcc.py:188-190,
+kws_keras.py:450, kws_on_mcu.py:293,343,...) can import this module in its place.
+
+  frames                  mfcc_utils.py:16-27     (pure indexing, stays on the host)
+  hertz_to_mel            mfcc_utils.py:30-34
+  gen_mel_weight_matrix   mfcc_utils.py:36-73     -> edison_gen_mel_weight_matrix (host C, float64)
+  batch_mfcc              mfcc_utils.py:75-131    -> edison_mfcc_batch, variant A
+  mfcc                    mfcc_utils.py:134-199   -> edison_mfcc_stages, variant A
+  mfcc_mcu                mfcc_utils.py:255-323   -> edison_mfcc_stages, variant B
+
+Not mirrored: ``mfcc_tf`` (needs TensorFlow; comparison-only) and ``dct2Makhoul`` (helper of the board tools).
+
+The GPU path is specialised for the reference's shipped geometry: 1024-sample frames and 32 mel bins
+(audio/config.py:15,19). Other values raise NotImplementedError rather than silently taking another path.
+The returned arrays are float32 promoted to float64 (the reference computes in float64); see DESIGN.md for
+the measured tolerance.
+"""
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+from .. import config as _cfg
+from ..context import default_context
+
+MEL_HIGH_FREQUENCY_Q = _cfg.MEL_HIGH_FREQUENCY_Q
+MEL_BREAK_FREQUENCY_HERTZ = _cfg.MEL_BREAK_FREQUENCY_HERTZ
+
+
+def frames(data, frame_length=3, frame_step=1):
+    """Split a data vector into (possibly overlapping) frames (mfcc_utils.py:16-27)."""
+    data = np.asarray(data)
+    n_frames = 1 + (data.shape[0] - frame_length) // frame_step
+    out = np.zeros((n_frames, frame_length))
+    for i in range(n_frames):
+        out[i] = data[i * frame_step:i * frame_step + frame_length]
+    return out
+
+
+def hertz_to_mel(frequencies_hertz):
+    """Hertz -> mel (mfcc_utils.py:30-34)."""
+    return MEL_HIGH_FREQUENCY_Q * np.log(1.0 + (frequencies_hertz / MEL_BREAK_FREQUENCY_HERTZ))
+
+
+def gen_mel_weight_matrix(num_mel_bins=20, num_spectrogram_bins=129, sample_rate=8000,
+                          lower_edge_hertz=125.0, upper_edge_hertz=3800.0):
+    """[num_spectrogram_bins, num_mel_bins] float64 triangular mel weights, DC row zero (mfcc_utils.py:36-73)."""
+    W = np.zeros((int(num_spectrogram_bins), int(num_mel_bins)), np.float64)
+    r = _lib.lib().edison_gen_mel_weight_matrix(int(num_mel_bins), int(num_spectrogram_bins), float(sample_rate),
+                                                float(lower_edge_hertz), float(upper_edge_hertz),
+                                                W.ctypes.data_as(ctypes.c_void_p))
+    if r != _lib.OK:
+        raise _lib.EdisonError(r, "edison_gen_mel_weight_matrix")
+    return W
+
+
+_configured = None
+
+
+def _prepare(fs, frame_len, mel_nbins, mel_lower_hz, mel_upper_hz, mel_mtx_scale=128):
+    global _configured
+    if frame_len != _lib.FRAME_LEN or mel_nbins != _lib.NUM_MEL:
+        raise NotImplementedError("the MI355X path implements the reference configuration frame_len=1024, "
+                                  "mel_nbins=32 (audio/config.py:15,19); got frame_len=%r mel_nbins=%r"
+                                  % (frame_len, mel_nbins))
+    ctx = default_context()
+    key = (float(fs), float(mel_lower_hz), float(mel_upper_hz), float(mel_mtx_scale))
+    default = (16000.0, 80.0, 7600.0, 128.0)
+    if key != (_configured or default):
+        ctx.configure_mfcc(*key)
+        _configured = key
+    return ctx
+
+
+def _frame_count(frame_count, nSamples, frame_len, frame_step):
+    if frame_count == 0:
+        frame_count = 1 + (nSamples - frame_len) // frame_step  # mfcc_utils.py:154-155
+    return int(frame_count)
+
+
+def _as_int16(data):
+    a = np.asarray(data)
+    if a.dtype != np.int16:
+        if np.issubdtype(a.dtype, np.floating) and not np.all(a == np.round(a)):
+            raise ValueError("the GPU path takes 16-bit PCM samples (the reference's 16 kHz/16 bit input)")
+        if a.size and (a.min() < -32768 or a.max() > 32767):
+            raise ValueError("sample values outside int16")
+        a = a.astype(np.int16)
+    return np.ascontiguousarray(a)
+
+
+def batch_mfcc(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, mel_nbins, mel_lower_hz, mel_upper_hz):
+    """Variant A over data[..., samples]; returns [n, frame_count, mel_nbins] (mfcc_utils.py:75-131)."""
+    ctx = _prepare(fs, frame_len, mel_nbins, mel_lower_hz, mel_upper_hz)
+    frame_count = _frame_count(frame_count, nSamples, frame_len, frame_step)
+    data = _as_int16(data)
+    print("Running mfcc for %d frames with %d step on %d samples" % (frame_count, frame_step, data.shape[0]))
+    output = np.zeros((data.shape[0], frame_count, mel_nbins))
+    for i in range(data.shape[0]):  # one C-ABI call per row keeps rows of any length independent
+        output[i] = ctx.mfcc(data[i], n_frames=frame_count, frame_step=frame_step, variant=_lib.MFCC_A, n_coef=mel_nbins)
+    return output
+
+
+def mfcc(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, mel_nbins, mel_lower_hz, mel_upper_hz,
+         dummy=None):
+    """Variant A; list of per-frame dicts with the reference's keys (mfcc_utils.py:134-199)."""
+    ctx = _prepare(fs, frame_len, mel_nbins, mel_lower_hz, mel_upper_hz)
+    frame_count = _frame_count(frame_count, nSamples, frame_len, frame_step)
+    st = ctx.mfcc_stages(_as_int16(data), n_frames=frame_count, frame_step=frame_step, variant=_lib.MFCC_A)
+    W = gen_mel_weight_matrix(num_mel_bins=mel_nbins, num_spectrogram_bins=frame_len // 2, sample_rate=fs,
+                              lower_edge_hertz=mel_lower_hz, upper_edge_hertz=mel_upper_hz)
+    output = []
+    for f in range(frame_count):
+        frame = {}
+        frame['t_start'] = f * frame_step / fs
+        frame['t_end'] = (f * frame_step + frame_len) / fs
+        frame['fft'] = st['fft'][f, :frame_len // 2].astype(np.complex128)
+        frame['spectrogram'] = st['spectrogram'][f, :frame_len // 2].astype(np.float64)
+        frame['mel_weight_matrix'] = W
+        frame['mel_spectrogram'] = st['mel_spectrogram'][f].astype(np.float64)
+        frame['log_mel_spectrogram'] = st['log_mel_spectrogram'][f].astype(np.float64)
+        frame['mfcc'] = st['mfcc'][f].astype(np.float64)
+        output.append(frame)
+    return output
+
+
+def mfcc_mcu(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, mel_nbins, mel_lower_hz, mel_upper_hz,
+             mel_mtx_scale, use_log=False):
+    """Variant B (the features the net was trained on); list of per-frame dicts (mfcc_utils.py:255-323)."""
+    ctx = _prepare(fs, frame_len, mel_nbins, mel_lower_hz, mel_upper_hz, mel_mtx_scale)
+    frame_count = _frame_count(frame_count, nSamples, frame_len, frame_step)
+    st = ctx.mfcc_stages(_as_int16(data), n_frames=frame_count, frame_step=frame_step, variant=_lib.MFCC_B,
+                         use_log=use_log)
+    W = mel_mtx_scale * gen_mel_weight_matrix(num_mel_bins=mel_nbins, num_spectrogram_bins=frame_len // 2 + 1,
+                                              sample_rate=fs, lower_edge_hertz=mel_lower_hz,
+                                              upper_edge_hertz=mel_upper_hz)
+    half = frame_len // 2
+    output = []
+    for f in range(frame_count):
+        frame = {}
+        frame['t_start'] = f * frame_step / fs
+        frame['t_end'] = (f * frame_step + frame_len) / fs
+        # full-length spectrum of a real signal from its 513 unique bins (conjugate symmetry)
+        X = st['fft'][f].astype(np.complex128)
+        frame['fft'] = 1.0 / 1024 * np.concatenate([X, np.conj(X[half - 1:0:-1])])
+        s = st['spectrogram'][f].astype(np.float64)
+        frame['spectrogram'] = np.concatenate([s, s[half - 1:0:-1]])
+        frame['mel_weight_matrix'] = W
+        frame['mel_spectrogram'] = st['mel_spectrogram'][f].astype(np.float64)
+        frame['log_mel_spectrogram'] = st['log_mel_spectrogram'][f].astype(np.float64)
+        frame['mfcc'] = st['mfcc'][f].astype(np.float64)
+        output.append(frame)
+    return output

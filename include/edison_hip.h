@@ -67,8 +67,11 @@ typedef struct edison_ctx edison_ctx;
 int edison_init(int device, edison_ctx **out);
 void edison_shutdown(edison_ctx *ctx);
 const char *edison_last_error(const edison_ctx *ctx); /* ctx may be NULL: last init error                */
-/* Use a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own. */
+/* Enqueue on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). The handle is used as
+ * given: NULL is HIP's default (null) stream, NOT "no stream". edison_reset_stream returns to the context's own
+ * private non-blocking stream (the state after edison_init). */
 int edison_set_stream(edison_ctx *ctx, void *hip_stream);
+int edison_reset_stream(edison_ctx *ctx);
 int edison_sync(edison_ctx *ctx);
 int edison_device_info(edison_ctx *ctx, char *name, int name_cap, int *n_cu, int64_t *hbm_bytes);
 

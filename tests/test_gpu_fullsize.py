@@ -1,0 +1,94 @@
+"""GPU tests at BASELINE.json's full sizes, through size-independent properties.
+
+The oracle cannot run 65 536 frames / 262 144 utterances in seconds, so the full-size batches are built from a
+small oracle-checked base set placed at rotating positions: element n of the big batch is base[(n + n // B) % B].
+Then (a) every output row must be bit-identical to the small-batch output of the base row it came from
+(position independence over the whole grid / persistent loop), and (b) the small batch is checked against the
+oracle. Device tensors come from torch (memory + stream plumbing only); the computation is the C-ABI call.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rot_index(torch, n, base, device):
+    i = torch.arange(n, device=device, dtype=torch.int64)
+    return (i + i // base) % base
+
+
+def test_mfcc_full_size_65536_frames(ctx, oracle_mod):
+    import torch
+    from edison_amd import _lib
+    dev = torch.device("cuda", ctx.device)
+    ctx.use_torch_stream()
+    B, N = 64, 65536
+    rng = np.random.default_rng(20)
+    base = np.clip(rng.normal(0, 3000, (B, 1024)), -32768, 32767).astype(np.int16)
+    base[0] = 0
+    base[1] = 32767
+    base[2] = -32768
+    tb = torch.from_numpy(base).to(dev)
+    idx = _rot_index(torch, N, B, dev)
+    audio = tb[idx].contiguous()                                   # [65536, 1024] int16 = 134 217 728 B
+    assert audio.numel() * 2 == 134217728
+    for variant, ov, atol, rtol in ((_lib.MFCC_A, 0, 1e-3, 1e-4), (_lib.MFCC_B, 1, 1e-2, 1e-5)):
+        small = torch.empty((B, 13), dtype=torch.float32, device=dev)
+        ctx.mfcc_t(tb, B, 1024, variant, 13, out=small)
+        big = torch.empty((N, 13), dtype=torch.float32, device=dev)
+        feat = torch.empty((N, 13), dtype=torch.int8, device=dev)
+        ctx.mfcc_t(audio, N, 1024, variant, 13, out=big, feat=feat)
+        torch.cuda.synchronize()
+        assert torch.equal(big, small[idx]), "output depends on the frame's position in the batch"
+        q = torch.clamp(big, -128, 127).round().to(torch.int8)
+        assert torch.equal(feat, q)
+        ref = oracle_mod.mfcc(base.reshape(-1), ov)[:, :13]
+        got = small.cpu().numpy()
+        assert np.all(np.abs(got - ref) <= atol + rtol * np.abs(ref))
+        # a checksum of checksums, for the log
+        print("variant", variant, "sum", float(big.double().sum()), "expected", float(small.double()[idx].sum()))
+
+
+def test_kws_full_size_262144_utterances(ctx, oracle_mod, oracle_model):
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    ctx.use_torch_stream()
+    B, N, L = 64, 262144, 31 * 1024
+    rng = np.random.default_rng(21)
+    base = np.concatenate([np.clip(rng.normal(0, 3000, (B - 8, L)), -32768, 32767),
+                           np.clip(rng.normal(0, 0.01 * 32767, (6, L)), -32768, 32767),
+                           np.zeros((2, L))]).astype(np.int16)
+    tb = torch.from_numpy(base).to(dev)
+    idx = _rot_index(torch, N, B, dev)
+    audio = torch.empty((N, L), dtype=torch.int16, device=dev)     # 16.6 GB
+    for lo in range(0, N, 16384):                                  # chunked gather keeps the temporary small
+        audio[lo:lo + 16384] = tb[idx[lo:lo + 16384]]
+    feat_s = torch.empty((B, 403), dtype=torch.int8, device=dev)
+    log_s = torch.empty((B, 10), dtype=torch.int8, device=dev)
+    sm_s = torch.empty((B, 10), dtype=torch.int8, device=dev)
+    am_s = torch.empty((B,), dtype=torch.int32, device=dev)
+    ctx.kws_t(tb, B, L, feat=feat_s, logits=log_s, softmax=sm_s, argmax=am_s)
+    feat = torch.empty((N, 403), dtype=torch.int8, device=dev)
+    logits = torch.empty((N, 10), dtype=torch.int8, device=dev)
+    sm = torch.empty((N, 10), dtype=torch.int8, device=dev)
+    am = torch.empty((N,), dtype=torch.int32, device=dev)
+    ctx.kws_t(audio, N, L, feat=feat, logits=logits, softmax=sm, argmax=am)
+    torch.cuda.synchronize()
+    assert torch.equal(feat, feat_s[idx]) and torch.equal(logits, log_s[idx])
+    assert torch.equal(sm, sm_s[idx]) and torch.equal(am, am_s[idx])
+    # without the optional feature buffer the library uses its own scratch: same answers
+    am2 = torch.empty((N,), dtype=torch.int32, device=dev)
+    ctx.kws_t(audio, N, L, argmax=am2)
+    torch.cuda.synchronize()
+    assert torch.equal(am2, am)
+    del audio
+    # the base batch against the oracle: CNN bit-exact on the GPU's features, features within one rounding step
+    f = feat_s.cpu().numpy()
+    o = oracle_mod.cnn(oracle_model, f, n_threads=4)
+    assert np.array_equal(o["logits"], log_s.cpu().numpy()) and np.array_equal(o["softmax"], sm_s.cpu().numpy())
+    assert np.array_equal(o["argmax"], am_s.cpu().numpy())
+    ref_feat = np.stack([oracle_mod.net_input(oracle_mod.mfcc(base[u], 1)[:, :13]).reshape(-1) for u in range(B)])
+    d = np.abs(ref_feat.astype(int) - f.astype(int))
+    assert d.max() <= 1 and (d != 0).sum() <= 3
+    counts = np.bincount(am.cpu().numpy(), minlength=10)
+    print("class histogram over 262144 utterances:", counts.tolist())

@@ -1,0 +1,270 @@
+"""GPU parity tests (-m gpu): the HIP hot path, called through the C-ABI, against the committed golden vectors
+(generated from the reference) and against the oracle on seeded inputs.
+
+Tolerances (fp32 kernel vs the reference's float64): SURVEY.md A.1
+    variant A  |d| <= 1e-3 + 1e-4*|ref|      variant B  |d| <= 1e-2 + 1e-5*|ref|
+The int8 CNN (every layer, softmax, argmax) is compared bit for bit.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+STREAMS = ["edison", "hey", "two_tone", "noise", "quiet", "extremes"]
+TOL = {"A": (1e-3, 1e-4), "B": (1e-2, 1e-5)}
+
+
+def _close(got, ref, variant):
+    atol, rtol = TOL[variant]
+    bad = np.abs(got - ref) > atol + rtol * np.abs(ref)
+    assert not bad.any(), "max |d| %.3e at %s" % (np.abs(got - ref).max(), np.argwhere(bad)[:4].tolist())
+
+
+def _variant(v):
+    from edison_amd import _lib
+    return _lib.MFCC_A if v == "A" else _lib.MFCC_B
+
+
+# ---------------------------------------------------------------------------------------------- MFCC
+
+@pytest.mark.parametrize("name", STREAMS)
+@pytest.mark.parametrize("variant", ["A", "B"])
+def test_mfcc_golden(ctx, mfcc_golden, name, variant):
+    x = mfcc_golden["in_" + name]
+    got = ctx.mfcc(x, variant=_variant(variant), n_coef=32)
+    _close(got, mfcc_golden["%s_mfcc_%s" % (variant, name)], variant)
+
+
+@pytest.mark.parametrize("variant", ["A", "B"])
+def test_mfcc_stages_golden(ctx, mfcc_golden, variant):
+    for name in ("edison", "two_tone", "extremes"):
+        x = mfcc_golden["in_" + name]
+        st = ctx.mfcc_stages(x, variant=_variant(variant))
+        spec = mfcc_golden["%s_spec_%s" % (variant, name)]
+        nb = 512 if variant == "A" else 513
+        scale = np.abs(spec).max()
+        assert np.abs(st["spectrogram"][:, :nb] - spec[:, :nb]).max() <= 2e-6 * scale
+        mel = mfcc_golden["%s_mel_%s" % (variant, name)]
+        assert np.abs(st["mel_spectrogram"] - mel).max() <= 2e-6 * np.abs(mel).max() + 1e-30
+        n = x.shape[0] // 1024
+        fft = np.fft.fft(x[:n * 1024].reshape(n, 1024).astype(np.float64))[:, :513]
+        assert np.abs(st["fft"] - fft).max() <= 2e-6 * np.abs(fft).max() + 1e-30
+        if variant == "A":
+            lm = mfcc_golden["A_logmel_" + name]
+            assert np.abs(st["log_mel_spectrogram"] - lm).max() <= 1e-4
+
+
+def test_mfcc_vs_oracle_seeded(ctx, oracle_mod):
+    rng = np.random.default_rng(20)
+    t = np.arange(1024) / 16000.0
+    frames = []
+    for i in range(256):
+        ph = rng.uniform(0, 2 * np.pi, 2)
+        f = rng.normal(0, 3000, 1024) + 1000 * np.cos(2 * np.pi * 1000 * t + ph[0]) + 500 * np.cos(2 * np.pi * 125 * t + ph[1])
+        frames.append(np.clip(f, -32768, 32767))
+    x = np.concatenate(frames).astype(np.int16)
+    for variant, ov in (("A", 0), ("B", 1)):
+        got = ctx.mfcc(x, variant=_variant(variant), n_coef=32)
+        _close(got, oracle_mod.mfcc(x, ov, n_threads=4), variant)
+
+
+def test_mfcc_overlap_unaligned_ncoef_log(ctx, oracle_mod, mfcc_golden):
+    x = mfcc_golden["in_noise"]
+    from edison_amd import _lib
+    got = ctx.mfcc(x[:4096], frame_step=512, variant=_lib.MFCC_B, n_coef=32)        # 50 % overlap
+    _close(got, mfcc_golden["B_mfcc_overlap512"], "B")
+    got = ctx.mfcc(x, frame_step=333, variant=_lib.MFCC_B, n_coef=32)               # odd hop -> 2-byte aligned frames
+    _close(got, oracle_mod.mfcc(x, 1, frame_step=333), "B")
+    got = ctx.mfcc(x[1:], frame_step=1024, variant=_lib.MFCC_A, n_coef=32)          # odd base offset
+    _close(got, oracle_mod.mfcc(x[1:], 0), "A")
+    full = ctx.mfcc(x, variant=_lib.MFCC_B, n_coef=32)
+    for nc in (1, 13, 31):
+        assert np.array_equal(ctx.mfcc(x, variant=_lib.MFCC_B, n_coef=nc), full[:, :nc])
+    got = ctx.mfcc(mfcc_golden["in_edison"], variant=_lib.MFCC_B, n_coef=32, use_log=True)
+    _close(got, mfcc_golden["Blog_mfcc_edison"], "A")
+
+
+def test_mfcc_empty_and_ragged(ctx, built_lib):
+    from edison_amd import _lib
+    assert ctx.mfcc(np.zeros(0, np.int16)).shape == (0, 32)
+    assert ctx.mfcc(np.zeros(1023, np.int16)).shape == (0, 32)          # shorter than one frame: zero frames, like frames()
+    assert ctx.mfcc(np.zeros(2047, np.int16)).shape == (1, 32)          # ragged tail ignored
+    with pytest.raises(ValueError):
+        ctx.mfcc(np.zeros(1024, np.int16), n_frames=2)
+    with pytest.raises(_lib.EdisonError):
+        ctx.mfcc(np.zeros(1024, np.int16), n_coef=33)
+    with pytest.raises(_lib.EdisonError):
+        ctx.mfcc(np.zeros(1024, np.int16), variant=7)
+    z = ctx.mfcc(np.zeros(1024, np.int16), variant=_lib.MFCC_A, n_coef=32)   # silence is legal: ln(0 + 1e-6)
+    assert np.isfinite(z).all() and abs(z[0, 0] - 32 * 2 * np.log(1e-6) / 8) < 1e-3
+
+
+def test_net_input_features(ctx, oracle_mod, kws_golden):
+    """int8 net input = round_half_even(clip(mfcc[:13])) (kws_nnom.py:359-361)."""
+    from edison_amd import _lib
+    for mode in ("zero", "edge"):
+        a = kws_golden["kws_%s_audio" % mode]
+        _, feat = ctx.mfcc(a, variant=_lib.MFCC_B, n_coef=13, want_feat=True)
+        assert np.array_equal(feat, kws_golden["kws_%s_feat" % mode])
+    rng = np.random.default_rng(5)
+    x = np.clip(rng.normal(0, 2500, 64 * 31 * 1024), -32768, 32767).astype(np.int16)
+    m, feat = ctx.mfcc(x, variant=_lib.MFCC_B, n_coef=13, want_feat=True)
+    # the int8 written by the kernel is exactly the rounding of the fp32 it wrote
+    assert np.array_equal(feat, np.clip(m, -128, 127).round().astype(np.int8))
+    ref = oracle_mod.net_input(oracle_mod.mfcc(x, 1, n_threads=4)[:, :13])
+    diff = np.abs(ref.astype(int) - feat.astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3     # fp32-vs-fp64 may flip a value sitting on x.5
+
+
+# ---------------------------------------------------------------------------------------------- CNN
+
+def test_cnn_golden_layers(ctx, cnn_golden):
+    lay = ctx.cnn_layers(cnn_golden["feats"])
+    for k in ("conv1", "pool1", "conv2", "pool2", "conv3", "conv4", "dense", "softmax"):
+        assert np.array_equal(lay[k], cnn_golden[k]), k
+    r = ctx.cnn(cnn_golden["feats"])
+    assert np.array_equal(r["logits"], cnn_golden["dense"])
+    assert np.array_equal(r["softmax"], cnn_golden["output"])
+    assert np.array_equal(r["argmax"], cnn_golden["argmax"])
+
+
+def test_cnn_vs_oracle_random(ctx, oracle_mod, oracle_model):
+    rng = np.random.default_rng(123)
+    f = np.concatenate([rng.integers(-128, 128, (12000, 403)),
+                        np.clip(rng.normal(0, 25, (6000, 403)), -128, 127).round(),
+                        np.clip(rng.normal(60, 80, (2000, 403)), -128, 127).round()]).astype(np.int8)
+    g = ctx.cnn(f)
+    o = oracle_mod.cnn(oracle_model, f, n_threads=8)
+    for k in ("logits", "softmax", "argmax"):
+        assert np.array_equal(g[k], o[k]), k
+    # ties and saturated softmax rows are in the sample (dense random inputs drive class 8 hard)
+    assert (g["softmax"] == 127).any() and (g["softmax"] == 0).any()
+
+
+def test_cnn_vs_reference_build(ctx, oracle_mod):
+    if not oracle_mod.have_ref():
+        pytest.skip("oracle/_ref not present")
+    rng = np.random.default_rng(321)
+    f = rng.integers(-128, 128, (1500, 403)).astype(np.int8)
+    g, r = ctx.cnn(f), oracle_mod.nnom_ref_batch(f)
+    for k in ("logits", "softmax", "argmax"):
+        assert np.array_equal(g[k], r[k]), k
+
+
+def test_cnn_edge_sizes(ctx, cnn_golden):
+    assert ctx.cnn(np.zeros((0, 403), np.int8))["argmax"].shape == (0,)
+    r = ctx.cnn(cnn_golden["feats"][:1])
+    assert r["logits"][0].tolist() == [-6, -5, -17, -15, -18, -11, -4, 2, -4, 8] and r["argmax"][0] == 9
+    # ties in the softmax output resolve to the FIRST maximum (nnom_utils.c:275-284)
+    r = ctx.cnn(cnn_golden["feats"])
+    for sm, am in zip(r["softmax"], r["argmax"]):
+        assert am == int(np.argmax(sm))
+
+
+# ---------------------------------------------------------------------------------------------- KWS
+
+def test_kws_golden_wav(ctx, kws_golden):
+    for mode in ("zero", "edge"):
+        r = ctx.kws(kws_golden["kws_%s_audio" % mode], n_utt=1)
+        assert np.array_equal(r["feat"].reshape(31, 13), kws_golden["kws_%s_feat" % mode])
+        assert np.array_equal(r["logits"][0], kws_golden["kws_%s_logits" % mode])
+        assert np.array_equal(r["softmax"][0], kws_golden["kws_%s_softmax" % mode])
+        assert r["argmax"][0] == kws_golden["kws_%s_argmax" % mode] == 0      # "edison"
+
+
+def test_kws_batch_vs_oracle(ctx, oracle_mod, oracle_model):
+    rng = np.random.default_rng(21)
+    n = 96
+    parts = [np.clip(rng.normal(0, 3000, (n // 3, 32000)), -32768, 32767),
+             np.clip(rng.normal(0, 0.01 * 32767, (n // 3, 32000)), -32768, 32767),
+             np.zeros((n // 3, 32000))]
+    audio = np.concatenate(parts).astype(np.int16)
+    for stride, a in ((32000, audio), (31744, np.ascontiguousarray(audio[:, :31744]))):
+        r = ctx.kws(a.reshape(-1), n_utt=n, utt_stride=stride)
+        o = oracle_mod.cnn(oracle_model, r["feat"], n_threads=4)     # CNN exactness on the features the GPU made
+        for k in ("logits", "softmax", "argmax"):
+            assert np.array_equal(r[k], o[k]), k
+        ref_feat = np.stack([oracle_mod.net_input(oracle_mod.mfcc(a[u], 1)[:, :13]).reshape(-1) for u in range(n)])
+        d = np.abs(ref_feat.astype(int) - r["feat"].astype(int))
+        assert d.max() <= 1 and (d != 0).sum() <= 4
+        ro = oracle_mod.cnn(oracle_model, ref_feat, n_threads=4)
+        assert (ro["argmax"] != r["argmax"]).sum() <= 1          # argmax flips only via a flipped feature
+
+
+# ---------------------------------------------------------------------------------------------- legacy C surface
+
+def test_legacy_ai_surface(built_lib, ctx, cnn_golden):
+    L = built_lib
+    assert L.aiInitialize() == 0
+    out = np.zeros(10, np.int8)
+    for i in (0, 1, 3, 20, 57):
+        f = np.ascontiguousarray(cnn_golden["feats"][i])
+        assert L.aiRunInference(f.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert np.array_equal(out, cnn_golden["output"][i])
+        label, prob = ctypes.c_uint32(), ctypes.c_float()
+        assert L.aiNnomPredict(ctypes.byref(label), ctypes.byref(prob)) == 0    # runs on the static input buffer
+        assert label.value == cnn_golden["argmax"][i]
+        s = int(cnn_golden["output"][i].astype(int).sum())
+        assert abs(prob.value - cnn_golden["output"][i].max() / s) < 1e-6
+    ob = np.frombuffer((ctypes.c_int8 * 10).from_address(L.aiNnomGetOutputBuffer()), dtype=np.int8)
+    assert np.array_equal(ob, cnn_golden["output"][57])
+
+
+def test_legacy_frame_and_push_flow(built_lib, ctx, kws_golden):
+    """app.c's streaming flow on the host: per frame MFCC -> mfccToNetInputPush -> aiRunInference."""
+    L = built_lib
+    assert L.aiInitialize() == 0
+    a = kws_golden["kws_zero_audio"]
+    out32 = np.zeros(32, np.float32)
+    for i in range(31):
+        fr = np.ascontiguousarray(a[i * 1024:(i + 1) * 1024])
+        assert L.edison_mfcc_frame(fr.ctypes.data_as(ctypes.c_void_p), 1, out32.ctypes.data_as(ctypes.c_void_p)) == 0
+        m16 = np.clip(np.round(out32[:13]), -32768, 32767).astype(np.int16)
+        L.mfccToNetInputPush(m16.ctypes.data_as(ctypes.c_void_p), 13, 31)
+    buf = np.frombuffer((ctypes.c_int8 * 403).from_address(L.aiNnomGetInputBuffer()), dtype=np.int8).copy()
+    assert np.array_equal(buf.reshape(31, 13), kws_golden["kws_zero_feat"])
+    out = np.zeros(10, np.int8)
+    assert L.aiRunInference(buf.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.array_equal(out, kws_golden["kws_zero_softmax"])
+
+
+# ---------------------------------------------------------------------------------------------- Python mirror / CLI
+
+def test_python_mirror_mfcc_utils(ctx, mfcc_golden):
+    from edison_amd.mfcc import mfcc_utils as mfu
+    x = mfcc_golden["in_edison"]
+    o = mfu.mfcc(x, 16000, len(x), 1024, 1024, 0, 1024, 32, 80.0, 7600.0)
+    assert len(o) == 10 and set(o[0]) == {"t_start", "t_end", "fft", "spectrogram", "mel_weight_matrix",
+                                          "mel_spectrogram", "log_mel_spectrogram", "mfcc"}
+    assert o[3]["t_start"] == 3 * 1024 / 16000 and o[3]["fft"].shape == (512,) and o[3]["mel_weight_matrix"].shape == (512, 32)
+    _close(np.array([f["mfcc"] for f in o]), mfcc_golden["A_mfcc_edison"], "A")
+    ob = mfu.mfcc_mcu(x, 16000, len(x), 1024, 1024, 0, 1024, 32, 80.0, 7600.0, 128)
+    assert ob[0]["fft"].shape == (1024,) and ob[0]["spectrogram"].shape == (1024,) and ob[0]["mel_weight_matrix"].shape == (513, 32)
+    _close(np.array([f["mfcc"] for f in ob]), mfcc_golden["B_mfcc_edison"], "B")
+    sp = np.array([f["spectrogram"] for f in ob])
+    assert np.abs(sp - mfcc_golden["B_spec_edison"]).max() <= 2e-6 * mfcc_golden["B_spec_edison"].max()
+    assert np.array_equal(ob[2]["log_mel_spectrogram"], ob[2]["mel_spectrogram"])     # use_log=False: same array content
+    b = mfu.batch_mfcc(mfcc_golden["batch_in"], 16000, 2048, 1024, 1024, 0, 1024, 32, 80.0, 7600.0)
+    assert b.shape == (4, 2, 32)
+    _close(b, mfcc_golden["batch_out"], "A")
+    # reconfiguring the filterbank goes through edison_mfcc_configure and back
+    o2 = mfu.mfcc_mcu(x, 16000, len(x), 1024, 1024, 0, 1024, 32, 300.0, 6000.0, 128)
+    assert np.abs(np.array([f["mfcc"] for f in o2]) - mfcc_golden["B_mfcc_edison"]).max() > 1.0
+    o3 = mfu.mfcc_mcu(x, 16000, len(x), 1024, 1024, 0, 1024, 32, 80.0, 7600.0, 128)
+    _close(np.array([f["mfcc"] for f in o3]), mfcc_golden["B_mfcc_edison"], "B")
+
+
+def test_cli_entry_points(ctx, kws_golden, mfcc_golden, tmp_path, capsys):
+    import scipy.io.wavfile as wavfile
+    from edison_amd import main as cli
+    wav = str(tmp_path / "edison_16k_16b.wav")
+    wavfile.write(wav, 16000, mfcc_golden["in_edison"])
+    assert cli.main(["main.py", "mfcc", "host", wav]) == 0
+    out = capsys.readouterr().out
+    assert "Number of input samples = 11243" in out and "(2, 10, 13)" in out
+    assert cli.main(["main.py", "kws", "mcu", "file", wav]) == 0
+    out = capsys.readouterr().out
+    assert "edison" in out.splitlines()[-2]
+    assert cli.main(["main.py", "kws", "mcu", "frame", wav]) == 0

@@ -1,0 +1,192 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports what the header declares, the
+host-only C functions (mel matrix, model loader, legacy glue) behave like the reference, and nothing computes
+without a GPU (the product has no CPU fallback)."""
+import ctypes
+import os
+import re
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol(built_lib):
+    from edison_amd import _lib
+    header = open(os.path.join(ROOT, "include", "edison_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b([A-Za-z_]\w*)\s*\([^;{}]*\)\s*;", header))
+    declared = {d for d in declared if not d.startswith("EDISON_")}
+    assert len(declared) >= 35
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert declared <= exported, declared - exported
+
+
+def test_library_contains_gfx950_code_object(built_lib):
+    from edison_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"ed_mfcc_kernel" in blob and b"ed_cnn_kernel" in blob
+
+
+def test_no_device_fails_loudly(built_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    from edison_amd import _lib
+    from edison_amd.context import Context
+    h = ctypes.c_void_p()
+    assert built_lib.edison_init(0, ctypes.byref(h)) == _lib.E_NO_DEVICE
+    assert b"no CPU path" in built_lib.edison_last_error(None)
+    with pytest.raises(_lib.EdisonError):
+        Context(0)
+    # legacy surface: initialisation reports the error code instead of computing on the host
+    assert built_lib.aiInitialize() == _lib.E_NO_DEVICE
+    out = np.zeros(10, np.int8)
+    assert built_lib.aiRunInference(np.zeros(403, np.int8).ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)) < 0
+
+
+def test_missing_library_raises(monkeypatch):
+    from edison_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libedison_hip.so")
+    with pytest.raises(FileNotFoundError, match="no CPU implementation"):
+        _lib.lib()
+
+
+def test_product_does_not_import_oracle():
+    """The product path must never route through the checker (oracle/) or the reference."""
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "edison_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip")):
+                txt = open(os.path.join(d, f), errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "liboracle" in txt or "libnnom_ref" in txt \
+                        or "/root/reference" in txt:
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad
+
+
+def test_gen_mel_weight_matrix_host_c(built_lib, mfcc_golden):
+    from edison_amd.mfcc import mfcc_utils as mfu
+    np.testing.assert_allclose(mfu.gen_mel_weight_matrix(32, 512, 16000, 80.0, 7600.0), mfcc_golden["mel_W512"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(mfu.gen_mel_weight_matrix(32, 513, 16000, 80.0, 7600.0), mfcc_golden["mel_W513"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(mfu.gen_mel_weight_matrix(), mfcc_golden["mel_W129_20"], rtol=0, atol=1e-13)
+    W = mfu.gen_mel_weight_matrix(32, 513, 16000, 80.0, 7600.0)
+    assert (W != 0).sum() == 922 and (W[1:] != 0).sum(axis=1).max() == 2  # each bin feeds <= 2 adjacent bands
+
+
+def test_frames_and_mel_helpers():
+    from edison_amd.mfcc import mfcc_utils as mfu
+    f = mfu.frames(np.arange(10), frame_length=4, frame_step=3)
+    assert f.shape == (3, 4) and f[2].tolist() == [6, 7, 8, 9]
+    assert mfu.frames(np.arange(3), 3, 1).shape == (1, 3)
+    assert abs(mfu.hertz_to_mel(700.0) - 1127.0 * np.log(2.0)) < 1e-12
+    with pytest.raises(NotImplementedError):
+        mfu._prepare(16000, 512, 32, 80.0, 7600.0)
+    with pytest.raises(NotImplementedError):
+        mfu._prepare(16000, 1024, 26, 20.0, 4000.0)
+
+
+def test_config_matches_reference_values():
+    from edison_amd import config as c
+    assert (c.fs, c.frame_length, c.num_mel_bins, c.num_mfcc, c.n_frames, c.nSamples) == (16000, 1024, 32, 13, 31, 32000)
+    assert (c.lower_edge_hertz, c.upper_edge_hertz, c.mel_mtx_scale) == (80.0, 7600.0, 128)
+    assert len(c.keywords) == 10 and c.keywords[0] == "edison" and c.keywords[9] == "_noise"
+
+
+def test_legacy_glue_host_side(built_lib):
+    """mfccToNetInput / mfccToNetInputPush (app.c:675-719), aiGetInputShape, keyword table: no GPU involved."""
+    L = built_lib
+    x, y = ctypes.c_uint16(), ctypes.c_uint16()
+    L.aiGetInputShape(ctypes.byref(x), ctypes.byref(y))
+    assert (x.value, y.value) == (13, 31)
+    assert L.aiGetKeywordCount() == 10
+    assert [L.aiGetKeywordFromIndex(i).decode() for i in range(10)] == ["edison", "cinema", "bedroom", "office",
+                                                                       "livingroom", "kitchen", "on", "off", "_cold", "_noise"]
+    buf = (ctypes.c_int8 * 403).from_address(L.aiNnomGetInputBuffer())
+    ctypes.memset(L.aiNnomGetInputBuffer(), 0, 403)
+    rows = []
+    for i in range(33):  # more pushes than rows: the window keeps the newest 31
+        m = (np.arange(13) * 40 - 200 + i).astype(np.int16)  # spans beyond [-128, 127] -> clipped
+        rows.append(np.clip(m, -128, 127).astype(np.int8))
+        L.mfccToNetInputPush(m.ctypes.data_as(ctypes.c_void_p), 13, 31)
+    got = np.frombuffer(buf, dtype=np.int8).reshape(31, 13).copy()
+    assert np.array_equal(got, np.stack(rows[-31:]))   # firmware appends the newest row at the bottom
+    m = np.full(13, 77, np.int16)
+    L.mfccToNetInput(m.ctypes.data_as(ctypes.c_void_p), 13, 31, 4)
+    assert (np.frombuffer(buf, dtype=np.int8).reshape(31, 13)[4] == 77).all()
+
+
+def test_weights_importer_roundtrip(tmp_path, oracle_mod):
+    """tools/import_weights_h.py: parse a synthetic weights.h, check graph, shifts and the dense de-interleave."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import import_weights_h as imp
+    rng = np.random.default_rng(0)
+    W = rng.integers(-128, 128, (10, 96)).astype(np.int8)
+    # forward interleave = what NNoM's generator emits for arm_fully_connected_q7_opt
+    stream = []
+    blk = [(0, 0), (1, 0), (0, 2), (1, 2), (2, 0), (3, 0), (2, 2), (3, 2), (0, 1), (1, 1), (0, 3), (1, 3), (2, 1), (3, 1), (2, 3), (3, 3)]
+    for r in range(0, 8, 4):
+        for c in range(0, 96, 4):
+            stream += [W[r + dr, c + dc] for dr, dc in blk]
+    stream += W[8].tolist() + W[9].tolist()
+    assert np.array_equal(imp.deinterleave_dense_opt(np.array(stream, np.int8), 10, 96), W)
+    # odd sizes: leftover columns and rows
+    W2 = rng.integers(-128, 128, (6, 7)).astype(np.int8)
+    s2 = []
+    for c in range(0, 4, 4):
+        s2 += [W2[dr, c + dc] for dr, dc in blk]
+    for c in range(4, 7):
+        s2 += [W2[dr, c] for dr in range(4)]
+    s2 += W2[4].tolist() + W2[5].tolist()
+    assert np.array_equal(imp.deinterleave_dense_opt(np.array(s2, np.int8), 6, 7), W2)
+    # the committed blob parses with the independent oracle reader and has the SURVEY A.2 shifts
+    M = oracle_mod.Model()
+    shifts = [(L["bias_lshift"], L["out_rshift"]) for L in M.layers if "out_rshift" in L]
+    assert shifts == [(4, 8), (5, 8), (7, 7), (9, 9), (2, 10)]
+    assert [L["w"].size for L in M.layers if "w" in L] == [400, 4608, 18432, 18432, 960]
+
+
+def test_model_loader_rejects_bad_blobs(built_lib):
+    """ed_parse_model is reached through edison_model_load_mem only with a context; validate the blob format
+    checks host-side through a tiny C driver-free path: the header magic and the topology table."""
+    blob = open(os.path.join(ROOT, "edison_amd", "data", "kws_nnom.ednn"), "rb").read()
+    assert blob[:8] == b"EDNNOM1\0"
+    in_h, in_w, in_c, n_layers, payload, flags = struct.unpack("<6i", blob[8:32])
+    assert (in_h, in_w, in_c, n_layers, flags) == (31, 13, 1, 8, 1)
+    assert len(blob) == 40 + 48 * n_layers + payload
+    types = [struct.unpack("<12i", blob[40 + 48 * i:88 + 48 * i])[0] for i in range(n_layers)]
+    assert types == [1, 2, 1, 2, 1, 1, 3, 4]
+
+
+def test_pad_or_cut_and_cli_dispatch(tmp_path, capsys):
+    from edison_amd.kws import kws_host
+    from edison_amd import main as cli
+    d = np.arange(10, dtype=np.int16)
+    assert kws_host.pad_or_cut(d, 16, "zero").tolist() == list(range(10)) + [0] * 6
+    assert kws_host.pad_or_cut(d, 16, "edge").tolist() == list(range(10)) + [9] * 6
+    assert kws_host.pad_or_cut(d, 4).tolist() == [0, 1, 2, 3]
+    assert cli.main(["main.py", "nosuch"]) == 1
+    assert cli.main(["main.py", "mfcc", "bogus"]) == 1
+    assert cli.main(["main.py", "kws", "bogus"]) == 1
+    assert cli.main(["main.py", "kws", "live", "host"]) == 0   # reference quirk (exit 1 after running) not kept
+    assert cli.main(["main.py", "mfcc", "host", str(tmp_path / "missing.wav")]) == 1
+
+
+def test_shard_range():
+    from edison_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 262144, 2097152, 1000003):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(2097152, 3, 8) == (786432, 1048576)
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
