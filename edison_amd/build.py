@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
     bdir = os.path.join(CSRC, "build")
     os.makedirs(bdir, exist_ok=True)
     objs = []
-    common = ["-O3", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter"]
+    common = ["-O3", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter"] + os.environ.get("ED_CFLAGS", "").split()
     for src in C_SOURCES:
         obj = os.path.join(bdir, src + ".o")
         cmd = [hipcc, "-x", "c", "-std=gnu11"] + common + ["-c", os.path.join(CSRC, src), "-o", obj]

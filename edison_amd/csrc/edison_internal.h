@@ -13,20 +13,25 @@ extern "C" {
 #endif
 
 /* ------------------------------------------------------------------ MFCC device tables (one per variant) */
-#define ED_MEL_T_MAX 40 /* tap-loop iterations per lane; the shipped filterbank needs 36 (widest band = 71 bins) */
+#define ED_MEL_T4_MAX 12  /* spectrum quads per lane; the shipped filterbank needs 10 (widest band = 71 bins) */
+#define ED_SPEC_QUADS 129 /* spectrum buffer = 513 bins padded to 516 floats                                  */
 
 typedef struct {
-	/* 512-point complex FFT of the packed real frame, 3 radix-8 passes (see mfcc_kernels.hip) */
-	float tw1[64][8][2]; /* [lane][p]   W512^(lane*p), p = 0..7 (p = 0 unused)                               */
-	float tw2[8][8][2];  /* [c][q]      W64^(c*q)                                                            */
+	/* Per-lane register constants, lane-minor so that a wavefront loads each of them with one coalesced read.
+	 * 512-point complex FFT of the packed real frame, 3 radix-8 passes (see mfcc_kernels.hip):               */
+	float tw1[8][64][2]; /* [p][lane]   W512^(lane*p), p = 0..7 (p = 0 unused)                               */
+	float tw2[8][64][2]; /* [q][lane]   W64^((lane&7)*q)                                                     */
+	/* mel filterbank: lane = (j = lane&31, h = lane>>5) sums half h of band j's taps, reading the spectrum
+	 * as 16-byte quads mel_start4[lane] + t, t < mel_T4, against mel_w4[t][lane][0..3]                       */
+	int32_t mel_start4[64];
+	/* ---- the block below is copied verbatim into LDS by every workgroup (ED_LDS_TAB_FLOATS(T4) floats) ---- */
+	/* DCT-II with the variant's normalisation folded in: lane (c = lane&31, h = lane>>5),
+	 * dct4[n4][lane][j] = scale * 2*cos(pi*c*(2*(4*n4+j+16h)+1)/64)                                         */
+	float dct4[4][64][4];
 	float twp[4][64][2]; /* [m][lane]   W1024^(lane+64m): real-FFT split twiddles                            */
-	/* mel filterbank, per-lane tap loop: lane = (j = lane&31, h = lane>>5) sums taps t of band j's half h   */
-	int32_t mel_start[64];
-	float mel_w[ED_MEL_T_MAX][64];
-	int32_t mel_T;
-	/* DCT-II with the variant's normalisation folded in: lane (c = lane&31, h) holds dct[n][lane], n<16,
-	 * = scale * 2*cos(pi*c*(2*(n+16h)+1)/64)                                                                */
-	float dct[16][64];
+	float mel_w4[ED_MEL_T4_MAX][64][4];
+	/* ---- end of the LDS image ---- */
+	int32_t mel_T4;
 	float spec_scale; /* applied to 2|X[k]|: A 0.5, B 0.5/1024/sqrt(2)                                       */
 	float log_offset; /* 1e-6                                                                                */
 	int32_t always_log; /* variant A                                                                         */
@@ -77,6 +82,8 @@ typedef struct {
 	int64_t frame_step;
 	int n_coef;
 	int use_log;
+	int mel_T4;               /* host copy of the variant's ed_mfcc_tables_t.mel_T4 (sizes the LDS tables)  */
+	int pad_;
 	float *mfcc;      /* [n_frames][n_coef] or NULL */
 	int8_t *feat;     /* [n_frames][n_coef] or NULL */
 	float feat_scale;

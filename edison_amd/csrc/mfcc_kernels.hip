@@ -7,33 +7,44 @@
  * output coefficients kept in registers/LDS (no intermediate HBM traffic: 2048 B in, <=128 B out per frame).
  *
  * Pipeline per wavefront (lane = 0..63):
- *   1. load      z[n] = x[2n] + i*x[2n+1], n = lane + 64a (a = 0..7): 8 coalesced 256-B wave loads
+ *   1. load      z[n] = x[2n] + i*x[2n+1], n = lane + 64a (a = 0..7): 8 coalesced 256-B wave loads, issued one
+ *                frame ahead (software prefetch) so HBM latency hides under the previous frame's arithmetic
  *   2. FFT512    3 radix-8 passes over the digits of n = 64a + 8b + c, k = p + 8q + 64r; the two digit
  *                transposes go through a wave-private, padded LDS buffer (conflict-free ds_*_b64)
  *   3. split     X[k] = E[k] + W1024^k O[k] from Z[k], conj Z[512-k]; lane handles the pair (k, 512-k)
- *   4. |X|       -> wave-private LDS spectrum S[0..512]
- *   5. mel       32 banded dot products: lane (band j = lane&31, half h = lane>>5) walks its taps,
- *                halves combined with one cross-lane shuffle
- *   6. ln / DCT  optional ln(x+1e-6); DCT-II from 16 per-lane table registers, halves combined by shuffle
+ *   4. |X|       -> wave-private LDS spectrum S[0..512] (+3 pad)
+ *   5. mel       32 banded dot products: lane (band j = lane&31, half h = lane>>5) reads its taps as 16-byte
+ *                quads (ds_read_b128 for spectrum and weights), halves combined with one cross-lane shuffle
+ *   6. ln / DCT  optional ln(x+1e-6); DCT-II against a per-lane LDS table, halves combined by shuffle
  *   7. store     n_coef fp32 and/or int8 (clip, round-half-even) per frame
  *
- * Waves never share LDS data, so there is no workgroup barrier inside the frame loop.
+ * Waves never share LDS data, so there is no workgroup barrier inside the frame loop. The constant tables
+ * (mel taps, DCT, split twiddles) are staged once per workgroup in LDS; only the pass-1/2 twiddles live in
+ * registers.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "edison_internal.h"
 
-#define ED_WAVES_PER_BLOCK 4
-#define ED_XBUF_FLOATS 1160 /* per-wave LDS: 576 complex exchange slots (also Pz + S) + 8 pad */
+#ifndef ED_WPB
+#define ED_WPB 8                 /* waves (= frames in flight) per workgroup                               */
+#endif
+#define ED_XBUF_FLOATS 1160      /* per-wave LDS: 576 complex exchange slots (also Pz + S + L) + pad        */
+#define ED_FIXTAB_FLOATS (4 * 64 * 4 + 4 * 64 * 2) /* dct | split twiddles, then mel_T4 x 64 weight quads   */
+
+#ifdef ED_MIN_WAVES
+#define ED_MFCC_BOUNDS __launch_bounds__(64 * ED_WPB, ED_MIN_WAVES)
+#else
+#define ED_MFCC_BOUNDS __launch_bounds__(64 * ED_WPB)
+#endif
 
 __device__ __forceinline__ void ed_wave_sync()
 {
-	/* Order this wave's LDS writes before its following LDS reads. A wave's DS instructions execute in
-	 * order; the fence only stops the compiler from moving them across each other. */
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	/* Order this wave's LDS writes before its following LDS reads. A wave's DS instructions are issued and
+	 * serviced in order, so no wait is needed; the (code-less) wave barrier only stops the compiler from
+	 * moving memory operations across this point. */
 	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ void ed_dft4(float y0r, float y0i, float y1r, float y1i, float y2r, float y2i, float y3r,
@@ -69,71 +80,93 @@ __device__ __forceinline__ void ed_radix8(float (&r)[8], float (&i)[8])
 	ed_dft4(vr[0], vi[0], vr[1], vi[1], vr[2], vi[2], vr[3], vi[3], r[1], i[1], r[3], i[3], r[5], i[5], r[7], i[7]);
 }
 
-template <bool STAGES>
-__global__ __launch_bounds__(64 * ED_WAVES_PER_BLOCK) void ed_mfcc_kernel(ed_mfcc_args_t args,
-                                                                          const ed_mfcc_tables_t *__restrict__ tab)
+/* First sample of frame f: (f / fpg) * group_stride + (f % fpg) * frame_step (f is wave-uniform, < 2^31). */
+__device__ __forceinline__ const int16_t *ed_frame_ptr(const ed_mfcc_args_t &a, uint32_t f)
+{
+	uint32_t g = 0, i = f;
+	if (a.frames_per_group < a.n_frames)
+	{
+		g = f / (uint32_t)a.frames_per_group;
+		i = f - g * (uint32_t)a.frames_per_group;
+	}
+	return a.audio + ((int64_t)g * a.group_stride + (int64_t)i * a.frame_step);
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void ed_load_frame(const int16_t *fp, int lane, uint32_t (&v)[8])
+{
+	if (ALIGNED)
+	{
+		const uint32_t *fp32 = reinterpret_cast<const uint32_t *>(fp);
+#pragma unroll
+		for (int a = 0; a < 8; a++) v[a] = fp32[lane + 64 * a];
+	}
+	else
+	{
+		const uint16_t *fu = reinterpret_cast<const uint16_t *>(fp);
+#pragma unroll
+		for (int a = 0; a < 8; a++)
+			v[a] = (uint32_t)fu[2 * (lane + 64 * a)] | ((uint32_t)fu[2 * (lane + 64 * a) + 1] << 16);
+	}
+}
+
+template <bool STAGES, bool ALIGNED>
+__global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
 {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	const int lane = threadIdx.x & 63;
-	const int wave = threadIdx.x >> 6;
-	const int T = tab->mel_T;
-	float *melw = smem;                                   /* [T][64] shared by the block      */
-	float *xbuf = smem + ED_MEL_T_MAX * 64 + wave * ED_XBUF_FLOATS; /* wave-private               */
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int T4 = args.mel_T4;                                                  /* == tab->mel_T4          */
+	const float4 *dctl = reinterpret_cast<const float4 *>(smem);                 /* [4][64] x 4 coefficients */
+	const float2 *tpl = reinterpret_cast<const float2 *>(smem + 1024);           /* [4][64] W1024^(lane+64m) */
+	const float4 *melw4 = reinterpret_cast<const float4 *>(smem + ED_FIXTAB_FLOATS); /* [T4][64] weight quads */
+	float *xbuf = smem + ED_FIXTAB_FLOATS + T4 * 256 + wave * ED_XBUF_FLOATS;    /* wave-private            */
 	float2 *xc = reinterpret_cast<float2 *>(xbuf);
 
-	for (int t = threadIdx.x; t < T * 64; t += blockDim.x) melw[t] = (&tab->mel_w[0][0])[t];
-	__syncthreads();
+	{ /* the table block [dct4 | twp | mel_w4(T4 rows)] is laid out in global memory exactly as in LDS */
+		const float4 *src = reinterpret_cast<const float4 *>(&tab->dct4[0][0][0]);
+		float4 *dst = reinterpret_cast<float4 *>(smem);
+		for (int t = threadIdx.x; t < (ED_FIXTAB_FLOATS + T4 * 256) / 4; t += blockDim.x) dst[t] = src[t];
+	}
 
-	/* per-lane constants, resident in registers for the whole persistent loop */
-	float t1r[8], t1i[8], t2r[8], t2i[8], tpr[4], tpi[4], dct[16];
+	/* pass-1/2 twiddles: resident in registers for the whole persistent loop */
+	float t1r[8], t1i[8], t2r[8], t2i[8];
 #pragma unroll
 	for (int p = 1; p < 8; p++)
 	{
-		t1r[p] = tab->tw1[lane][p][0]; t1i[p] = tab->tw1[lane][p][1];
-		t2r[p] = tab->tw2[lane & 7][p][0]; t2i[p] = tab->tw2[lane & 7][p][1];
+		const float2 a = *reinterpret_cast<const float2 *>(&tab->tw1[p][lane][0]);
+		const float2 b = *reinterpret_cast<const float2 *>(&tab->tw2[p][lane][0]);
+		t1r[p] = a.x; t1i[p] = a.y; t2r[p] = b.x; t2i[p] = b.y;
 	}
-#pragma unroll
-	for (int m = 0; m < 4; m++) { tpr[m] = tab->twp[m][lane][0]; tpi[m] = tab->twp[m][lane][1]; }
-#pragma unroll
-	for (int n = 0; n < 16; n++) dct[n] = tab->dct[n][lane];
-	const int mel_start = tab->mel_start[lane];
+	__syncthreads();
+#ifdef ED_STAGGER
+	/* Waves that share a SIMD (w, w+4 of a workgroup; the workgroups of a CU) run the same program; start
+	 * them a fraction of a frame apart so that one wave's LDS-heavy transposes overlap another's arithmetic. */
+	for (int s = ((wave >> 2) * 2 + (blockIdx.x & 1)); s > 0; s--) __builtin_amdgcn_s_sleep(ED_STAGGER);
+#endif
+	const int mel_start4 = tab->mel_start4[lane];
 	const float spec_scale = tab->spec_scale;
 	const float log_offset = tab->log_offset;
 	const bool do_log = tab->always_log || args.use_log;
-
 	const int hi3 = lane >> 3, lo3 = lane & 7;
 
-	for (int64_t f = (int64_t)blockIdx.x * ED_WAVES_PER_BLOCK + wave; f < args.n_frames;
-	     f += (int64_t)gridDim.x * ED_WAVES_PER_BLOCK)
-	{
-		const int64_t g = f / args.frames_per_group;
-		const int64_t start = g * args.group_stride + (f - g * args.frames_per_group) * args.frame_step;
-		const int16_t *fp = args.audio + start;
+	const uint32_t n_frames = (uint32_t)args.n_frames;
+	const uint32_t stride = gridDim.x * ED_WPB;
+	uint32_t f = blockIdx.x * ED_WPB + wave;
+	uint32_t raw[8];
+	if (f < n_frames) ed_load_frame<ALIGNED>(ed_frame_ptr(args, f), lane, raw);
 
-		/* ---- 1. load: lane gets z[lane + 64a] */
+	for (; f < n_frames; f += stride)
+	{
+		/* ---- 1. unpack this frame, then put the next frame's loads in flight */
 		float re[8], im[8];
-		if ((reinterpret_cast<uintptr_t>(fp) & 3) == 0)
+#pragma unroll
+		for (int a = 0; a < 8; a++)
 		{
-			const uint32_t *fp32 = reinterpret_cast<const uint32_t *>(fp);
-			uint32_t v[8];
-#pragma unroll
-			for (int a = 0; a < 8; a++) v[a] = fp32[lane + 64 * a];
-#pragma unroll
-			for (int a = 0; a < 8; a++)
-			{
-				re[a] = (float)(int16_t)(v[a] & 0xffffu);
-				im[a] = (float)(int16_t)(v[a] >> 16);
-			}
+			re[a] = (float)(int16_t)(raw[a] & 0xffffu);
+			im[a] = (float)(int16_t)(raw[a] >> 16);
 		}
-		else
-		{
-#pragma unroll
-			for (int a = 0; a < 8; a++)
-			{
-				re[a] = (float)fp[2 * (lane + 64 * a)];
-				im[a] = (float)fp[2 * (lane + 64 * a) + 1];
-			}
-		}
+		if (f + stride < n_frames) ed_load_frame<ALIGNED>(ed_frame_ptr(args, f + stride), lane, raw);
 
 		/* ---- 2a. pass 1: DFT over a, twiddle W512^(lane*p) */
 		ed_radix8(re, im);
@@ -185,16 +218,17 @@ __global__ __launch_bounds__(64 * ED_WAVES_PER_BLOCK) void ed_mfcc_kernel(ed_mfc
 		for (int r = 4; r < 8; r++) xc[lane + 64 * (r - 4)] = make_float2(re[r], im[r]);
 		ed_wave_sync();
 		float slo[4], shi[4];
-		float flr[4], fli[4], fhr[4], fhi[4]; /* X2[k], X2[512-k] for the stage dump */
+		float flr[4], fli[4], fhr[4], fhi[4]; /* X[k], X[512-k] for the stage dump */
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 		{
 			float2 pz = xc[256 - lane - 64 * m]; /* Z[512 - k]; slot 256 (lane 0, m 0) is Z[512] = Z[0] */
 			if (m == 0 && lane == 0) pz = make_float2(re[0], im[0]);
+			const float2 tw = tpl[64 * m + lane];
 			float ar = re[m] + pz.x, ai = im[m] - pz.y; /* A  = Z[k] + conj Z[512-k]          = 2 E[k]      */
 			float br = re[m] - pz.x, bi = im[m] + pz.y; /* B  = Z[k] - conj Z[512-k]; O2 = -i*B = 2 O[k]    */
-			float tr = tpr[m] * bi + tpi[m] * br;       /* T  = W1024^k * (bi - i*br)                        */
-			float ti = tpi[m] * bi - tpr[m] * br;
+			float tr = tw.x * bi + tw.y * br;           /* T  = W1024^k * (bi - i*br)                        */
+			float ti = tw.y * bi - tw.x * br;
 			float xr = ar + tr, xi = ai + ti;           /* 2 X[k]                                            */
 			float yr = ar - tr, yi = ai - ti;           /* conj(2 X[512-k])                                  */
 			slo[m] = __fsqrt_rn(xr * xr + xi * xi) * spec_scale;
@@ -204,7 +238,8 @@ __global__ __launch_bounds__(64 * ED_WAVES_PER_BLOCK) void ed_mfcc_kernel(ed_mfc
 		/* k = 256 pairs with itself: X[256] = conj(Z[256]) (lane 0, reg 4) */
 		const float s256 = 2.0f * __fsqrt_rn(re[4] * re[4] + im[4] * im[4]) * spec_scale;
 
-		/* ---- 4. spectrum to LDS (floats 576..1088 of the wave buffer: disjoint from Pz) */
+		/* ---- 4. spectrum to LDS (floats 576..1091 of the wave buffer: disjoint from Pz; S[513..515] hold
+		 *         finite leftovers of the transposes and only ever meet zero weights) */
 		float *S = xbuf + 576;
 #pragma unroll
 		for (int m = 0; m < 4; m++)
@@ -217,7 +252,7 @@ __global__ __launch_bounds__(64 * ED_WAVES_PER_BLOCK) void ed_mfcc_kernel(ed_mfc
 		{
 			if (args.fft)
 			{
-				float2 *F = reinterpret_cast<float2 *>(args.fft) + f * 513;
+				float2 *F = reinterpret_cast<float2 *>(args.fft) + (int64_t)f * 513;
 #pragma unroll
 				for (int m = 0; m < 4; m++)
 				{
@@ -230,18 +265,27 @@ __global__ __launch_bounds__(64 * ED_WAVES_PER_BLOCK) void ed_mfcc_kernel(ed_mfc
 		ed_wave_sync();
 		if (STAGES && args.spec)
 		{
-			for (int k = lane; k < 513; k += 64) args.spec[f * 513 + k] = S[k];
+			for (int k = lane; k < 513; k += 64) args.spec[(int64_t)f * 513 + k] = S[k];
 		}
 
-		/* ---- 5. mel filterbank: lane (band, half) walks its taps */
-		float acc = 0.0f;
-		for (int t = 0; t < T; t++) acc = fmaf(S[mel_start + t], melw[t * 64 + lane], acc);
+		/* ---- 5. mel filterbank: lane (band, half) walks its taps a quad at a time */
+		const float4 *S4 = reinterpret_cast<const float4 *>(S) + mel_start4;
+		float acc0 = 0.0f, acc1 = 0.0f;
+		for (int t = 0; t < T4; t++)
+		{
+			const float4 s = S4[t], w = melw4[t * 64 + lane];
+			acc0 = fmaf(s.x, w.x, acc0);
+			acc1 = fmaf(s.y, w.y, acc1);
+			acc0 = fmaf(s.z, w.z, acc0);
+			acc1 = fmaf(s.w, w.w, acc1);
+		}
+		const float acc = acc0 + acc1;
 		float e = acc + __shfl_xor(acc, 32);
 		float lm = do_log ? logf(e + log_offset) : e;
 		if (STAGES && lane < 32)
 		{
-			if (args.mel) args.mel[f * 32 + lane] = e;
-			if (args.logmel) args.logmel[f * 32 + lane] = lm;
+			if (args.mel) args.mel[(int64_t)f * 32 + lane] = e;
+			if (args.logmel) args.logmel[(int64_t)f * 32 + lane] = lm;
 		}
 
 		/* ---- 6. DCT-II: lane (c = lane&31, h) sums n = 16h..16h+15 */
@@ -253,11 +297,11 @@ __global__ __launch_bounds__(64 * ED_WAVES_PER_BLOCK) void ed_mfcc_kernel(ed_mfc
 #pragma unroll
 		for (int n4 = 0; n4 < 4; n4++)
 		{
-			float4 v = L4[n4];
-			d = fmaf(v.x, dct[4 * n4 + 0], d);
-			d = fmaf(v.y, dct[4 * n4 + 1], d);
-			d = fmaf(v.z, dct[4 * n4 + 2], d);
-			d = fmaf(v.w, dct[4 * n4 + 3], d);
+			const float4 v = L4[n4], w = dctl[64 * n4 + lane];
+			d = fmaf(v.x, w.x, d);
+			d = fmaf(v.y, w.y, d);
+			d = fmaf(v.z, w.z, d);
+			d = fmaf(v.w, w.w, d);
 		}
 		d += __shfl_xor(d, 32);
 		ed_wave_sync(); /* Lb / S are rewritten by the next frame */
@@ -265,29 +309,49 @@ __global__ __launch_bounds__(64 * ED_WAVES_PER_BLOCK) void ed_mfcc_kernel(ed_mfc
 		/* ---- 7. store */
 		if (lane < args.n_coef)
 		{
-			if (args.mfcc) args.mfcc[f * args.n_coef + lane] = d;
+			if (args.mfcc) args.mfcc[(int64_t)f * args.n_coef + lane] = d;
 			if (args.feat)
 			{
 				float q = d * args.feat_scale;
 				q = fminf(fmaxf(q, -128.0f), 127.0f);
-				args.feat[f * args.n_coef + lane] = (int8_t)__float2int_rn(q);
+				args.feat[(int64_t)f * args.n_coef + lane] = (int8_t)__float2int_rn(q);
 			}
 		}
 	}
 }
 
+static int g_mfcc_blocks_per_cu = -1;
+
 extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
                               hipStream_t stream)
 {
 	if (args->n_frames <= 0) return 0;
-	const size_t lds = sizeof(float) * (ED_MEL_T_MAX * 64 + ED_WAVES_PER_BLOCK * ED_XBUF_FLOATS);
-	int64_t blocks = (args->n_frames + ED_WAVES_PER_BLOCK - 1) / ED_WAVES_PER_BLOCK;
-	const int64_t cap = (int64_t)n_cu * 8;
+	if (args->mel_T4 < 1 || args->mel_T4 > ED_MEL_T4_MAX) return (int)hipErrorInvalidValue;
+	const size_t lds = sizeof(float) * (ED_FIXTAB_FLOATS + args->mel_T4 * 256 + ED_WPB * ED_XBUF_FLOATS);
+	if (g_mfcc_blocks_per_cu < 0)
+	{
+		/* persistent grid = exactly what is resident; sized once from the fast kernel's occupancy */
+		int nb = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ed_mfcc_kernel<false, true>, 64 * ED_WPB, lds) != hipSuccess || nb < 1)
+			nb = 1;
+		g_mfcc_blocks_per_cu = nb;
+	}
+	int64_t blocks = (args->n_frames + ED_WPB - 1) / ED_WPB;
+	const int64_t cap = (int64_t)n_cu * g_mfcc_blocks_per_cu;
 	if (blocks > cap) blocks = cap;
-	dim3 grid((unsigned)blocks), block(64 * ED_WAVES_PER_BLOCK);
+	/* 4-byte loads need every frame start 4-byte aligned */
+	const bool aligned = ((reinterpret_cast<uintptr_t>(args->audio) & 3) == 0) && (args->frame_step % 2 == 0) &&
+	                     (args->group_stride % 2 == 0);
+	dim3 grid((unsigned)blocks), block(64 * ED_WPB);
 	if (stages)
-		hipLaunchKernelGGL(ed_mfcc_kernel<true>, grid, block, lds, stream, *args, dev_tab);
+	{
+		if (aligned) hipLaunchKernelGGL((ed_mfcc_kernel<true, true>), grid, block, lds, stream, *args, dev_tab);
+		else hipLaunchKernelGGL((ed_mfcc_kernel<true, false>), grid, block, lds, stream, *args, dev_tab);
+	}
 	else
-		hipLaunchKernelGGL(ed_mfcc_kernel<false>, grid, block, lds, stream, *args, dev_tab);
+	{
+		if (aligned) hipLaunchKernelGGL((ed_mfcc_kernel<false, true>), grid, block, lds, stream, *args, dev_tab);
+		else hipLaunchKernelGGL((ed_mfcc_kernel<false, false>), grid, block, lds, stream, *args, dev_tab);
+	}
 	return (int)hipGetLastError();
 }

@@ -70,13 +70,9 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 		for (int p = 0; p < 8; p++)
 		{
 			double a = -2.0 * M_PI * (double)(l * p) / 512.0;
-			out->tw1[l][p][0] = (float)cos(a); out->tw1[l][p][1] = (float)sin(a);
-		}
-	for (int c = 0; c < 8; c++)
-		for (int q = 0; q < 8; q++)
-		{
-			double a = -2.0 * M_PI * (double)(c * q) / 64.0;
-			out->tw2[c][q][0] = (float)cos(a); out->tw2[c][q][1] = (float)sin(a);
+			out->tw1[p][l][0] = (float)cos(a); out->tw1[p][l][1] = (float)sin(a);
+			a = -2.0 * M_PI * (double)((l & 7) * p) / 64.0;
+			out->tw2[p][l][0] = (float)cos(a); out->tw2[p][l][1] = (float)sin(a);
 		}
 	for (int m = 0; m < 4; m++)
 		for (int l = 0; l < 64; l++)
@@ -94,43 +90,44 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 	 * (mfcc_utils.py:282,309); in float arithmetic that is the identity up to rounding, so the device
 	 * uses the unscaled matrix. mel_mtx_scale is accepted for signature compatibility. */
 	(void)mel_mtx_scale;
-	int T = 0;
-	int ks[EDISON_NUM_MEL], ke[EDISON_NUM_MEL];
-	for (int j = 0; j < NMEL; j++)
+	/* Lane (band j = lane&31, half h = lane>>5) owns the taps [a, b) of its band and reads the spectrum as
+	 * 16-byte quads: quad index s4 + t, t < T4, weights w[t][lane][0..3] (zero outside [a, b)). */
+	int T4 = 1;
+	int la[64], lb[64];
+	for (int l = 0; l < 64; l++)
 	{
+		const int j = l & 31, h = l >> 5;
 		int first = -1, last = -1;
 		for (int k = 0; k < nbins; k++)
 			if (W[(size_t)k * NMEL + j] != 0.0) { if (first < 0) first = k; last = k; }
 		if (first < 0) { first = 0; last = -1; } /* empty band (degenerate edges) */
-		ks[j] = first; ke[j] = last + 1;
-		int half = (ke[j] - ks[j] + 1) / 2;
-		if (half > T) T = half;
+		const int ks = first, ke = last + 1, half = (ke - ks + 1) / 2;
+		la[l] = h == 0 ? ks : (ks + half < ke ? ks + half : ke);
+		lb[l] = h == 0 ? (ks + half < ke ? ks + half : ke) : ke;
+		const int quads = lb[l] > la[l] ? (lb[l] - 1) / 4 - la[l] / 4 + 1 : 0;
+		if (quads > T4) T4 = quads;
 	}
-	if (T < 1) T = 1;
-	if (T > ED_MEL_T_MAX)
+	if (T4 > ED_MEL_T4_MAX)
 	{
-		if (err) snprintf(err, err_cap, "mel band of %d bins exceeds the kernel's tap budget (%d per half)", 2 * T,
-		                  ED_MEL_T_MAX);
+		if (err) snprintf(err, err_cap, "mel band needs %d spectrum quads per half, the kernel's budget is %d", T4,
+		                  ED_MEL_T4_MAX);
 		free(W);
 		return EDISON_E_NO_IMPL;
 	}
-	out->mel_T = T;
+	out->mel_T4 = T4;
 	for (int l = 0; l < 64; l++)
 	{
-		int j = l & 31, h = l >> 5;
-		int half = (ke[j] - ks[j] + 1) / 2;
-		int a = h == 0 ? ks[j] : ks[j] + half;          /* this lane's taps: [a, b) */
-		int b = h == 0 ? ks[j] + half : ke[j];
-		if (b > ke[j]) b = ke[j];
-		int start = a;
-		if (start > 513 - T) start = 513 - T;             /* keep start + T - 1 <= 512 (the S buffer has 513) */
-		if (start < 0) start = 0;
-		out->mel_start[l] = start;
-		for (int t = 0; t < T; t++)
-		{
-			int k = start + t;
-			out->mel_w[t][l] = (k >= a && k < b && k < nbins) ? (float)W[(size_t)k * NMEL + j] : 0.0f;
-		}
+		const int j = l & 31;
+		int s4 = la[l] / 4;
+		if (s4 > ED_SPEC_QUADS - T4) s4 = ED_SPEC_QUADS - T4; /* keep every read inside the padded spectrum */
+		if (s4 < 0) s4 = 0;
+		out->mel_start4[l] = s4;
+		for (int t = 0; t < T4; t++)
+			for (int c = 0; c < 4; c++)
+			{
+				const int k = 4 * (s4 + t) + c;
+				out->mel_w4[t][l][c] = (k >= la[l] && k < lb[l] && k < nbins) ? (float)W[(size_t)k * NMEL + j] : 0.0f;
+			}
 	}
 	free(W);
 
@@ -142,7 +139,8 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 		for (int n = 0; n < 16; n++)
 		{
 			int nn = n + 16 * h;
-			out->dct[n][l] = (float)(dscale * 2.0 * cos(M_PI * (double)c * (double)(2 * nn + 1) / (double)(2 * NMEL)));
+			out->dct4[n / 4][l][n % 4] =
+			    (float)(dscale * 2.0 * cos(M_PI * (double)c * (double)(2 * nn + 1) / (double)(2 * NMEL)));
 		}
 	}
 	out->spec_scale = (variant == EDISON_MFCC_A) ? 0.5f : (float)(0.5 / 1024.0 / sqrt(2.0));
