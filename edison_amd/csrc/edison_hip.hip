@@ -19,6 +19,9 @@ extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t
 extern "C" int ed_launch_cnn(const ed_cnn_model_t *dev_model, const int8_t *feat, int64_t n_utt, int8_t *logits,
                              int8_t *softmax, int32_t *argmax, int8_t *acts, int n_cu, hipStream_t stream);
 
+extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const int8_t *feat, int64_t n_utt, int8_t *logits,
+                                  int8_t *softmax, int32_t *argmax, int n_cu, hipStream_t stream);
+
 struct edison_ctx
 {
 	int device;
@@ -29,7 +32,8 @@ struct edison_ctx
 	hipStream_t stream;
 	ed_mfcc_tables_t *d_tab[2]; /* variant A, B */
 	int mel_T4[2];
-	ed_cnn_model_t *d_model;
+	ed_cnn_model_t *d_model;           /* layer-by-layer diagnostic kernel (edison_cnn_layers) */
+	ed_cnn_mfma_model_t *d_model_mfma; /* MFMA fast path                                       */
 	int have_model;
 	/* growable device scratch for the host-pointer entry points and the fused KWS path */
 	void *scratch;
@@ -134,6 +138,7 @@ extern "C" void edison_shutdown(edison_ctx *ctx)
 	(void)hipDeviceSynchronize();
 	for (int v = 0; v < 2; v++) if (ctx->d_tab[v]) (void)hipFree(ctx->d_tab[v]);
 	if (ctx->d_model) (void)hipFree(ctx->d_model);
+	if (ctx->d_model_mfma) (void)hipFree(ctx->d_model_mfma);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	free(ctx);
@@ -193,14 +198,18 @@ extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t b
 {
 	if (!ctx || !blob) return EDISON_E_ARGUMENT;
 	ed_cnn_model_t *h = (ed_cnn_model_t *)malloc(sizeof(ed_cnn_model_t));
-	if (!h) return set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed");
-	int r = ed_parse_model(blob, blob_bytes, h, ctx->err, sizeof(ctx->err));
-	if (r != EDISON_OK) { free(h); return r; }
+	ed_cnn_mfma_model_t *hm = (ed_cnn_mfma_model_t *)malloc(sizeof(ed_cnn_mfma_model_t));
+	if (!h || !hm) { free(h); free(hm); return set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed"); }
+	int r = ed_parse_model(blob, blob_bytes, h, hm, ctx->err, sizeof(ctx->err));
+	if (r != EDISON_OK) { free(h); free(hm); return r; }
 	hipError_t e = hipSetDevice(ctx->device);
 	if (e == hipSuccess && !ctx->d_model) e = hipMalloc((void **)&ctx->d_model, sizeof(ed_cnn_model_t));
+	if (e == hipSuccess && !ctx->d_model_mfma) e = hipMalloc((void **)&ctx->d_model_mfma, sizeof(ed_cnn_mfma_model_t));
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 	if (e == hipSuccess) e = hipMemcpy(ctx->d_model, h, sizeof(ed_cnn_model_t), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(ctx->d_model_mfma, hm, sizeof(ed_cnn_mfma_model_t), hipMemcpyHostToDevice);
 	free(h);
+	free(hm);
 	ED_HIP(ctx, e);
 	ctx->have_model = 1;
 	return EDISON_OK;
@@ -320,7 +329,9 @@ static int cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t
 	if (!ctx || n_utt < 0 || (!feat && n_utt > 0)) return EDISON_E_ARGUMENT;
 	if (!ctx->have_model) return set_err(ctx, EDISON_E_NO_MODEL, "no CNN model loaded (edison_model_load)");
 	if (n_utt == 0) return EDISON_OK;
-	int e = ed_launch_cnn(ctx->d_model, feat, n_utt, logits, softmax, argmax, acts, ctx->n_cu, ctx->stream);
+	/* per-layer activations come from the layer-by-layer kernel; everything else runs on the matrix cores */
+	int e = acts ? ed_launch_cnn(ctx->d_model, feat, n_utt, logits, softmax, argmax, acts, ctx->n_cu, ctx->stream)
+	             : ed_launch_cnn_mfma(ctx->d_model_mfma, feat, n_utt, logits, softmax, argmax, ctx->n_cu, ctx->stream);
 	if (e != 0)
 	{
 		snprintf(ctx->err, sizeof(ctx->err), "CNN kernel launch failed: %s", hipGetErrorString((hipError_t)e));

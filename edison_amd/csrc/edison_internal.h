@@ -71,7 +71,31 @@ typedef struct {
 	int32_t pad_[3];
 } ed_cnn_model_t;
 
-int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, char *err, size_t err_cap);
+/*
+ * The same parameters laid out for v_mfma_i32_32x32x32_i8 (fast path, cnn_mfma_kernels.hip). Every layer is the
+ * GEMM D[out_channel][pixel] = sum_k A[out_channel][k] * B[k][pixel]; A (weights) is stored as ready-made
+ * operand fragments: fragment = 64 lanes x 16 bytes, lane l holds A[row = l&31][k = 32*kstep + 16*(l>>5) + j],
+ * j = 0..15, so a wavefront fetches one fragment with a single conflict-free ds_read_b128.
+ *   a1  conv1 as a Toeplitz GEMM: row = x*16 + o (9 x 16 = 144 rows -> 5 row tiles), k = ky*16 + xx over five
+ *       16-byte-padded input rows (K = 80 -> 3 k-steps); A = w1[o][ky][xx - x] inside the 5-tap window, else 0
+ *   a2  conv2: 32 rows, k = tap*16 + ci (K = 144 -> 5 k-steps, the last half zero)
+ *   a3  conv3: 64 rows (2 row tiles), k = tap*32 + ci (9 k-steps)
+ *   a4  conv4: 32 rows, k = tap*64 + ci (18 k-steps)
+ *   afc dense: 10 rows padded to 32, k = 96 (3 k-steps)
+ */
+typedef struct {
+	int8_t a1[15][1024]; /* [row_tile*3 + kstep] */
+	int8_t a2[5][1024];
+	int8_t a3[18][1024]; /* [row_tile*9 + kstep] */
+	int8_t a4[18][1024];
+	int8_t afc[3][1024];
+	int32_t b1[ED_C1_O], b2[ED_C2_O], b3[ED_C3_O], b4[ED_C4_O], bfc[16]; /* accumulator seeds as above */
+	int32_t rs1, rs2, rs3, rs4, rsfc;
+	int32_t pad_[3];
+} ed_cnn_mfma_model_t;
+
+int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, ed_cnn_mfma_model_t *out_mfma, char *err,
+                   size_t err_cap);
 
 /* ------------------------------------------------------------------ kernel launchers (HIP side)           */
 typedef struct {

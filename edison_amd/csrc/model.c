@@ -40,7 +40,30 @@ static void pack(const int8_t *w, int O, int K, int K4, int OS, int32_t *out)
 		}
 }
 
-int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, char *err, size_t err_cap)
+/* Fill one MFMA A-operand fragment: lane l, byte j  <-  a(row0 + (l & 31), 32*kstep + 16*(l >> 5) + j). */
+typedef int8_t (*a_elem_fn)(const int8_t *w, int row, int k);
+
+static void fill_frag(int8_t *frag, const int8_t *w, a_elem_fn a, int row0, int kstep)
+{
+	for (int l = 0; l < 64; l++)
+		for (int j = 0; j < 16; j++)
+			frag[l * 16 + j] = a(w, row0 + (l & 31), 32 * kstep + 16 * (l >> 5) + j);
+}
+
+/* conv1 as Toeplitz: row = x*16 + o, k = ky*16 + xx; w1 is OHWI [16][5][5][1] */
+static int8_t a1_elem(const int8_t *w, int row, int k)
+{
+	const int x = row >> 4, o = row & 15, ky = k >> 4, xx = k & 15;
+	if (x >= 9 || ky >= 5 || xx - x < 0 || xx - x >= 5) return 0;
+	return w[(o * 5 + ky) * 5 + (xx - x)];
+}
+static int8_t a2_elem(const int8_t *w, int row, int k) { return k < 144 ? w[row * 144 + k] : 0; } /* k = tap*16+ci */
+static int8_t a3_elem(const int8_t *w, int row, int k) { return w[row * 288 + k]; }                /* k = tap*32+ci */
+static int8_t a4_elem(const int8_t *w, int row, int k) { return w[row * 576 + k]; }                /* k = tap*64+ci */
+static int8_t afc_elem(const int8_t *w, int row, int k) { return row < ED_FC_O ? w[row * ED_FC_I + k] : 0; }
+
+int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, ed_cnn_mfma_model_t *out_mfma, char *err,
+                   size_t err_cap)
 {
 	const unsigned char *p = (const unsigned char *)blob;
 	if (blob == NULL || blob_bytes < 40 || memcmp(p, "EDNNOM1\0", 8) != 0) return fail(err, err_cap, "not an .ednn model blob");
@@ -95,5 +118,22 @@ int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, cha
 	for (int o = 0; o < ED_C4_O; o++) out->b4[o] = seed(payload[r[5].v[10] + o], r[5].v[6], r[5].v[7]);
 	for (int o = 0; o < ED_FC_O; o++) out->bfc[o] = seed(payload[r[6].v[10] + o], r[6].v[6], r[6].v[7]);
 	out->rs1 = r[0].v[7]; out->rs2 = r[2].v[7]; out->rs3 = r[4].v[7]; out->rs4 = r[5].v[7]; out->rsfc = r[6].v[7];
+
+	if (out_mfma)
+	{
+		ed_cnn_mfma_model_t *m = out_mfma;
+		memset(m, 0, sizeof(*m));
+		for (int rt = 0; rt < 5; rt++)
+			for (int s = 0; s < 3; s++) fill_frag(m->a1[rt * 3 + s], payload + r[0].v[9], a1_elem, 32 * rt, s);
+		for (int s = 0; s < 5; s++) fill_frag(m->a2[s], payload + r[2].v[9], a2_elem, 0, s);
+		for (int rt = 0; rt < 2; rt++)
+			for (int s = 0; s < 9; s++) fill_frag(m->a3[rt * 9 + s], payload + r[4].v[9], a3_elem, 32 * rt, s);
+		for (int s = 0; s < 18; s++) fill_frag(m->a4[s], payload + r[5].v[9], a4_elem, 0, s);
+		for (int s = 0; s < 3; s++) fill_frag(m->afc[s], payload + r[6].v[9], afc_elem, 0, s);
+		memcpy(m->b1, out->b1, sizeof(m->b1)); memcpy(m->b2, out->b2, sizeof(m->b2));
+		memcpy(m->b3, out->b3, sizeof(m->b3)); memcpy(m->b4, out->b4, sizeof(m->b4));
+		memcpy(m->bfc, out->bfc, sizeof(m->bfc));
+		m->rs1 = out->rs1; m->rs2 = out->rs2; m->rs3 = out->rs3; m->rs4 = out->rs4; m->rsfc = out->rsfc;
+	}
 	return EDISON_OK;
 }
