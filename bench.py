@@ -74,6 +74,19 @@ def synth_utterances(n_utt, seed, device, chunk=4096):
     return out
 
 
+def hbm_traffic_from_profiles(key):
+    """(bytes per launch, source file) from the newest profiles/r*_rocprof_summary.json, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprof_summary.json")))
+    if not files:
+        return None
+    try:
+        h = json.load(open(files[-1]))["hbm"][key]
+        return (round(h["FETCH_SIZE_bytes_corrected"] + h["WRITE_SIZE_bytes_corrected"]), os.path.relpath(files[-1], ROOT))
+    except (KeyError, ValueError):
+        return None
+
+
 def timed_region(step_fn, steps, warmup, world):
     """W untimed + exactly K timed steps, barrier + synchronize on both sides; returns (wall ms/step, event ms/step)."""
     for i in range(warmup):
@@ -186,6 +199,12 @@ def main():
                     units_per_launch=nf, kernel_ms=round(ev_ms, 4))
     checksum = float(out.double().sum().item())
     del bufs
+    # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
+    # this command, FETCH_SIZE doubled as the gfx950 guide prescribes); only valid for the default batch size
+    tr = hbm_traffic_from_profiles("ed_mfcc_kernel<false, true>:short") if nf == 65536 else None
+    if tr is not None:
+        roofline["traffic"] = tr[0]
+        roofline["traffic_source"] = tr[1]
 
     # ------------------------------------------------------------------ kws: MFCC + int8 CNN (+ all-gather) (configs[2]/[3])
     kws = None
