@@ -31,7 +31,7 @@ struct edison_ctx
 	hipStream_t own_stream;
 	hipStream_t stream;
 	ed_mfcc_tables_t *d_tab[2]; /* variant A, B */
-	int mel_T4[2];
+	int mel_NLO[2], mel_NHI[2];
 	ed_cnn_model_t *d_model;           /* layer-by-layer diagnostic kernel (edison_cnn_layers) */
 	ed_cnn_mfma_model_t *d_model_mfma; /* MFMA fast path                                       */
 	int have_model;
@@ -72,7 +72,8 @@ static int upload_tables(edison_ctx *ctx, double fs, double lo, double hi, doubl
 		/* synchronous w.r.t. the stream: a kernel in flight may still be reading the old tables */
 		ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		hipError_t e = hipMemcpy(ctx->d_tab[v], h, sizeof(ed_mfcc_tables_t), hipMemcpyHostToDevice);
-		ctx->mel_T4[v] = h->mel_T4;
+		ctx->mel_NLO[v] = h->mel_NLO;
+		ctx->mel_NHI[v] = h->mel_NHI;
 		free(h);
 		ED_HIP(ctx, e);
 	}
@@ -297,7 +298,8 @@ static int mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, 
 	memset(&a, 0, sizeof(a));
 	a.audio = audio; a.n_frames = n_frames; a.frames_per_group = fpg; a.group_stride = group_stride;
 	a.frame_step = frame_step; a.n_coef = n_coef; a.use_log = (variant & EDISON_MFCC_USE_LOG) ? 1 : 0;
-	a.mel_T4 = ctx->mel_T4[v];
+	a.mel_NLO = ctx->mel_NLO[v];
+	a.mel_NHI = ctx->mel_NHI[v];
 	a.mfcc = mfcc; a.feat = feat; a.feat_scale = feat_scale;
 	a.fft = fft; a.spec = spec; a.mel = mel; a.logmel = logmel;
 	int e = ed_launch_mfcc(&a, ctx->d_tab[v], stages, ctx->n_cu, ctx->stream);

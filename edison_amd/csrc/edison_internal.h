@@ -13,7 +13,9 @@ extern "C" {
 #endif
 
 /* ------------------------------------------------------------------ MFCC device tables (one per variant) */
-#define ED_MEL_T4_MAX 12  /* spectrum quads per lane; the shipped filterbank needs 10 (widest band = 71 bins) */
+#define ED_MEL_NLO_MAX 3  /* spectrum quads per lane for the narrow band of its pair (shipped filterbank: 2)  */
+#define ED_MEL_NHI_MAX 6  /* ... and for the wide band (shipped: 5; the widest band spans 19 quads / 4 lanes) */
+#define ED_MEL_TQ_MAX (ED_MEL_NLO_MAX + ED_MEL_NHI_MAX)
 #define ED_SPEC_QUADS 129 /* spectrum buffer = 513 bins padded to 516 floats                                  */
 
 typedef struct {
@@ -21,17 +23,20 @@ typedef struct {
 	 * 512-point complex FFT of the packed real frame, 3 radix-8 passes (see mfcc_kernels.hip):               */
 	float tw1[8][64][2]; /* [p][lane]   W512^(lane*p), p = 0..7 (p = 0 unused)                               */
 	float tw2[8][64][2]; /* [q][lane]   W64^((lane&7)*q)                                                     */
-	/* mel filterbank: lane = (j = lane&31, h = lane>>5) sums half h of band j's taps, reading the spectrum
-	 * as 16-byte quads mel_start4[lane] + t, t < mel_T4, against mel_w4[t][lane][0..3]                       */
-	int32_t mel_start4[64];
-	/* ---- the block below is copied verbatim into LDS by every workgroup (ED_LDS_TAB_FLOATS(T4) floats) ---- */
-	/* DCT-II with the variant's normalisation folded in: lane (c = lane&31, h = lane>>5),
-	 * dct4[n4][lane][j] = scale * 2*cos(pi*c*(2*(4*n4+j+16h)+1)/64)                                         */
-	float dct4[4][64][4];
+	/* mel filterbank, balanced: lane (b = lane&15, r = lane>>4) owns quarter r of TWO bands -- the narrow band
+	 * b and the wide band 31-b -- and reads the spectrum as 16-byte quads: mel_slo4[lane] + t, t < mel_NLO,
+	 * against mel_w4[t][lane], then mel_shi4[lane] + t, t < mel_NHI, against mel_w4[mel_NLO + t][lane].
+	 * The four quarters of a band are summed across the lane rows (xor 16, xor 32).                          */
+	int32_t mel_slo4[64], mel_shi4[64];
+	/* ---- the block below is copied verbatim into LDS by every workgroup ---- */
+	/* DCT-II with the variant's normalisation folded in, using D[31-n][c] = (-1)^c D[n][c]:
+	 * y[c] = sum_{n<16} D[n][c] * (L[n] + (-1)^c L[31-n]); lane (c = lane&31, h = lane>>5) sums n = 8h..8h+7,
+	 * dct4[n4][lane][j] = scale * 2*cos(pi*c*(2*(8h+4*n4+j)+1)/64)                                           */
+	float dct4[2][64][4];
 	float twp[4][64][2]; /* [m][lane]   W1024^(lane+64m): real-FFT split twiddles                            */
-	float mel_w4[ED_MEL_T4_MAX][64][4];
+	float mel_w4[ED_MEL_TQ_MAX][64][4];
 	/* ---- end of the LDS image ---- */
-	int32_t mel_T4;
+	int32_t mel_NLO, mel_NHI;
 	float spec_scale; /* applied to 2|X[k]|: A 0.5, B 0.5/1024/sqrt(2)                                       */
 	float log_offset; /* 1e-6                                                                                */
 	int32_t always_log; /* variant A                                                                         */
@@ -106,8 +111,7 @@ typedef struct {
 	int64_t frame_step;
 	int n_coef;
 	int use_log;
-	int mel_T4;               /* host copy of the variant's ed_mfcc_tables_t.mel_T4 (sizes the LDS tables)  */
-	int pad_;
+	int mel_NLO, mel_NHI;     /* host copies of the variant's ed_mfcc_tables_t fields (size the LDS tables) */
 	float *mfcc;      /* [n_frames][n_coef] or NULL */
 	int8_t *feat;     /* [n_frames][n_coef] or NULL */
 	float feat_scale;

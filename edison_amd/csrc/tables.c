@@ -90,44 +90,58 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 	 * (mfcc_utils.py:282,309); in float arithmetic that is the identity up to rounding, so the device
 	 * uses the unscaled matrix. mel_mtx_scale is accepted for signature compatibility. */
 	(void)mel_mtx_scale;
-	/* Lane (band j = lane&31, half h = lane>>5) owns the taps [a, b) of its band and reads the spectrum as
-	 * 16-byte quads: quad index s4 + t, t < T4, weights w[t][lane][0..3] (zero outside [a, b)). */
-	int T4 = 1;
-	int la[64], lb[64];
-	for (int l = 0; l < 64; l++)
+	/* Balanced tap assignment. The spectrum is read as 16-byte quads; band j spans the quads q0[j]..q1[j].
+	 * Band widths grow with frequency (7..71 bins), so lane (b = lane&15, r = lane>>4) takes quarter r of the
+	 * narrow band b AND quarter r of the wide band 31-b: n = ceil(quads/4) consecutive quads of each. */
+	int q0[EDISON_NUM_MEL], nq[EDISON_NUM_MEL], ks[EDISON_NUM_MEL], ke[EDISON_NUM_MEL];
+	for (int j = 0; j < NMEL; j++)
 	{
-		const int j = l & 31, h = l >> 5;
 		int first = -1, last = -1;
 		for (int k = 0; k < nbins; k++)
 			if (W[(size_t)k * NMEL + j] != 0.0) { if (first < 0) first = k; last = k; }
 		if (first < 0) { first = 0; last = -1; } /* empty band (degenerate edges) */
-		const int ks = first, ke = last + 1, half = (ke - ks + 1) / 2;
-		la[l] = h == 0 ? ks : (ks + half < ke ? ks + half : ke);
-		lb[l] = h == 0 ? (ks + half < ke ? ks + half : ke) : ke;
-		const int quads = lb[l] > la[l] ? (lb[l] - 1) / 4 - la[l] / 4 + 1 : 0;
-		if (quads > T4) T4 = quads;
+		ks[j] = first; ke[j] = last + 1;
+		q0[j] = first / 4;
+		nq[j] = last >= first ? last / 4 - first / 4 + 1 : 0;
 	}
-	if (T4 > ED_MEL_T4_MAX)
+	int NLO = 1, NHI = 1;
+	for (int b = 0; b < 16; b++)
 	{
-		if (err) snprintf(err, err_cap, "mel band needs %d spectrum quads per half, the kernel's budget is %d", T4,
-		                  ED_MEL_T4_MAX);
+		if ((nq[b] + 3) / 4 > NLO) NLO = (nq[b] + 3) / 4;
+		if ((nq[31 - b] + 3) / 4 > NHI) NHI = (nq[31 - b] + 3) / 4;
+	}
+	if (NLO > ED_MEL_NLO_MAX || NHI > ED_MEL_NHI_MAX)
+	{
+		if (err) snprintf(err, err_cap, "mel filterbank needs %d+%d spectrum quads per lane, the kernel's budget is %d+%d",
+		                  NLO, NHI, ED_MEL_NLO_MAX, ED_MEL_NHI_MAX);
 		free(W);
 		return EDISON_E_NO_IMPL;
 	}
-	out->mel_T4 = T4;
+	/* the kernel is compiled for two table shapes: 2+5 quads per lane (the shipped filterbank) and 3+6 */
+	if (NLO <= 2 && NHI <= 5) { NLO = 2; NHI = 5; } else { NLO = ED_MEL_NLO_MAX; NHI = ED_MEL_NHI_MAX; }
+	out->mel_NLO = NLO; out->mel_NHI = NHI;
 	for (int l = 0; l < 64; l++)
 	{
-		const int j = l & 31;
-		int s4 = la[l] / 4;
-		if (s4 > ED_SPEC_QUADS - T4) s4 = ED_SPEC_QUADS - T4; /* keep every read inside the padded spectrum */
-		if (s4 < 0) s4 = 0;
-		out->mel_start4[l] = s4;
-		for (int t = 0; t < T4; t++)
-			for (int c = 0; c < 4; c++)
-			{
-				const int k = 4 * (s4 + t) + c;
-				out->mel_w4[t][l][c] = (k >= la[l] && k < lb[l] && k < nbins) ? (float)W[(size_t)k * NMEL + j] : 0.0f;
-			}
+		const int b = l & 15, rr = l >> 4;
+		for (int part = 0; part < 2; part++)
+		{
+			const int j = part == 0 ? b : 31 - b, N = part == 0 ? NLO : NHI;
+			const int per = (nq[j] + 3) / 4;                   /* quads per quarter of this band            */
+			const int pq0 = q0[j] + rr * per;                  /* this lane's quads: [pq0, pq1)             */
+			int pq1 = pq0 + per;
+			if (pq1 > q0[j] + nq[j]) pq1 = q0[j] + nq[j];
+			int s4 = pq0;
+			if (s4 > ED_SPEC_QUADS - N) s4 = ED_SPEC_QUADS - N; /* keep every read inside the padded spectrum */
+			if (s4 < 0) s4 = 0;
+			if (part == 0) out->mel_slo4[l] = s4; else out->mel_shi4[l] = s4;
+			for (int t = 0; t < N; t++)
+				for (int c = 0; c < 4; c++)
+				{
+					const int q = s4 + t, k = 4 * q + c;
+					const int mine = q >= pq0 && q < pq1 && k >= ks[j] && k < ke[j] && k < nbins;
+					out->mel_w4[(part == 0 ? 0 : NLO) + t][l][c] = mine ? (float)W[(size_t)k * NMEL + j] : 0.0f;
+				}
+		}
 	}
 	free(W);
 
@@ -136,9 +150,9 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 	for (int l = 0; l < 64; l++)
 	{
 		int c = l & 31, h = l >> 5;
-		for (int n = 0; n < 16; n++)
+		for (int n = 0; n < 8; n++)
 		{
-			int nn = n + 16 * h;
+			int nn = n + 8 * h; /* 0..15; the kernel folds in n' = 31 - nn through cos symmetry */
 			out->dct4[n / 4][l][n % 4] =
 			    (float)(dscale * 2.0 * cos(M_PI * (double)c * (double)(2 * nn + 1) / (double)(2 * NMEL)));
 		}

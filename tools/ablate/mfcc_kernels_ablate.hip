@@ -24,15 +24,17 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "edison_internal.h"
+#ifndef ED_ABLATE
+#define ED_ABLATE 0
+#endif
 
 #ifndef ED_WPB
 #define ED_WPB 8                 /* waves (= frames in flight) per workgroup                               */
 #endif
 #define ED_XBUF_FLOATS 1160      /* per-wave LDS: 576 complex exchange slots (also Pz + S + L) + pad        */
-#define ED_FIXTAB_FLOATS (2 * 64 * 4 + 4 * 64 * 2) /* dct | split twiddles, then (NLO+NHI) x 64 weight quads */
+#define ED_FIXTAB_FLOATS (4 * 64 * 4 + 4 * 64 * 2) /* dct | split twiddles, then mel_T4 x 64 weight quads   */
 
 #ifdef ED_MIN_WAVES
 #define ED_MFCC_BOUNDS __launch_bounds__(64 * ED_WPB, ED_MIN_WAVES)
@@ -111,22 +113,23 @@ __device__ __forceinline__ void ed_load_frame(const int16_t *fp, int lane, uint3
 	}
 }
 
-template <bool STAGES, bool ALIGNED, int NLO, int NHI>
+template <bool STAGES, bool ALIGNED>
 __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
 {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const float4 *dctl = reinterpret_cast<const float4 *>(smem);                 /* [2][64] x 4 coefficients */
-	const float2 *tpl = reinterpret_cast<const float2 *>(smem + 512);            /* [4][64] W1024^(lane+64m) */
-	const float4 *melw4 = reinterpret_cast<const float4 *>(smem + ED_FIXTAB_FLOATS); /* [NLO+NHI][64] quads   */
-	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + wave * ED_XBUF_FLOATS; /* wave-private      */
+	const int T4 = args.mel_T4;                                                  /* == tab->mel_T4          */
+	const float4 *dctl = reinterpret_cast<const float4 *>(smem);                 /* [4][64] x 4 coefficients */
+	const float2 *tpl = reinterpret_cast<const float2 *>(smem + 1024);           /* [4][64] W1024^(lane+64m) */
+	const float4 *melw4 = reinterpret_cast<const float4 *>(smem + ED_FIXTAB_FLOATS); /* [T4][64] weight quads */
+	float *xbuf = smem + ED_FIXTAB_FLOATS + T4 * 256 + wave * ED_XBUF_FLOATS;    /* wave-private            */
 	float2 *xc = reinterpret_cast<float2 *>(xbuf);
 
-	{ /* the table block [dct4 | twp | mel_w4(NLO+NHI rows)] is laid out in global memory exactly as in LDS */
+	{ /* the table block [dct4 | twp | mel_w4(T4 rows)] is laid out in global memory exactly as in LDS */
 		const float4 *src = reinterpret_cast<const float4 *>(&tab->dct4[0][0][0]);
 		float4 *dst = reinterpret_cast<float4 *>(smem);
-		for (int t = threadIdx.x; t < (ED_FIXTAB_FLOATS + (NLO + NHI) * 256) / 4; t += blockDim.x) dst[t] = src[t];
+		for (int t = threadIdx.x; t < (ED_FIXTAB_FLOATS + T4 * 256) / 4; t += blockDim.x) dst[t] = src[t];
 	}
 
 	/* pass-1/2 twiddles: resident in registers for the whole persistent loop */
@@ -144,7 +147,7 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 	 * them a fraction of a frame apart so that one wave's LDS-heavy transposes overlap another's arithmetic. */
 	for (int s = ((wave >> 2) * 2 + (blockIdx.x & 1)); s > 0; s--) __builtin_amdgcn_s_sleep(ED_STAGGER);
 #endif
-	const int mel_slo4 = tab->mel_slo4[lane], mel_shi4 = tab->mel_shi4[lane];
+	const int mel_start4 = tab->mel_start4[lane];
 	const float spec_scale = tab->spec_scale;
 	const float log_offset = tab->log_offset;
 	const bool do_log = tab->always_log || args.use_log;
@@ -169,7 +172,7 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		if (f + stride < n_frames) ed_load_frame<ALIGNED>(ed_frame_ptr(args, f + stride), lane, raw);
 
 		/* ---- 2a. pass 1: DFT over a, twiddle W512^(lane*p) */
-		ed_radix8(re, im);
+		if (!(ED_ABLATE & 8)) ed_radix8(re, im); else { for (int i_ = 0; i_ < 8; i_++) { re[i_] += im[(i_+1)&7]; } }
 #pragma unroll
 		for (int p = 1; p < 8; p++)
 		{
@@ -179,10 +182,10 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		}
 		/* transpose 1: (lane = 8b+c, reg p) -> (lane = 8p+c, reg b); slot = 72p + 8b + c */
 #pragma unroll
-		for (int p = 0; p < 8; p++) xc[72 * p + lane] = make_float2(re[p], im[p]);
+		for (int p = 0; p < ((ED_ABLATE & 4) ? 1 : 8); p++) xc[72 * p + lane] = make_float2(re[p], im[p]);
 		ed_wave_sync();
 #pragma unroll
-		for (int b = 0; b < 8; b++)
+		for (int b = 0; b < ((ED_ABLATE & 4) ? 1 : 8); b++)
 		{
 			float2 v = xc[72 * hi3 + 8 * b + lo3];
 			re[b] = v.x; im[b] = v.y;
@@ -190,7 +193,7 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		ed_wave_sync();
 
 		/* ---- 2b. pass 2: DFT over b, twiddle W64^(c*q) */
-		ed_radix8(re, im);
+		if (!(ED_ABLATE & 8)) ed_radix8(re, im); else { for (int i_ = 0; i_ < 8; i_++) { re[i_] += im[(i_+1)&7]; } }
 #pragma unroll
 		for (int q = 1; q < 8; q++)
 		{
@@ -200,10 +203,10 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		}
 		/* transpose 2: (lane = 8p+c, reg q) -> (lane = p+8q, reg c); slot = 66c + p + 8q */
 #pragma unroll
-		for (int q = 0; q < 8; q++) xc[66 * lo3 + hi3 + 8 * q] = make_float2(re[q], im[q]);
+		for (int q = 0; q < ((ED_ABLATE & 4) ? 1 : 8); q++) xc[66 * lo3 + hi3 + 8 * q] = make_float2(re[q], im[q]);
 		ed_wave_sync();
 #pragma unroll
-		for (int c = 0; c < 8; c++)
+		for (int c = 0; c < ((ED_ABLATE & 4) ? 1 : 8); c++)
 		{
 			float2 v = xc[66 * c + lane];
 			re[c] = v.x; im[c] = v.y;
@@ -211,7 +214,7 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		ed_wave_sync();
 
 		/* ---- 2c. pass 3: DFT over c  ->  reg r holds Z[lane + 64r] */
-		ed_radix8(re, im);
+		if (!(ED_ABLATE & 8)) ed_radix8(re, im); else { for (int i_ = 0; i_ < 8; i_++) { re[i_] += im[(i_+1)&7]; } }
 
 		/* ---- 3. real-FFT split. Partner buffer Pz[j] = Z[256 + j] (regs 4..7), read back reversed. */
 #pragma unroll
@@ -231,12 +234,12 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 			float ti = tw.y * bi - tw.x * br;
 			float xr = ar + tr, xi = ai + ti;           /* 2 X[k]                                            */
 			float yr = ar - tr, yi = ai - ti;           /* conj(2 X[512-k])                                  */
-			slo[m] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi) * spec_scale; /* v_sqrt_f32, 1 ulp */
-			shi[m] = __builtin_amdgcn_sqrtf(yr * yr + yi * yi) * spec_scale;
+			slo[m] = __fsqrt_rn(xr * xr + xi * xi) * spec_scale;
+			shi[m] = __fsqrt_rn(yr * yr + yi * yi) * spec_scale;
 			if (STAGES) { flr[m] = 0.5f * xr; fli[m] = 0.5f * xi; fhr[m] = 0.5f * yr; fhi[m] = -0.5f * yi; }
 		}
 		/* k = 256 pairs with itself: X[256] = conj(Z[256]) (lane 0, reg 4) */
-		const float s256 = 2.0f * __builtin_amdgcn_sqrtf(re[4] * re[4] + im[4] * im[4]) * spec_scale;
+		const float s256 = 2.0f * __fsqrt_rn(re[4] * re[4] + im[4] * im[4]) * spec_scale;
 
 		/* ---- 4. spectrum to LDS (floats 576..1091 of the wave buffer: disjoint from Pz; S[513..515] hold
 		 *         finite leftovers of the transposes and only ever meet zero weights) */
@@ -268,50 +271,41 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 			for (int k = lane; k < 513; k += 64) args.spec[(int64_t)f * 513 + k] = S[k];
 		}
 
-		/* ---- 5. mel filterbank, balanced: lane (b = lane&15, r = lane>>4) sums quarter r of the narrow band b
-		 *         and of the wide band 31-b; all quad reads of a part are issued before the first use */
-		const float4 *S4 = reinterpret_cast<const float4 *>(S);
-		float alo0 = 0.0f, alo1 = 0.0f, ahi0 = 0.0f, ahi1 = 0.0f;
-#pragma unroll
-		for (int t = 0; t < NLO; t++)
+		/* ---- 5. mel filterbank: lane (band, half) walks its taps a quad at a time */
+		const float4 *S4 = reinterpret_cast<const float4 *>(S) + mel_start4;
+		float acc0 = 0.0f, acc1 = 0.0f;
+		for (int t = 0; t < ((ED_ABLATE & 1) ? 1 : T4); t++)
 		{
-			const float4 s = S4[mel_slo4 + t], w = melw4[t * 64 + lane];
-			alo0 = fmaf(s.x, w.x, alo0); alo1 = fmaf(s.y, w.y, alo1);
-			alo0 = fmaf(s.z, w.z, alo0); alo1 = fmaf(s.w, w.w, alo1);
+			const float4 s = S4[t], w = melw4[t * 64 + lane];
+			acc0 = fmaf(s.x, w.x, acc0);
+			acc1 = fmaf(s.y, w.y, acc1);
+			acc0 = fmaf(s.z, w.z, acc0);
+			acc1 = fmaf(s.w, w.w, acc1);
 		}
-#pragma unroll
-		for (int t = 0; t < NHI; t++)
+		const float acc = acc0 + acc1;
+		float e = acc + __shfl_xor(acc, 32);
+		float lm = do_log ? logf(e + log_offset) : e;
+		if (STAGES && lane < 32)
 		{
-			/* at most three quad pairs (24 registers) in flight: bounds the register footprint of this stage */
-			if (t % 3 == 0) __builtin_amdgcn_sched_barrier(0);
-			const float4 s = S4[mel_shi4 + t], w = melw4[(NLO + t) * 64 + lane];
-			ahi0 = fmaf(s.x, w.x, ahi0); ahi1 = fmaf(s.y, w.y, ahi1);
-			ahi0 = fmaf(s.z, w.z, ahi0); ahi1 = fmaf(s.w, w.w, ahi1);
-		}
-		__builtin_amdgcn_sched_barrier(0);
-		float elo = alo0 + alo1, ehi = ahi0 + ahi1;
-		elo += __shfl_xor(elo, 16); ehi += __shfl_xor(ehi, 16); /* the four quarters live in the four lane rows */
-		elo += __shfl_xor(elo, 32); ehi += __shfl_xor(ehi, 32);
-		const float llo = do_log ? __logf(elo + log_offset) : elo; /* band b    */
-		const float lhi = do_log ? __logf(ehi + log_offset) : ehi; /* band 31-b */
-		if (STAGES && lane < 16)
-		{
-			if (args.mel) { args.mel[(int64_t)f * 32 + lane] = elo; args.mel[(int64_t)f * 32 + 31 - lane] = ehi; }
-			if (args.logmel) { args.logmel[(int64_t)f * 32 + lane] = llo; args.logmel[(int64_t)f * 32 + 31 - lane] = lhi; }
+			if (args.mel) args.mel[(int64_t)f * 32 + lane] = e;
+			if (args.logmel) args.logmel[(int64_t)f * 32 + lane] = lm;
 		}
 
-		/* ---- 6. DCT-II through cos symmetry: y[c] = sum_{n<16} D[n][c] * (L[n] + (-1)^c L[31-n]);
-		 *         lane (c = lane&31, h = lane>>5) sums n = 8h..8h+7 */
-		float *Lb = xbuf + 1104; /* u[16] | v[16], 16-B aligned */
-		if (lane < 16) { Lb[lane] = llo + lhi; Lb[16 + lane] = llo - lhi; }
+		/* ---- 6. DCT-II: lane (c = lane&31, h) sums n = 16h..16h+15 */
+		float *Lb = xbuf + 1104; /* 32 floats, 16-B aligned */
+		if (lane < 32) Lb[lane] = lm;
 		ed_wave_sync();
-		const float4 *L4 = reinterpret_cast<const float4 *>(Lb + 16 * (lane & 1) + 8 * (lane >> 5));
-		const float4 v0 = L4[0], v1 = L4[1], w0 = dctl[lane], w1 = dctl[64 + lane];
-		float d = v0.x * w0.x, d1 = v1.x * w1.x;
-		d = fmaf(v0.y, w0.y, d); d1 = fmaf(v1.y, w1.y, d1);
-		d = fmaf(v0.z, w0.z, d); d1 = fmaf(v1.z, w1.z, d1);
-		d = fmaf(v0.w, w0.w, d); d1 = fmaf(v1.w, w1.w, d1);
-		d += d1;
+		const float4 *L4 = reinterpret_cast<const float4 *>(Lb + 16 * (lane >> 5));
+		float d = 0.0f;
+#pragma unroll
+		for (int n4 = 0; n4 < ((ED_ABLATE & 2) ? 1 : 4); n4++)
+		{
+			const float4 v = L4[n4], w = dctl[64 * n4 + lane];
+			d = fmaf(v.x, w.x, d);
+			d = fmaf(v.y, w.y, d);
+			d = fmaf(v.z, w.z, d);
+			d = fmaf(v.w, w.w, d);
+		}
 		d += __shfl_xor(d, 32);
 		ed_wave_sync(); /* Lb / S are rewritten by the next frame */
 
@@ -329,25 +323,24 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 	}
 }
 
-static int g_mfcc_blocks_per_cu[2] = {-1, -1};
+static int g_mfcc_blocks_per_cu = -1;
 
-template <int NLO, int NHI>
-static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
-                                hipStream_t stream, int *blocks_per_cu)
+extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
+                              hipStream_t stream)
 {
-	const size_t lds = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED_WPB * ED_XBUF_FLOATS);
-	if (*blocks_per_cu < 0)
+	if (args->n_frames <= 0) return 0;
+	if (args->mel_T4 < 1 || args->mel_T4 > ED_MEL_T4_MAX) return (int)hipErrorInvalidValue;
+	const size_t lds = sizeof(float) * (ED_FIXTAB_FLOATS + args->mel_T4 * 256 + ED_WPB * ED_XBUF_FLOATS);
+	if (g_mfcc_blocks_per_cu < 0)
 	{
 		/* persistent grid = exactly what is resident; sized once from the fast kernel's occupancy */
 		int nb = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ed_mfcc_kernel<false, true, NLO, NHI>, 64 * ED_WPB, lds) != hipSuccess || nb < 1)
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ed_mfcc_kernel<false, true>, 64 * ED_WPB, lds) != hipSuccess || nb < 1)
 			nb = 1;
-		const char *env = getenv("ED_MFCC_BLOCKS_PER_CU"); /* tuning knob: cap the persistent grid */
-		if (env && atoi(env) > 0 && atoi(env) < nb) nb = atoi(env);
-		*blocks_per_cu = nb;
+		g_mfcc_blocks_per_cu = nb;
 	}
 	int64_t blocks = (args->n_frames + ED_WPB - 1) / ED_WPB;
-	const int64_t cap = (int64_t)n_cu * *blocks_per_cu;
+	const int64_t cap = (int64_t)n_cu * g_mfcc_blocks_per_cu;
 	if (blocks > cap) blocks = cap;
 	/* 4-byte loads need every frame start 4-byte aligned */
 	const bool aligned = ((reinterpret_cast<uintptr_t>(args->audio) & 3) == 0) && (args->frame_step % 2 == 0) &&
@@ -355,25 +348,13 @@ static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables
 	dim3 grid((unsigned)blocks), block(64 * ED_WPB);
 	if (stages)
 	{
-		if (aligned) hipLaunchKernelGGL((ed_mfcc_kernel<true, true, NLO, NHI>), grid, block, lds, stream, *args, dev_tab);
-		else hipLaunchKernelGGL((ed_mfcc_kernel<true, false, NLO, NHI>), grid, block, lds, stream, *args, dev_tab);
+		if (aligned) hipLaunchKernelGGL((ed_mfcc_kernel<true, true>), grid, block, lds, stream, *args, dev_tab);
+		else hipLaunchKernelGGL((ed_mfcc_kernel<true, false>), grid, block, lds, stream, *args, dev_tab);
 	}
 	else
 	{
-		if (aligned) hipLaunchKernelGGL((ed_mfcc_kernel<false, true, NLO, NHI>), grid, block, lds, stream, *args, dev_tab);
-		else hipLaunchKernelGGL((ed_mfcc_kernel<false, false, NLO, NHI>), grid, block, lds, stream, *args, dev_tab);
+		if (aligned) hipLaunchKernelGGL((ed_mfcc_kernel<false, true>), grid, block, lds, stream, *args, dev_tab);
+		else hipLaunchKernelGGL((ed_mfcc_kernel<false, false>), grid, block, lds, stream, *args, dev_tab);
 	}
 	return (int)hipGetLastError();
-}
-
-extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
-                              hipStream_t stream)
-{
-	if (args->n_frames <= 0) return 0;
-	/* the two table shapes tables.c produces */
-	if (args->mel_NLO == 2 && args->mel_NHI == 5)
-		return ed_launch_mfcc_shape<2, 5>(args, dev_tab, stages, n_cu, stream, &g_mfcc_blocks_per_cu[0]);
-	if (args->mel_NLO == ED_MEL_NLO_MAX && args->mel_NHI == ED_MEL_NHI_MAX)
-		return ed_launch_mfcc_shape<ED_MEL_NLO_MAX, ED_MEL_NHI_MAX>(args, dev_tab, stages, n_cu, stream, &g_mfcc_blocks_per_cu[1]);
-	return (int)hipErrorInvalidValue;
 }
