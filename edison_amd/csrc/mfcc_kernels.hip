@@ -48,6 +48,22 @@ __device__ __forceinline__ void ed_wave_sync()
 	__builtin_amdgcn_wave_barrier();
 }
 
+/* x[lane] + x[lane ^ 32] in every lane: v_permlane32_swap exchanges the upper half of one register with the
+ * lower half of another, so swapping a register with a copy of itself leaves (lo,lo) and (hi,hi). */
+__device__ __forceinline__ float ed_sum_halves(float x)
+{
+	const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+	return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+/* sum over the four 16-lane rows, result in every lane: v_permlane16_swap (odd rows of one register <-> even rows
+ * of the other) gives the row-pair sums, ed_sum_halves finishes. */
+__device__ __forceinline__ float ed_sum_rows(float x)
+{
+	const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+	return ed_sum_halves(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+}
+
 __device__ __forceinline__ void ed_dft4(float y0r, float y0i, float y1r, float y1i, float y2r, float y2i, float y3r,
                                         float y3i, float &o0r, float &o0i, float &o1r, float &o1i, float &o2r,
                                         float &o2i, float &o3r, float &o3i)
@@ -123,6 +139,13 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + wave * ED_XBUF_FLOATS; /* wave-private      */
 	float2 *xc = reinterpret_cast<float2 *>(xbuf);
 
+	/* the first frame's samples go in flight before anything else: their HBM latency hides under the table staging */
+	const uint32_t n_frames = (uint32_t)args.n_frames;
+	const uint32_t stride = gridDim.x * ED_WPB;
+	uint32_t f = blockIdx.x * ED_WPB + wave;
+	uint32_t raw[8];
+	if (f < n_frames) ed_load_frame<ALIGNED>(ed_frame_ptr(args, f), lane, raw);
+
 	{ /* the table block [dct4 | twp | mel_w4(NLO+NHI rows)] is laid out in global memory exactly as in LDS */
 		const float4 *src = reinterpret_cast<const float4 *>(&tab->dct4[0][0][0]);
 		float4 *dst = reinterpret_cast<float4 *>(smem);
@@ -149,12 +172,6 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 	const float log_offset = tab->log_offset;
 	const bool do_log = tab->always_log || args.use_log;
 	const int hi3 = lane >> 3, lo3 = lane & 7;
-
-	const uint32_t n_frames = (uint32_t)args.n_frames;
-	const uint32_t stride = gridDim.x * ED_WPB;
-	uint32_t f = blockIdx.x * ED_WPB + wave;
-	uint32_t raw[8];
-	if (f < n_frames) ed_load_frame<ALIGNED>(ed_frame_ptr(args, f), lane, raw);
 
 	for (; f < n_frames; f += stride)
 	{
@@ -213,17 +230,19 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		/* ---- 2c. pass 3: DFT over c  ->  reg r holds Z[lane + 64r] */
 		ed_radix8(re, im);
 
-		/* ---- 3. real-FFT split. Partner buffer Pz[j] = Z[256 + j] (regs 4..7), read back reversed. */
-#pragma unroll
-		for (int r = 4; r < 8; r++) xc[lane + 64 * (r - 4)] = make_float2(re[r], im[r]);
-		ed_wave_sync();
+		/* ---- 3. real-FFT split. The partner Z[512-k] of k = lane + 64m (m < 4) is register 7-m of lane
+		 *         (64 - lane) % 64: pulled through the LDS crossbar (ds_bpermute, no LDS memory, one trip).
+		 *         Lane 0 is its own partner, one register further up: Z[512 - 64m] = its register 8-m (Z[512] = Z[0]). */
 		float slo[4], shi[4];
 		float flr[4], fli[4], fhr[4], fhi[4]; /* X[k], X[512-k] for the stage dump */
+		const int pull = ((64 - lane) & 63) << 2;
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 		{
-			float2 pz = xc[256 - lane - 64 * m]; /* Z[512 - k]; slot 256 (lane 0, m 0) is Z[512] = Z[0] */
-			if (m == 0 && lane == 0) pz = make_float2(re[0], im[0]);
+			float2 pz;
+			pz.x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m])));
+			pz.y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m])));
+			if (lane == 0) pz = make_float2(re[(8 - m) & 7], im[(8 - m) & 7]);
 			const float2 tw = tpl[64 * m + lane];
 			float ar = re[m] + pz.x, ai = im[m] - pz.y; /* A  = Z[k] + conj Z[512-k]          = 2 E[k]      */
 			float br = re[m] - pz.x, bi = im[m] + pz.y; /* B  = Z[k] - conj Z[512-k]; O2 = -i*B = 2 O[k]    */
@@ -289,9 +308,8 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 			ahi0 = fmaf(s.z, w.z, ahi0); ahi1 = fmaf(s.w, w.w, ahi1);
 		}
 		__builtin_amdgcn_sched_barrier(0);
-		float elo = alo0 + alo1, ehi = ahi0 + ahi1;
-		elo += __shfl_xor(elo, 16); ehi += __shfl_xor(ehi, 16); /* the four quarters live in the four lane rows */
-		elo += __shfl_xor(elo, 32); ehi += __shfl_xor(ehi, 32);
+		/* the four quarters live in the four 16-lane rows: sum them with VALU row swaps (no LDS trip) */
+		const float elo = ed_sum_rows(alo0 + alo1), ehi = ed_sum_rows(ahi0 + ahi1);
 		const float llo = do_log ? __logf(elo + log_offset) : elo; /* band b    */
 		const float lhi = do_log ? __logf(ehi + log_offset) : ehi; /* band 31-b */
 		if (STAGES && lane < 16)
@@ -311,8 +329,7 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		d = fmaf(v0.y, w0.y, d); d1 = fmaf(v1.y, w1.y, d1);
 		d = fmaf(v0.z, w0.z, d); d1 = fmaf(v1.z, w1.z, d1);
 		d = fmaf(v0.w, w0.w, d); d1 = fmaf(v1.w, w1.w, d1);
-		d += d1;
-		d += __shfl_xor(d, 32);
+		d = ed_sum_halves(d + d1);
 		ed_wave_sync(); /* Lb / S are rewritten by the next frame */
 
 		/* ---- 7. store */
