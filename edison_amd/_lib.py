@@ -50,6 +50,12 @@ SIGNATURES = {
     "edison_cnn_batch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "edison_cnn_layers": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "edison_kws_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_stream_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "edison_stream_destroy": (None, [c_void_p]),
+    "edison_stream_reset": (c_int, [c_void_p]),
+    "edison_stream_push_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_stream_push": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_stream_frames_seen": (c_int64, [c_void_p]),
     # legacy firmware call surface
     "aiInitialize": (c_int, []),
     "aiGetInputShape": (None, [ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint16)]),

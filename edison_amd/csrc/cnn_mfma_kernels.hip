@@ -57,7 +57,7 @@ __device__ __forceinline__ int edm_max(int a, int b) { return a > b ? a : b; }
 
 __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_mfma_model_t *__restrict__ model,
                                                                  const int8_t *__restrict__ feat, int64_t n_utt,
-                                                                 int8_t *__restrict__ logits,
+                                                                 int64_t feat_stride, int8_t *__restrict__ logits,
                                                                  int8_t *__restrict__ softmax,
                                                                  int32_t *__restrict__ argmax)
 {
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 			uint32_t d[4] = {0, 0, 0, 0};
 			if (u < nb)
 			{
-				const uint8_t *g = reinterpret_cast<const uint8_t *>(feat) + (base + u) * (int64_t)(ED_IN_H * ED_IN_W) + y * ED_IN_W;
+				const uint8_t *g = reinterpret_cast<const uint8_t *>(feat) + (base + u) * feat_stride + y * ED_IN_W;
 #pragma unroll
 				for (int j = 0; j < ED_IN_W; j++) d[j >> 2] |= (uint32_t)g[j] << (8 * (j & 3));
 			}
@@ -291,8 +291,11 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 
 static int g_cnn_mfma_ready = 0;
 
-extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const int8_t *feat, int64_t n_utt, int8_t *logits,
-                                  int8_t *softmax, int32_t *argmax, int n_cu, hipStream_t stream)
+/* feat_stride = bytes between consecutive utterances' feature maps: 403 for packed utterances, 13 for the
+ * sliding windows of a stream (window i = feature rows i..i+30 of one long [rows][13] buffer). */
+extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const int8_t *feat, int64_t n_utt,
+                                  int64_t feat_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu,
+                                  hipStream_t stream)
 {
 	if (n_utt <= 0) return 0;
 	const size_t lds = sizeof(ed_cnn_mfma_model_t) + (size_t)EDM_U * EDM_UTT;
@@ -306,6 +309,6 @@ extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const in
 	int64_t blocks = (n_utt + EDM_U - 1) / EDM_U;
 	if (blocks > n_cu) blocks = n_cu; /* 157 KB of LDS: one workgroup per CU */
 	hipLaunchKernelGGL(ed_cnn_mfma_kernel, dim3((unsigned)blocks), dim3(EDM_THREADS), lds, stream, dev_model, feat, n_utt,
-	                   logits, softmax, argmax);
+	                   feat_stride, logits, softmax, argmax);
 	return (int)hipGetLastError();
 }

@@ -1,0 +1,63 @@
+/*
+ * edison_ctx.h -- the context object behind the opaque `edison_ctx *` of include/edison_hip.h, shared by the
+ * HIP shim files (edison_hip.hip, edison_stream.hip). Not part of the public ABI.
+ */
+#ifndef EDISON_CTX_H
+#define EDISON_CTX_H
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include "../../include/edison_hip.h"
+#include "edison_internal.h"
+
+extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
+                              hipStream_t stream);
+extern "C" int ed_launch_cnn(const ed_cnn_model_t *dev_model, const int8_t *feat, int64_t n_utt, int8_t *logits,
+                             int8_t *softmax, int32_t *argmax, int8_t *acts, int n_cu, hipStream_t stream);
+extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const int8_t *feat, int64_t n_utt,
+                                  int64_t feat_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu,
+                                  hipStream_t stream);
+
+struct edison_ctx
+{
+	int device;
+	int n_cu;
+	size_t hbm_bytes;
+	char name[128];
+	hipStream_t own_stream;
+	hipStream_t stream;
+	ed_mfcc_tables_t *d_tab[2]; /* variant A, B */
+	int mel_NLO[2], mel_NHI[2];
+	ed_cnn_model_t *d_model;           /* layer-by-layer diagnostic kernel (edison_cnn_layers) */
+	ed_cnn_mfma_model_t *d_model_mfma; /* MFMA fast path                                       */
+	int have_model;
+	/* growable device scratch for the host-pointer entry points and the fused KWS path */
+	void *scratch;
+	size_t scratch_bytes;
+	char err[512];
+};
+
+#define ED_HIP(ctx, call)                                                                                     \
+	do {                                                                                                      \
+		hipError_t e_ = (call);                                                                               \
+		if (e_ != hipSuccess)                                                                                 \
+		{                                                                                                     \
+			snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+			         __FILE__, __LINE__);                                                                     \
+			return EDISON_E_RUNTIME;                                                                          \
+		}                                                                                                     \
+	} while (0)
+
+static inline int ed_set_err(edison_ctx *ctx, int code, const char *msg)
+{
+	if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
+	return code;
+}
+
+/* Fill the launch arguments of the MFCC kernel for `variant` and enqueue it on the context's stream. */
+int ed_ctx_mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
+                       int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
+                       int stages, float *fft, float *spec, float *mel, float *logmel);
+
+#endif

@@ -11,54 +11,11 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../../include/edison_hip.h"
-#include "edison_internal.h"
-
-extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
-                              hipStream_t stream);
-extern "C" int ed_launch_cnn(const ed_cnn_model_t *dev_model, const int8_t *feat, int64_t n_utt, int8_t *logits,
-                             int8_t *softmax, int32_t *argmax, int8_t *acts, int n_cu, hipStream_t stream);
-
-extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const int8_t *feat, int64_t n_utt, int8_t *logits,
-                                  int8_t *softmax, int32_t *argmax, int n_cu, hipStream_t stream);
-
-struct edison_ctx
-{
-	int device;
-	int n_cu;
-	size_t hbm_bytes;
-	char name[128];
-	hipStream_t own_stream;
-	hipStream_t stream;
-	ed_mfcc_tables_t *d_tab[2]; /* variant A, B */
-	int mel_NLO[2], mel_NHI[2];
-	ed_cnn_model_t *d_model;           /* layer-by-layer diagnostic kernel (edison_cnn_layers) */
-	ed_cnn_mfma_model_t *d_model_mfma; /* MFMA fast path                                       */
-	int have_model;
-	/* growable device scratch for the host-pointer entry points and the fused KWS path */
-	void *scratch;
-	size_t scratch_bytes;
-	char err[512];
-};
+#include "edison_ctx.h"
 
 static char g_init_err[512] = "";
 
-#define ED_HIP(ctx, call)                                                                                     \
-	do {                                                                                                      \
-		hipError_t e_ = (call);                                                                               \
-		if (e_ != hipSuccess)                                                                                 \
-		{                                                                                                     \
-			snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
-			         __FILE__, __LINE__);                                                                     \
-			return EDISON_E_RUNTIME;                                                                          \
-		}                                                                                                     \
-	} while (0)
-
-static int set_err(edison_ctx *ctx, int code, const char *msg)
-{
-	if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
-	return code;
-}
+static int set_err(edison_ctx *ctx, int code, const char *msg) { return ed_set_err(ctx, code, msg); }
 
 static int upload_tables(edison_ctx *ctx, double fs, double lo, double hi, double scale)
 {
@@ -285,6 +242,18 @@ static int ensure_scratch(edison_ctx *ctx, size_t bytes)
 /* ---------------------------------------------------------------------------------------- hot path, device */
 static int mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
                        int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
+                       int stages, float *fft, float *spec, float *mel, float *logmel);
+
+int ed_ctx_mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
+                       int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
+                       int stages, float *fft, float *spec, float *mel, float *logmel)
+{
+	return mfcc_launch(ctx, audio, n_frames, fpg, group_stride, frame_step, variant, n_coef, mfcc, feat, feat_scale,
+	                   stages, fft, spec, mel, logmel);
+}
+
+static int mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
+                       int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
                        int stages, float *fft, float *spec, float *mel, float *logmel)
 {
 	const int v = variant & 0xff;
@@ -333,7 +302,7 @@ static int cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t
 	if (n_utt == 0) return EDISON_OK;
 	/* per-layer activations come from the layer-by-layer kernel; everything else runs on the matrix cores */
 	int e = acts ? ed_launch_cnn(ctx->d_model, feat, n_utt, logits, softmax, argmax, acts, ctx->n_cu, ctx->stream)
-	             : ed_launch_cnn_mfma(ctx->d_model_mfma, feat, n_utt, logits, softmax, argmax, ctx->n_cu, ctx->stream);
+	             : ed_launch_cnn_mfma(ctx->d_model_mfma, feat, n_utt, EDISON_NET_IN, logits, softmax, argmax, ctx->n_cu, ctx->stream);
 	if (e != 0)
 	{
 		snprintf(ctx->err, sizeof(ctx->err), "CNN kernel launch failed: %s", hipGetErrorString((hipError_t)e));

@@ -1,0 +1,195 @@
+/*
+ * edison_stream.hip -- continuous-microphone mode on the GPU: the counterpart of the firmware's
+ * appMicMfccInfereContinuous (firmware/src/app.c:288-371) and appAudioEvent (app.c:635-663):
+ *
+ *     per new 1024-sample frame:  audioCalcMFCCs -> mfccToNetInputPush (drop the oldest of 31 rows, append the
+ *                                 newest, app.c:706-719) -> aiRunInference on the 31 x 13 window
+ *
+ * Here a push delivers `chunk` hops of new samples at once (chunk = 1 for lowest latency, thousands for
+ * throughput). Frames may overlap (hop 512 = the 50 % overlap of BASELINE config 5; hop 1024 = the shipped
+ * firmware cadence, audio/config.py:27). Device-resident state: the last 1024 - hop samples and the last 30
+ * feature rows. The sliding window is never copied per frame: window i of a push is rows i..i+30 of one
+ * [30 + chunk][13] int8 buffer, which the CNN kernel reads with a 13-byte "utterance" stride.
+ *
+ * The three device operations of a push (MFCC kernel, CNN kernel, history shift) are captured ONCE into a hipGraph
+ * and replayed per push. The net input starts as zeros like the firmware's static netInput buffer.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "edison_ctx.h"
+
+struct edison_stream
+{
+	edison_ctx *ctx;
+	int hop, chunk, tail; /* tail = 1024 - hop samples of history */
+	int16_t *d_audio;     /* [tail + chunk*hop]                      */
+	int8_t *d_feat;       /* [(30 + chunk) * 13]                     */
+	int8_t *d_soft;       /* [chunk * 10]                            */
+	int8_t *d_logits;     /* [chunk * 10]                            */
+	int32_t *d_argmax;    /* [chunk]                                 */
+	hipStream_t own;      /* the graph always runs on this private stream (the default stream cannot be captured);  */
+	hipEvent_t ev_in, ev_out; /* ordered against the context's current stream with events                      */
+	hipGraph_t graph;
+	hipGraphExec_t exec;
+	int64_t frames_seen;
+};
+
+__global__ void ed_stream_shift_kernel(int16_t *audio, int tail, int new_samples, int8_t *feat, int chunk)
+{
+	/* keep the newest `tail` samples and the newest 30 feature rows at the front of their buffers. One workgroup:
+	 * read everything into registers first, then barrier, then write (source and destination may overlap). */
+	const int t = threadIdx.x;
+	int16_t a[4];
+	int8_t f[2];
+	for (int i = 0; i < 4; i++) { const int j = t + i * 256; a[i] = j < tail ? audio[new_samples + j] : (int16_t)0; }
+	for (int i = 0; i < 2; i++) { const int j = t + i * 256; f[i] = j < 30 * EDISON_NUM_MFCC ? feat[chunk * EDISON_NUM_MFCC + j] : (int8_t)0; }
+	__syncthreads();
+	for (int i = 0; i < 4; i++) { const int j = t + i * 256; if (j < tail) audio[j] = a[i]; }
+	for (int i = 0; i < 2; i++) { const int j = t + i * 256; if (j < 30 * EDISON_NUM_MFCC) feat[j] = f[i]; }
+}
+
+static int enqueue_push_on_ctx_stream(edison_stream *s);
+
+/* enqueue the three device operations of a push on the stream's private hipStream */
+static int enqueue_push(edison_stream *s)
+{
+	hipStream_t saved = s->ctx->stream;
+	s->ctx->stream = s->own;
+	int r = enqueue_push_on_ctx_stream(s);
+	s->ctx->stream = saved;
+	return r;
+}
+
+static int enqueue_push_on_ctx_stream(edison_stream *s)
+{
+	edison_ctx *ctx = s->ctx;
+	/* variant B, 13 coefficients, int8 net input (scale 1): rows 30.. of the feature buffer */
+	int r = ed_ctx_mfcc_launch(ctx, s->d_audio, s->chunk, s->chunk, 0, s->hop, EDISON_MFCC_B, EDISON_NUM_MFCC, NULL,
+	                           s->d_feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
+	if (r != EDISON_OK) return r;
+	int e = ed_launch_cnn_mfma(ctx->d_model_mfma, s->d_feat, s->chunk, EDISON_NUM_MFCC, s->d_logits, s->d_soft, s->d_argmax,
+	                           ctx->n_cu, ctx->stream);
+	if (e != 0) return ed_set_err(ctx, EDISON_E_RUNTIME, "stream: CNN launch failed");
+	hipLaunchKernelGGL(ed_stream_shift_kernel, dim3(1), dim3(256), 0, ctx->stream, s->d_audio, s->tail, s->chunk * s->hop,
+	                   s->d_feat, s->chunk);
+	return hipGetLastError() == hipSuccess ? EDISON_OK : ed_set_err(ctx, EDISON_E_RUNTIME, "stream: shift launch failed");
+}
+
+extern "C" void edison_stream_destroy(edison_stream *s)
+{
+	if (!s) return;
+	if (s->own) (void)hipStreamSynchronize(s->own);
+	if (s->exec) (void)hipGraphExecDestroy(s->exec);
+	if (s->graph) (void)hipGraphDestroy(s->graph);
+	if (s->d_audio) (void)hipFree(s->d_audio);
+	if (s->d_feat) (void)hipFree(s->d_feat);
+	if (s->d_soft) (void)hipFree(s->d_soft);
+	if (s->d_logits) (void)hipFree(s->d_logits);
+	if (s->d_argmax) (void)hipFree(s->d_argmax);
+	if (s->ev_in) (void)hipEventDestroy(s->ev_in);
+	if (s->ev_out) (void)hipEventDestroy(s->ev_out);
+	if (s->own) (void)hipStreamDestroy(s->own);
+	free(s);
+}
+
+extern "C" int edison_stream_reset(edison_stream *s)
+{
+	if (!s) return EDISON_E_ARGUMENT;
+	edison_ctx *ctx = s->ctx;
+	ED_HIP(ctx, hipMemsetAsync(s->d_audio, 0, sizeof(int16_t) * (size_t)(s->tail + s->chunk * s->hop), s->own));
+	ED_HIP(ctx, hipMemsetAsync(s->d_feat, 0, (size_t)(30 + s->chunk) * EDISON_NUM_MFCC, s->own));
+	ED_HIP(ctx, hipStreamSynchronize(s->own));
+	s->frames_seen = 0;
+	return EDISON_OK;
+}
+
+extern "C" int edison_stream_create(edison_ctx *ctx, int hop, int chunk_frames, edison_stream **out)
+{
+	if (!ctx || !out) return EDISON_E_ARGUMENT;
+	*out = NULL;
+	if (!ctx->have_model) return ed_set_err(ctx, EDISON_E_NO_MODEL, "no CNN model loaded (edison_model_load)");
+	if (hop < 2 || hop > EDISON_FRAME_LEN || (hop & 1) || chunk_frames < 1 || chunk_frames > (1 << 22))
+		return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: hop must be even and 2..1024, chunk 1..4M frames");
+	edison_stream *s = (edison_stream *)calloc(1, sizeof(edison_stream));
+	if (!s) return ed_set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed");
+	s->ctx = ctx; s->hop = hop; s->chunk = chunk_frames; s->tail = EDISON_FRAME_LEN - hop;
+	hipError_t e = hipSetDevice(ctx->device);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipMalloc((void **)&s->d_audio, sizeof(int16_t) * (size_t)(s->tail + s->chunk * s->hop) + 16);
+	if (e == hipSuccess) e = hipMalloc((void **)&s->d_feat, (size_t)(30 + s->chunk) * EDISON_NUM_MFCC + 16);
+	if (e == hipSuccess) e = hipMalloc((void **)&s->d_soft, (size_t)s->chunk * EDISON_NET_OUT + 16);
+	if (e == hipSuccess) e = hipMalloc((void **)&s->d_logits, (size_t)s->chunk * EDISON_NET_OUT + 16);
+	if (e == hipSuccess) e = hipMalloc((void **)&s->d_argmax, sizeof(int32_t) * (size_t)s->chunk);
+	if (e != hipSuccess)
+	{
+		edison_stream_destroy(s);
+		return ed_set_err(ctx, e == hipErrorOutOfMemory ? EDISON_E_NO_MEMORY : EDISON_E_RUNTIME, "stream: device allocation failed");
+	}
+	int r = edison_stream_reset(s);
+	/* one eager push on silence: sizes the persistent grids / sets kernel attributes outside of graph capture */
+	if (r == EDISON_OK) r = enqueue_push(s);
+	if (r == EDISON_OK && hipStreamSynchronize(s->own) != hipSuccess) r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: warm-up failed");
+	if (r == EDISON_OK) r = edison_stream_reset(s);
+	if (r == EDISON_OK)
+	{
+		/* capture one push into a graph; every later push is a single hipGraphLaunch */
+		e = hipStreamBeginCapture(s->own, hipStreamCaptureModeThreadLocal);
+		if (e == hipSuccess)
+		{
+			r = enqueue_push(s);
+			hipError_t e2 = hipStreamEndCapture(s->own, &s->graph);
+			if (r == EDISON_OK && e2 != hipSuccess) r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: graph capture failed");
+			if (r == EDISON_OK && hipGraphInstantiate(&s->exec, s->graph, NULL, NULL, 0) != hipSuccess)
+				r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: graph instantiation failed");
+		}
+		else
+			r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: cannot begin graph capture on this stream");
+	}
+	if (r != EDISON_OK) { edison_stream_destroy(s); return r; }
+	*out = s;
+	return EDISON_OK;
+}
+
+/* samples: chunk*hop NEW int16 samples in device memory. Outputs (device, each may be NULL): softmax / logits
+ * [chunk][10], argmax [chunk]; entry i belongs to the window that ends with the i-th new frame. Asynchronous. */
+extern "C" int edison_stream_push_dev(edison_stream *s, const int16_t *samples, int8_t *logits, int8_t *softmax,
+                                      int32_t *argmax)
+{
+	if (!s || !samples) return EDISON_E_ARGUMENT;
+	edison_ctx *ctx = s->ctx;
+	const size_t nnew = (size_t)s->chunk * s->hop;
+	/* the caller produced `samples` on the context's stream: the private stream waits for that point ... */
+	ED_HIP(ctx, hipEventRecord(s->ev_in, ctx->stream));
+	ED_HIP(ctx, hipStreamWaitEvent(s->own, s->ev_in, 0));
+	ED_HIP(ctx, hipMemcpyAsync(s->d_audio + s->tail, samples, nnew * sizeof(int16_t), hipMemcpyDeviceToDevice, s->own));
+	ED_HIP(ctx, hipGraphLaunch(s->exec, s->own));
+	if (logits) ED_HIP(ctx, hipMemcpyAsync(logits, s->d_logits, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToDevice, s->own));
+	if (softmax) ED_HIP(ctx, hipMemcpyAsync(softmax, s->d_soft, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToDevice, s->own));
+	if (argmax) ED_HIP(ctx, hipMemcpyAsync(argmax, s->d_argmax, (size_t)s->chunk * sizeof(int32_t), hipMemcpyDeviceToDevice, s->own));
+	/* ... and the context's stream continues only after the outputs are written */
+	ED_HIP(ctx, hipEventRecord(s->ev_out, s->own));
+	ED_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_out, 0));
+	s->frames_seen += s->chunk;
+	return EDISON_OK;
+}
+
+/* the same with host pointers; synchronous */
+extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8_t *logits, int8_t *softmax, int32_t *argmax)
+{
+	if (!s || !samples) return EDISON_E_ARGUMENT;
+	edison_ctx *ctx = s->ctx;
+	const size_t nnew = (size_t)s->chunk * s->hop;
+	ED_HIP(ctx, hipMemcpyAsync(s->d_audio + s->tail, samples, nnew * sizeof(int16_t), hipMemcpyHostToDevice, s->own));
+	ED_HIP(ctx, hipGraphLaunch(s->exec, s->own));
+	if (logits) ED_HIP(ctx, hipMemcpyAsync(logits, s->d_logits, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToHost, s->own));
+	if (softmax) ED_HIP(ctx, hipMemcpyAsync(softmax, s->d_soft, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToHost, s->own));
+	if (argmax) ED_HIP(ctx, hipMemcpyAsync(argmax, s->d_argmax, (size_t)s->chunk * sizeof(int32_t), hipMemcpyDeviceToHost, s->own));
+	ED_HIP(ctx, hipStreamSynchronize(s->own));
+	s->frames_seen += s->chunk;
+	return EDISON_OK;
+}
+
+extern "C" int64_t edison_stream_frames_seen(const edison_stream *s) { return s ? s->frames_seen : -1; }

@@ -151,6 +151,23 @@ int edison_cnn_layers(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t
 int edison_kws_batch(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride, int8_t *feat,
                      int8_t *logits, int8_t *softmax, int32_t *argmax);
 
+/* ---- continuous-microphone mode ------------------------------------------------------------------------
+ * The firmware's appMicMfccInfereContinuous / appAudioEvent loop (firmware/src/app.c:288-371, 635-663): every new
+ * frame -> MFCC -> mfccToNetInputPush (31-row sliding window, app.c:706-719) -> inference. A push delivers
+ * chunk_frames hops of `hop` NEW samples (hop 1024 = firmware cadence, 512 = 50 % overlap); the stream keeps the
+ * last 1024-hop samples and the last 30 feature rows on the device and starts from silence / a zero window like
+ * the firmware's static buffers. Output i of a push belongs to the window ending with its i-th new frame.
+ * One push = one hipGraph launch (MFCC kernel, CNN kernel over sliding windows, history shift).            */
+typedef struct edison_stream edison_stream;
+int edison_stream_create(edison_ctx *ctx, int hop, int chunk_frames, edison_stream **out);
+void edison_stream_destroy(edison_stream *s);
+int edison_stream_reset(edison_stream *s);
+int edison_stream_push_dev(edison_stream *s, const int16_t *samples /* device, chunk*hop */, int8_t *logits,
+                           int8_t *softmax, int32_t *argmax /* device, may be NULL */);
+int edison_stream_push(edison_stream *s, const int16_t *samples /* host */, int8_t *logits, int8_t *softmax,
+                       int32_t *argmax);
+int64_t edison_stream_frames_seen(const edison_stream *s);
+
 /* ---- legacy call surface of the reference firmware (batch = 1, process-global context) --------------- */
 /* firmware/src/ai/ai.h:74-80. aiInitialize() creates the global context on device $EDISON_DEVICE (default 0)
  * and loads $EDISON_MODEL (default: kws_nnom.ednn next to the library). in_data: 403 int8, out_data: 10 int8. */

@@ -1,0 +1,67 @@
+"""GPU tests of the continuous-microphone mode (edison_stream_*): a stream fed in chunks must give, for every new
+frame, exactly what the batch path gives on the corresponding 31-frame window (the firmware's sliding window,
+app.c:706-719), and the CNN outputs must be bit-exact against the oracle on the streamed features."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _windows_from_features(rows):
+    """rows: [n_frames, 13] int8 (oldest first). Window i ends with frame i; missing history = zeros."""
+    n = rows.shape[0]
+    padded = np.concatenate([np.zeros((30, 13), np.int8), rows])
+    return np.stack([padded[i:i + 31].reshape(-1) for i in range(n)])
+
+
+@pytest.mark.parametrize("hop,chunk", [(1024, 1), (1024, 7), (512, 5), (512, 64)])
+def test_stream_matches_batch_windows(ctx, oracle_mod, oracle_model, hop, chunk):
+    from edison_amd import _lib
+    from edison_amd.stream import Stream
+    rng = np.random.default_rng(hop + chunk)
+    n_push = 9 if chunk < 32 else 3
+    n_frames = n_push * chunk
+    audio = np.clip(rng.normal(0, 2500, n_frames * hop), -32768, 32767).astype(np.int16)
+    st = Stream(ctx, hop=hop, chunk_frames=chunk)
+    outs = [st.push(audio[i * chunk * hop:(i + 1) * chunk * hop]) for i in range(n_push)]
+    assert st.frames_seen == n_frames
+    soft = np.concatenate([o["softmax"] for o in outs])
+    logits = np.concatenate([o["logits"] for o in outs])
+    am = np.concatenate([o["argmax"] for o in outs])
+    # the stream implicitly starts with 1024-hop samples of silence in front of the first hop
+    full = np.concatenate([np.zeros(1024 - hop, np.int16), audio])
+    _, feat = ctx.mfcc(full, n_frames=n_frames, frame_step=hop, variant=_lib.MFCC_B, n_coef=13, want_feat=True)
+    win = _windows_from_features(feat)
+    ref = ctx.cnn(win)                                  # batch path of the same library on the same windows
+    assert np.array_equal(soft, ref["softmax"]) and np.array_equal(logits, ref["logits"]) and np.array_equal(am, ref["argmax"])
+    o = oracle_mod.cnn(oracle_model, win, n_threads=4)  # and the oracle on those windows
+    assert np.array_equal(soft, o["softmax"]) and np.array_equal(am, o["argmax"])
+    # reset returns to the silent start
+    st.reset()
+    again = st.push(audio[:chunk * hop])
+    assert np.array_equal(again["softmax"], outs[0]["softmax"])
+    st.close()
+
+
+def test_stream_utterance_equals_kws(ctx, kws_golden):
+    """Feeding the 31 frames of the reference wav (hop 1024) ends on the same decision as the batch KWS call."""
+    from edison_amd.stream import Stream
+    a = kws_golden["kws_zero_audio"][:31 * 1024]
+    st = Stream(ctx, hop=1024, chunk_frames=31)
+    o = st.push(a)
+    assert np.array_equal(o["logits"][-1], kws_golden["kws_zero_logits"])
+    assert np.array_equal(o["softmax"][-1], kws_golden["kws_zero_softmax"]) and o["keywords"][-1] == "edison"
+    st.close()
+
+
+def test_stream_argument_checks(ctx):
+    from edison_amd import _lib
+    from edison_amd.stream import Stream
+    with pytest.raises(_lib.EdisonError):
+        Stream(ctx, hop=333, chunk_frames=1)      # odd hop: frames would not be 4-byte aligned
+    with pytest.raises(_lib.EdisonError):
+        Stream(ctx, hop=2048, chunk_frames=1)
+    st = Stream(ctx, hop=512, chunk_frames=2)
+    with pytest.raises(ValueError):
+        st.push(np.zeros(1000, np.int16))
+    st.close()
