@@ -114,6 +114,51 @@ def timed_region(step_fn, steps, warmup, world):
     return wall, ev
 
 
+def stream_bench(ctx, dev):
+    """BASELINE configs[4]: 1 h of synthetic 16 kHz audio (57.6 M samples), 1024-sample frames at hop 512
+    (50 % overlap) -> 112 499 frames, an inference on the newest 31 frames after every frame.
+    (a) latency: one frame per push (one hipGraph launch each), host-timed push -> result on the host;
+    (b) throughput: the whole hour in pushes of 4096 frames."""
+    from edison_amd.stream import Stream
+    hop, total = 512, 57600000
+    n_frames = (total - 1024) // hop + 1                      # 112 499
+    g = torch.Generator(device=dev)
+    g.manual_seed(23)
+    audio = (torch.randn((total,), generator=g, device=dev) * 3000.0).clamp_(-32768, 32767).to(torch.int16)
+    # (a) latency, chunk = 1, host pointers (includes the 1 KB upload and 24 B download of a real microphone loop)
+    st = Stream(ctx, hop=hop, chunk_frames=1)
+    host = audio[:2100 * hop].cpu().numpy()
+    lat = []
+    for i in range(2100):
+        t0 = time.perf_counter()
+        st.push(host[i * hop:(i + 1) * hop])
+        lat.append(time.perf_counter() - t0)
+    st.close()
+    lat = np.array(lat[100:]) * 1e6
+    # (b) throughput, chunk = 4096 frames, device pointers
+    chunk = 4096
+    st = Stream(ctx, hop=hop, chunk_frames=chunk)
+    am = torch.empty((chunk,), dtype=torch.int32, device=dev)
+    n_push = (n_frames - 1) // chunk                          # whole chunks only; the remainder is < 4 % of the hour
+    body = audio[1024 - hop:]                                 # the stream starts from 1024-hop samples of silence
+    st.push_t(body[:chunk * hop], argmax=am)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_push):
+        st.push_t(body[i * chunk * hop:(i + 1) * chunk * hop], argmax=am)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st.close()
+    del audio
+    return dict(workload="1 h stream, 16 kHz, frame 1024, hop 512, window 31 frames, inference per frame",
+                latency_us=dict(p50=round(float(np.percentile(lat, 50)), 1), p90=round(float(np.percentile(lat, 90)), 1),
+                                p99=round(float(np.percentile(lat, 99)), 1), pushes=int(lat.size),
+                                what="host push of 512 new samples -> softmax/argmax on the host, one hipGraph launch"),
+                throughput=dict(frames_per_s=round(n_push * chunk / dt, 1), inferences_per_s=round(n_push * chunk / dt, 1),
+                                frames=n_push * chunk, chunk_frames=chunk, seconds=round(dt, 4),
+                                realtime_factor=round(n_push * chunk * hop / 16000.0 / dt, 1)))
+
+
 def cpu_baseline(n_threads):
     """The oracle's C restatement (checker code, timed here only as the reported CPU baseline)."""
     from oracle import oracle
@@ -121,18 +166,18 @@ def cpu_baseline(n_threads):
     rng = np.random.default_rng(20)
     res = {}
     # MFCC variant B, float64 like the reference's numpy path; sample sized for ~10 s
-    n = 4096
+    n = 65536
     x = np.clip(rng.normal(0, 3000, n * 1024), -32768, 32767).astype(np.int16)
-    t0 = time.perf_counter(); oracle.mfcc(x, oracle.VARIANT_B, n_threads=n_threads); dt = time.perf_counter() - t0
-    reps = max(1, min(64, int(8.0 / max(dt, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    oracle.mfcc(x[:4096 * 1024], oracle.VARIANT_B, n_threads=n_threads)     # warm-up (thread pool, page faults)
+    reps, t0 = 0, time.perf_counter()
+    while reps < 1 or (time.perf_counter() - t0 < 8.0 and reps < 200):      # ~8-10 s of CPU work
         oracle.mfcc(x, oracle.VARIANT_B, n_threads=n_threads)
+        reps += 1
     dt = (time.perf_counter() - t0) / reps
     res["mfcc"] = dict(value=n / dt, unit="frames/s", cores=n_threads, kind="port",
                        sample="%d frames x %d passes, oracle/mfcc_ref.c variant B float64, %d OpenMP threads" % (n, reps, n_threads))
     # full KWS: MFCC B + int8 CNN restatement, all threads
-    nu = 256
+    nu = 2048
     a = np.clip(rng.normal(0, 3000, nu * 31744), -32768, 32767).astype(np.int16)
     model = oracle.Model()
 
@@ -140,11 +185,11 @@ def cpu_baseline(n_threads):
         m = oracle.mfcc(a, oracle.VARIANT_B, n_threads=n_threads)[:, :13]
         f = oracle.net_input(m).reshape(nu, 403)
         return oracle.cnn(model, f, n_threads=n_threads)
-    t0 = time.perf_counter(); kws_once(); dt = time.perf_counter() - t0
-    reps = max(1, min(32, int(8.0 / max(dt, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    kws_once()
+    reps, t0 = 0, time.perf_counter()
+    while reps < 1 or (time.perf_counter() - t0 < 8.0 and reps < 200):
         kws_once()
+        reps += 1
     dt = (time.perf_counter() - t0) / reps
     res["kws"] = dict(value=nu / dt, unit="inferences/s", cores=n_threads, kind="port",
                       sample="%d utterances x %d passes, oracle MFCC B + int8 CNN restatement, %d OpenMP threads" % (nu, reps, n_threads))
@@ -166,6 +211,7 @@ def main():
     ap.add_argument("--rotate", type=int, default=3, help="distinct MFCC input batches cycled through (defeats the 256 MiB L3)")
     ap.add_argument("--skip-kws", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-stream", action="store_true")
     args = ap.parse_args()
 
     from edison_amd import parallel, _lib
@@ -235,6 +281,11 @@ def main():
                    class_histogram=hist)
         del audio
 
+    # ------------------------------------------------------------------ streaming (configs[4]): rank 0, N = 1 only
+    streaming = None
+    if rank == 0 and world == 1 and not args.skip_stream:
+        streaming = stream_bench(ctx, dev)
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.skip_cpu:
@@ -254,6 +305,8 @@ def main():
                     roofline=roofline, device=info["name"], checksum=checksum)
         if kws is not None:
             line["kws"] = kws
+        if streaming is not None:
+            line["streaming"] = streaming
         if cpu is not None:
             if "mfcc" in cpu:
                 line["cpu_baseline"] = cpu["mfcc"]
