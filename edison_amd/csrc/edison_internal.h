@@ -33,7 +33,7 @@ typedef struct {
 	 * y[c] = sum_{n<16} D[n][c] * (L[n] + (-1)^c L[31-n]); lane (c = lane&31, h = lane>>5) sums n = 8h..8h+7,
 	 * dct4[n4][lane][j] = scale * 2*cos(pi*c*(2*(8h+4*n4+j)+1)/64)                                           */
 	float dct4[2][64][4];
-	float twp[4][64][2]; /* [m][lane]   W1024^(lane+64m): real-FFT split twiddles                            */
+	float twp[4][64][2]; /* [m][lane]   W1024^(k0+64m), k0 = (lane>>3) + 8*(lane&7): real-FFT split twiddles    */
 	float mel_w4[ED_MEL_TQ_MAX][64][4];
 	/* ---- end of the LDS image ---- */
 	int32_t mel_NLO, mel_NHI;

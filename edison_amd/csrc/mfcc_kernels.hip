@@ -9,13 +9,18 @@
  * Pipeline per wavefront (lane = 0..63):
  *   1. load      z[n] = x[2n] + i*x[2n+1], n = lane + 64a (a = 0..7): 8 coalesced 256-B wave loads, issued one
  *                frame ahead (software prefetch) so HBM latency hides under the previous frame's arithmetic
- *   2. FFT512    3 radix-8 passes over the digits of n = 64a + 8b + c, k = p + 8q + 64r; the two digit
- *                transposes go through a wave-private, padded LDS buffer (conflict-free ds_*_b64)
- *   3. split     X[k] = E[k] + W1024^k O[k] from Z[k], conj Z[512-k]; lane handles the pair (k, 512-k)
+ *   2. FFT512    3 radix-8 passes over the digits of n = 64a + 8b + c, k = p + 8q + 64r, ENTIRELY IN REGISTERS:
+ *                the two digit transposes (register index <-> three lane-index bits) are butterfly exchanges on
+ *                the VALU -- v_permlane32_swap / v_permlane16_swap for lane bits 5 / 4, DPP row_shr/row_shl with
+ *                bank masks for bits 3 / 2, DPP quad_perm + select for bits 1 / 0. The LDS pipe, which a
+ *                write-then-read transpose saturates first on this chip, carries none of the FFT.
+ *   3. split     X[k] = E[k] + W1024^k O[k] from Z[k], conj Z[512-k]; lane handles the pair (k, 512-k); the
+ *                partner value comes through ds_bpermute (LDS crossbar, no LDS memory)
  *   4. |X|       -> wave-private LDS spectrum S[0..512] (+3 pad)
- *   5. mel       32 banded dot products: lane (band j = lane&31, half h = lane>>5) reads its taps as 16-byte
- *                quads (ds_read_b128 for spectrum and weights), halves combined with one cross-lane shuffle
- *   6. ln / DCT  optional ln(x+1e-6); DCT-II against a per-lane LDS table, halves combined by shuffle
+ *   5. mel       32 banded dot products, balanced: lane (b = lane&15, r = lane>>4) sums quarter r of the narrow
+ *                band b and of the wide band 31-b as 16-byte quads (ds_read_b128 spectrum + weights); quarters are
+ *                summed over the lane rows with VALU row swaps
+ *   6. ln / DCT  optional ln(x+1e-6); DCT-II through cos symmetry against a per-lane LDS table
  *   7. store     n_coef fp32 and/or int8 (clip, round-half-even) per frame
  *
  * Waves never share LDS data, so there is no workgroup barrier inside the frame loop. The constant tables
@@ -31,8 +36,13 @@
 #ifndef ED_WPB
 #define ED_WPB 8                 /* waves (= frames in flight) per workgroup                               */
 #endif
-#define ED_XBUF_FLOATS 1160      /* per-wave LDS: 576 complex exchange slots (also Pz + S + L) + pad        */
+#define ED_XBUF_FLOATS 576       /* per-wave LDS: spectrum S[516] | DCT input u[16], v[16] | pad            */
 #define ED_FIXTAB_FLOATS (2 * 64 * 4 + 4 * 64 * 2) /* dct | split twiddles, then (NLO+NHI) x 64 weight quads */
+
+#ifndef ED_TW_LDS
+#define ED_TW_LDS 0              /* 1: pass-1/2 twiddles read from LDS instead of living in 28 registers      */
+#endif
+#define ED_TWTAB_FLOATS (ED_TW_LDS ? 2048 : 0)
 
 #ifdef ED_MIN_WAVES
 #define ED_MFCC_BOUNDS __launch_bounds__(64 * ED_WPB, ED_MIN_WAVES)
@@ -62,6 +72,64 @@ __device__ __forceinline__ float ed_sum_rows(float x)
 {
 	const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
 	return ed_sum_halves(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+}
+
+/*
+ * One butterfly stage of an in-register transpose: for the register pair (A: register-index bit 0, B: bit 1) and lane
+ * bit LB, exchange A at lanes whose bit LB is 1 with B at the partner lanes (lane ^ (1 << LB)) whose bit LB is 0.
+ * Three such stages (three register-index bits against three lane bits) swap a 3-bit register index with a 3-bit
+ * lane-index field: element (lane field = u, register = v) moves to (lane field = v, register = u).
+ */
+template <int LB>
+__device__ __forceinline__ void ed_xchg(float &A, float &B, int lane)
+{
+	const unsigned a = __float_as_uint(A), b = __float_as_uint(B);
+	if (LB == 5)
+	{
+		const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); /* A.upper half <-> B.lower half */
+		A = __uint_as_float(r[0]); B = __uint_as_float(r[1]);
+	}
+	else if (LB == 4)
+	{
+		const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); /* A.odd rows <-> B.even rows */
+		A = __uint_as_float(r[0]); B = __uint_as_float(r[1]);
+	}
+	else if (LB == 3)
+	{
+		/* row_shr:8 -> lanes 8..15 of a row (banks 2,3) read lane-8; row_shl:8 -> lanes 0..7 (banks 0,1) read lane+8 */
+		const unsigned na = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x118, 0xf, 0xc, false);
+		const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x108, 0xf, 0x3, false);
+		A = __uint_as_float(na); B = __uint_as_float(nb);
+	}
+	else if (LB == 2)
+	{
+		/* row_shr:4 into banks 1,3 (lane bit 2 set); row_shl:4 into banks 0,2 */
+		const unsigned na = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x114, 0xf, 0xa, false);
+		const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x104, 0xf, 0x5, false);
+		A = __uint_as_float(na); B = __uint_as_float(nb);
+	}
+	else
+	{
+		/* inside a quad no mask applies: pull the partner lane with quad_perm, select on the lane bit */
+		constexpr int ctrl = (LB == 1) ? 0x4E /* [2,3,0,1] */ : 0xB1 /* [1,0,3,2] */;
+		const unsigned pb = (unsigned)__builtin_amdgcn_mov_dpp((int)b, ctrl, 0xf, 0xf, false);
+		const unsigned pa = (unsigned)__builtin_amdgcn_mov_dpp((int)a, ctrl, 0xf, 0xf, false);
+		const bool up = (lane >> LB) & 1;
+		A = __uint_as_float(up ? pb : a);
+		B = __uint_as_float(up ? b : pa);
+	}
+}
+
+/* swap the 3-bit register index of x[0..7] with lane bits LB0 (register bit 0), LB1 (bit 1), LB2 (bit 2) */
+template <int LB0, int LB1, int LB2>
+__device__ __forceinline__ void ed_transpose8(float (&x)[8], int lane)
+{
+#pragma unroll
+	for (int i = 0; i < 8; i += 2) ed_xchg<LB0>(x[i], x[i + 1], lane);
+#pragma unroll
+	for (int i = 0; i < 8; i++) if (!(i & 2)) ed_xchg<LB1>(x[i], x[i + 2], lane);
+#pragma unroll
+	for (int i = 0; i < 4; i++) ed_xchg<LB2>(x[i], x[i + 4], lane);
 }
 
 __device__ __forceinline__ void ed_dft4(float y0r, float y0i, float y1r, float y1i, float y2r, float y2i, float y3r,
@@ -134,10 +202,9 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const float4 *dctl = reinterpret_cast<const float4 *>(smem);                 /* [2][64] x 4 coefficients */
-	const float2 *tpl = reinterpret_cast<const float2 *>(smem + 512);            /* [4][64] W1024^(lane+64m) */
+	const float2 *tpl = reinterpret_cast<const float2 *>(smem + 512);            /* [4][64] split twiddles   */
 	const float4 *melw4 = reinterpret_cast<const float4 *>(smem + ED_FIXTAB_FLOATS); /* [NLO+NHI][64] quads   */
-	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + wave * ED_XBUF_FLOATS; /* wave-private      */
-	float2 *xc = reinterpret_cast<float2 *>(xbuf);
+	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED_TWTAB_FLOATS + wave * ED_XBUF_FLOATS; /* wave-private */
 
 	/* the first frame's samples go in flight before anything else: their HBM latency hides under the table staging */
 	const uint32_t n_frames = (uint32_t)args.n_frames;
@@ -152,6 +219,16 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		for (int t = threadIdx.x; t < (ED_FIXTAB_FLOATS + (NLO + NHI) * 256) / 4; t += blockDim.x) dst[t] = src[t];
 	}
 
+#if ED_TW_LDS
+	/* pass-1/2 twiddles: per-lane LDS tables [p][lane] (conflict-free ds_read_b64), 28 registers saved */
+	const float2 *tw1l = reinterpret_cast<const float2 *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256) + lane;
+	const float2 *tw2l = tw1l + 512;
+	{
+		const float4 *src = reinterpret_cast<const float4 *>(&tab->tw1[0][0][0]); /* tw1 | tw2 are adjacent */
+		float4 *dst = reinterpret_cast<float4 *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256);
+		for (int t = threadIdx.x; t < 2048 / 4; t += blockDim.x) dst[t] = src[t];
+	}
+#else
 	/* pass-1/2 twiddles: resident in registers for the whole persistent loop */
 	float t1r[8], t1i[8], t2r[8], t2i[8];
 #pragma unroll
@@ -161,17 +238,17 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		const float2 b = *reinterpret_cast<const float2 *>(&tab->tw2[p][lane][0]);
 		t1r[p] = a.x; t1i[p] = a.y; t2r[p] = b.x; t2i[p] = b.y;
 	}
-	__syncthreads();
-#ifdef ED_STAGGER
-	/* Waves that share a SIMD (w, w+4 of a workgroup; the workgroups of a CU) run the same program; start
-	 * them a fraction of a frame apart so that one wave's LDS-heavy transposes overlap another's arithmetic. */
-	for (int s = ((wave >> 2) * 2 + (blockIdx.x & 1)); s > 0; s--) __builtin_amdgcn_s_sleep(ED_STAGGER);
 #endif
+	__syncthreads();
 	const int mel_slo4 = tab->mel_slo4[lane], mel_shi4 = tab->mel_shi4[lane];
 	const float spec_scale = tab->spec_scale;
 	const float log_offset = tab->log_offset;
 	const bool do_log = tab->always_log || args.use_log;
-	const int hi3 = lane >> 3, lo3 = lane & 7;
+	/* after the two transposes lane (p = lane>>3, q = lane&7) holds Z[k0 + 64r] in register r, k0 = p + 8q */
+	const int k0 = (lane >> 3) + 8 * (lane & 7);
+	const int k0p = (64 - k0) & 63;                          /* low 6 bits of the partner index 512 - k    */
+	const int pull = (((k0p & 7) << 3) | (k0p >> 3)) << 2;   /* byte address of the lane that holds it     */
+	if (lane < 3) xbuf[513 + lane] = 0.0f;                   /* spectrum padding: read by the last quad only */
 
 	for (; f < n_frames; f += stride)
 	{
@@ -185,57 +262,52 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		}
 		if (f + stride < n_frames) ed_load_frame<ALIGNED>(ed_frame_ptr(args, f + stride), lane, raw);
 
-		/* ---- 2a. pass 1: DFT over a, twiddle W512^(lane*p) */
+		/* ---- 2a. pass 1: DFT over a (registers), twiddle W512^(lane*p); lane = 8b + c */
 		ed_radix8(re, im);
 #pragma unroll
 		for (int p = 1; p < 8; p++)
 		{
+#if ED_TW_LDS
+			const float2 w = tw1l[64 * p];
+			const float wr = w.x, wi = w.y;
+#else
+			const float wr = t1r[p], wi = t1i[p];
+#endif
 			float xr = re[p], xi = im[p];
-			re[p] = xr * t1r[p] - xi * t1i[p];
-			im[p] = xr * t1i[p] + xi * t1r[p];
+			re[p] = xr * wr - xi * wi;
+			im[p] = xr * wi + xi * wr;
 		}
-		/* transpose 1: (lane = 8b+c, reg p) -> (lane = 8p+c, reg b); slot = 72p + 8b + c */
-#pragma unroll
-		for (int p = 0; p < 8; p++) xc[72 * p + lane] = make_float2(re[p], im[p]);
-		ed_wave_sync();
-#pragma unroll
-		for (int b = 0; b < 8; b++)
-		{
-			float2 v = xc[72 * hi3 + 8 * b + lo3];
-			re[b] = v.x; im[b] = v.y;
-		}
-		ed_wave_sync();
+		/* transpose 1: register p <-> lane bits 3..5 (b): (lane 8b+c, reg p) -> (lane 8p+c, reg b) */
+		ed_transpose8<3, 4, 5>(re, lane);
+		ed_transpose8<3, 4, 5>(im, lane);
 
-		/* ---- 2b. pass 2: DFT over b, twiddle W64^(c*q) */
+		/* ---- 2b. pass 2: DFT over b, twiddle W64^(c*q); lane = 8p + c */
 		ed_radix8(re, im);
 #pragma unroll
 		for (int q = 1; q < 8; q++)
 		{
+#if ED_TW_LDS
+			const float2 w = tw2l[64 * q];
+			const float wr = w.x, wi = w.y;
+#else
+			const float wr = t2r[q], wi = t2i[q];
+#endif
 			float xr = re[q], xi = im[q];
-			re[q] = xr * t2r[q] - xi * t2i[q];
-			im[q] = xr * t2i[q] + xi * t2r[q];
+			re[q] = xr * wr - xi * wi;
+			im[q] = xr * wi + xi * wr;
 		}
-		/* transpose 2: (lane = 8p+c, reg q) -> (lane = p+8q, reg c); slot = 66c + p + 8q */
-#pragma unroll
-		for (int q = 0; q < 8; q++) xc[66 * lo3 + hi3 + 8 * q] = make_float2(re[q], im[q]);
-		ed_wave_sync();
-#pragma unroll
-		for (int c = 0; c < 8; c++)
-		{
-			float2 v = xc[66 * c + lane];
-			re[c] = v.x; im[c] = v.y;
-		}
-		ed_wave_sync();
+		/* transpose 2: register q <-> lane bits 0..2 (c): (lane 8p+c, reg q) -> (lane 8p+q, reg c) */
+		ed_transpose8<0, 1, 2>(re, lane);
+		ed_transpose8<0, 1, 2>(im, lane);
 
-		/* ---- 2c. pass 3: DFT over c  ->  reg r holds Z[lane + 64r] */
+		/* ---- 2c. pass 3: DFT over c  ->  reg r holds Z[k0 + 64r], k0 = p + 8q */
 		ed_radix8(re, im);
 
-		/* ---- 3. real-FFT split. The partner Z[512-k] of k = lane + 64m (m < 4) is register 7-m of lane
-		 *         (64 - lane) % 64: pulled through the LDS crossbar (ds_bpermute, no LDS memory, one trip).
-		 *         Lane 0 is its own partner, one register further up: Z[512 - 64m] = its register 8-m (Z[512] = Z[0]). */
+		/* ---- 3. real-FFT split. The partner Z[512-k] of k = k0 + 64m (m < 4) is register 7-m of the lane whose
+		 *         k0 is (64 - k0) % 64: pulled through the LDS crossbar (ds_bpermute, no LDS memory, one trip).
+		 *         Lane 0 (k0 = 0) is its own partner, one register further up: Z[512 - 64m] = its register 8-m. */
 		float slo[4], shi[4];
 		float flr[4], fli[4], fhr[4], fhi[4]; /* X[k], X[512-k] for the stage dump */
-		const int pull = ((64 - lane) & 63) << 2;
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 		{
@@ -243,7 +315,7 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 			pz.x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m])));
 			pz.y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m])));
 			if (lane == 0) pz = make_float2(re[(8 - m) & 7], im[(8 - m) & 7]);
-			const float2 tw = tpl[64 * m + lane];
+			const float2 tw = tpl[64 * m + lane];       /* W1024^(k0 + 64m)                                  */
 			float ar = re[m] + pz.x, ai = im[m] - pz.y; /* A  = Z[k] + conj Z[512-k]          = 2 E[k]      */
 			float br = re[m] - pz.x, bi = im[m] + pz.y; /* B  = Z[k] - conj Z[512-k]; O2 = -i*B = 2 O[k]    */
 			float tr = tw.x * bi + tw.y * br;           /* T  = W1024^k * (bi - i*br)                        */
@@ -257,14 +329,13 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		/* k = 256 pairs with itself: X[256] = conj(Z[256]) (lane 0, reg 4) */
 		const float s256 = 2.0f * __builtin_amdgcn_sqrtf(re[4] * re[4] + im[4] * im[4]) * spec_scale;
 
-		/* ---- 4. spectrum to LDS (floats 576..1091 of the wave buffer: disjoint from Pz; S[513..515] hold
-		 *         finite leftovers of the transposes and only ever meet zero weights) */
-		float *S = xbuf + 576;
+		/* ---- 4. spectrum to LDS; S[513..515] were zeroed before the loop and only ever meet zero weights */
+		float *S = xbuf;
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 		{
-			S[lane + 64 * m] = slo[m];
-			S[512 - lane - 64 * m] = shi[m];
+			S[k0 + 64 * m] = slo[m];
+			S[512 - k0 - 64 * m] = shi[m];
 		}
 		if (lane == 0) S[256] = s256;
 		if (STAGES)
@@ -275,8 +346,8 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 #pragma unroll
 				for (int m = 0; m < 4; m++)
 				{
-					F[lane + 64 * m] = make_float2(flr[m], fli[m]);
-					F[512 - lane - 64 * m] = make_float2(fhr[m], fhi[m]);
+					F[k0 + 64 * m] = make_float2(flr[m], fli[m]);
+					F[512 - k0 - 64 * m] = make_float2(fhr[m], fhi[m]);
 				}
 				if (lane == 0) F[256] = make_float2(re[4], -im[4]);
 			}
@@ -320,7 +391,7 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 
 		/* ---- 6. DCT-II through cos symmetry: y[c] = sum_{n<16} D[n][c] * (L[n] + (-1)^c L[31-n]);
 		 *         lane (c = lane&31, h = lane>>5) sums n = 8h..8h+7 */
-		float *Lb = xbuf + 1104; /* u[16] | v[16], 16-B aligned */
+		float *Lb = xbuf + 528; /* u[16] | v[16], 16-B aligned, behind the spectrum */
 		if (lane < 16) { Lb[lane] = llo + lhi; Lb[16 + lane] = llo - lhi; }
 		ed_wave_sync();
 		const float4 *L4 = reinterpret_cast<const float4 *>(Lb + 16 * (lane & 1) + 8 * (lane >> 5));
@@ -352,7 +423,7 @@ template <int NLO, int NHI>
 static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
                                 hipStream_t stream, int *blocks_per_cu)
 {
-	const size_t lds = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED_WPB * ED_XBUF_FLOATS);
+	const size_t lds = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED_TWTAB_FLOATS + ED_WPB * ED_XBUF_FLOATS);
 	if (*blocks_per_cu < 0)
 	{
 		/* persistent grid = exactly what is resident; sized once from the fast kernel's occupancy */

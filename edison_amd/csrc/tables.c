@@ -77,7 +77,9 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 	for (int m = 0; m < 4; m++)
 		for (int l = 0; l < 64; l++)
 		{
-			double a = -2.0 * M_PI * (double)(l + 64 * m) / 1024.0;
+			/* after the two in-register transposes lane (p = l>>3, q = l&7) holds Z[k0 + 64r], k0 = p + 8q */
+			const int k0 = (l >> 3) + 8 * (l & 7);
+			double a = -2.0 * M_PI * (double)(k0 + 64 * m) / 1024.0;
 			out->twp[m][l][0] = (float)cos(a); out->twp[m][l][1] = (float)sin(a);
 		}
 
