@@ -51,7 +51,9 @@ def build(force=False, verbose=False):
         objs.append(obj)
     for src in HIP_SOURCES:
         obj = os.path.join(bdir, src + ".o")
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17"] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
+        # -fno-slp-vectorize: on gfx950 v_pk_{add,mul,fma}_f32 issue at half the rate of their scalar forms, so
+        # SLP-packing adjacent fp32 ops buys nothing and costs the v_mov's that build the register pairs
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-fno-slp-vectorize"] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -36,7 +36,15 @@
 #ifndef ED_WPB
 #define ED_WPB 8                 /* waves (= frames in flight) per workgroup                               */
 #endif
+#if ED_T2_LDS
+#define ED_XBUF_FLOATS 1160      /* per-wave LDS: 526 complex transpose slots | spectrum S[516] at 576 | u,v at 1104 */
+#define ED_S_OFF 576
+#define ED_L_OFF 1104
+#else
 #define ED_XBUF_FLOATS 576       /* per-wave LDS: spectrum S[516] | DCT input u[16], v[16] | pad            */
+#define ED_S_OFF 0
+#define ED_L_OFF 528
+#endif
 #define ED_FIXTAB_FLOATS (2 * 64 * 4 + 4 * 64 * 2) /* dct | split twiddles, then (NLO+NHI) x 64 weight quads */
 
 #ifndef ED_TW_LDS
@@ -157,12 +165,21 @@ __device__ __forceinline__ void ed_radix8(float (&r)[8], float (&i)[8])
 		ur[a] = r[a] + r[a + 4]; ui[a] = i[a] + i[a + 4];
 		vr[a] = r[a] - r[a + 4]; vi[a] = i[a] - i[a + 4];
 	}
-	float t;
-	t = vr[1]; vr[1] = h * (vr[1] + vi[1]); vi[1] = h * (vi[1] - t);   /* * (1 - i)/sqrt2  */
-	t = vr[2]; vr[2] = vi[2]; vi[2] = -t;                               /* * (-i)           */
-	t = vr[3]; vr[3] = h * (vi[3] - vr[3]); vi[3] = -h * (vi[3] + t);   /* * (-1 - i)/sqrt2 */
 	ed_dft4(ur[0], ui[0], ur[1], ui[1], ur[2], ui[2], ur[3], ui[3], r[0], i[0], r[2], i[2], r[4], i[4], r[6], i[6]);
-	ed_dft4(vr[0], vi[0], vr[1], vi[1], vr[2], vi[2], vr[3], vi[3], r[1], i[1], r[3], i[3], r[5], i[5], r[7], i[7]);
+	/* odd outputs: DFT4 of (v0, v1*(1-i)/sqrt2, v2*(-i), v3*(-1-i)/sqrt2). The 1/sqrt2 of the two rotated
+	 * inputs is not applied to them but carried into the last butterfly as an FMA coefficient:
+	 *   y1 = h*t1, t1 = (v1r+v1i, v1i-v1r);   y3 = h*t3, t3 = (v3i-v3r, -(v3i+v3r));   y2 = (v2i, -v2r)
+	 *   X1 = a1 + h*w, X5 = a1 - h*w, X3... with u = t1+t3, w = -i*(t1-t3), a0 = v0+y2, a1 = v0-y2           */
+	const float t1r = vr[1] + vi[1], t1i = vi[1] - vr[1];
+	const float t3r = vi[3] - vr[3], t3i = -(vi[3] + vr[3]);
+	const float a0r = vr[0] + vi[2], a0i = vi[0] - vr[2];
+	const float a1r = vr[0] - vi[2], a1i = vi[0] + vr[2];
+	const float u_r = t1r + t3r, u_i = t1i + t3i;
+	const float w_r = t1i - t3i, w_i = t3r - t1r;
+	r[1] = fmaf(h, u_r, a0r);  i[1] = fmaf(h, u_i, a0i);   /* Y0 = a0 + a2 */
+	r[5] = fmaf(-h, u_r, a0r); i[5] = fmaf(-h, u_i, a0i);  /* Y2 = a0 - a2 */
+	r[3] = fmaf(h, w_r, a1r);  i[3] = fmaf(h, w_i, a1i);   /* Y1 = a1 + a3 */
+	r[7] = fmaf(-h, w_r, a1r); i[7] = fmaf(-h, w_i, a1i);  /* Y3 = a1 - a3 */
 }
 
 /* First sample of frame f: (f / fpg) * group_stride + (f % fpg) * frame_step (f is wave-uniform, < 2^31). */
@@ -244,11 +261,15 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 	const float spec_scale = tab->spec_scale;
 	const float log_offset = tab->log_offset;
 	const bool do_log = tab->always_log || args.use_log;
-	/* after the two transposes lane (p = lane>>3, q = lane&7) holds Z[k0 + 64r] in register r, k0 = p + 8q */
-	const int k0 = (lane >> 3) + 8 * (lane & 7);
+	/* after the two transposes this lane holds Z[k0 + 64r] in register r (ED_K0: natural order with the LDS
+	 * transpose, octal-digit-swapped with the DPP one) */
+	const int k0 = ED_K0(lane);
 	const int k0p = (64 - k0) & 63;                          /* low 6 bits of the partner index 512 - k    */
-	const int pull = (((k0p & 7) << 3) | (k0p >> 3)) << 2;   /* byte address of the lane that holds it     */
-	if (lane < 3) xbuf[513 + lane] = 0.0f;                   /* spectrum padding: read by the last quad only */
+	const int pull = (ED_T2_LDS ? k0p : (((k0p & 7) << 3) | (k0p >> 3))) << 2; /* lane that holds it, as a byte address */
+	const int hi3 = lane >> 3, lo3 = lane & 7;
+	float2 *xc = reinterpret_cast<float2 *>(xbuf);
+	(void)hi3; (void)lo3; (void)xc;
+	if (lane < 3) xbuf[ED_S_OFF + 513 + lane] = 0.0f;        /* spectrum padding: read by the last quad only */
 
 	for (; f < n_frames; f += stride)
 	{
@@ -296,9 +317,24 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 			re[q] = xr * wr - xi * wi;
 			im[q] = xr * wi + xi * wr;
 		}
+#if ED_T2_LDS
+		/* transpose 2 through the wave-private LDS buffer: (lane 8p+c, reg q) -> (lane p+8q, reg c); slot
+		 * 66c + p + 8q is conflict-free for the ds_write_b64 (16-lane groups) and the ds_read_b64 alike */
+#pragma unroll
+		for (int q = 0; q < 8; q++) xc[66 * lo3 + hi3 + 8 * q] = make_float2(re[q], im[q]);
+		ed_wave_sync();
+#pragma unroll
+		for (int c = 0; c < 8; c++)
+		{
+			float2 v = xc[66 * c + lane];
+			re[c] = v.x; im[c] = v.y;
+		}
+		ed_wave_sync();
+#else
 		/* transpose 2: register q <-> lane bits 0..2 (c): (lane 8p+c, reg q) -> (lane 8p+q, reg c) */
 		ed_transpose8<0, 1, 2>(re, lane);
 		ed_transpose8<0, 1, 2>(im, lane);
+#endif
 
 		/* ---- 2c. pass 3: DFT over c  ->  reg r holds Z[k0 + 64r], k0 = p + 8q */
 		ed_radix8(re, im);
@@ -322,15 +358,17 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 			float ti = tw.y * bi - tw.x * br;
 			float xr = ar + tr, xi = ai + ti;           /* 2 X[k]                                            */
 			float yr = ar - tr, yi = ai - ti;           /* conj(2 X[512-k])                                  */
-			slo[m] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi) * spec_scale; /* v_sqrt_f32, 1 ulp */
-			shi[m] = __builtin_amdgcn_sqrtf(yr * yr + yi * yi) * spec_scale;
+			/* |2X| by v_sqrt_f32 (1 ulp). The spectrum's scale (1/2 and the variant's normalisation) is folded
+			 * into the mel weights; it is applied explicitly only where the spectrum itself is dumped. */
+			slo[m] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
+			shi[m] = __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
 			if (STAGES) { flr[m] = 0.5f * xr; fli[m] = 0.5f * xi; fhr[m] = 0.5f * yr; fhi[m] = -0.5f * yi; }
 		}
 		/* k = 256 pairs with itself: X[256] = conj(Z[256]) (lane 0, reg 4) */
-		const float s256 = 2.0f * __builtin_amdgcn_sqrtf(re[4] * re[4] + im[4] * im[4]) * spec_scale;
+		const float s256 = 2.0f * __builtin_amdgcn_sqrtf(re[4] * re[4] + im[4] * im[4]);
 
 		/* ---- 4. spectrum to LDS; S[513..515] were zeroed before the loop and only ever meet zero weights */
-		float *S = xbuf;
+		float *S = xbuf + ED_S_OFF; /* disjoint from the transpose slots 0..525 */
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 		{
@@ -355,7 +393,7 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		ed_wave_sync();
 		if (STAGES && args.spec)
 		{
-			for (int k = lane; k < 513; k += 64) args.spec[(int64_t)f * 513 + k] = S[k];
+			for (int k = lane; k < 513; k += 64) args.spec[(int64_t)f * 513 + k] = S[k] * spec_scale;
 		}
 
 		/* ---- 5. mel filterbank, balanced: lane (b = lane&15, r = lane>>4) sums quarter r of the narrow band b
@@ -391,7 +429,7 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 
 		/* ---- 6. DCT-II through cos symmetry: y[c] = sum_{n<16} D[n][c] * (L[n] + (-1)^c L[31-n]);
 		 *         lane (c = lane&31, h = lane>>5) sums n = 8h..8h+7 */
-		float *Lb = xbuf + 528; /* u[16] | v[16], 16-B aligned, behind the spectrum */
+		float *Lb = xbuf + ED_L_OFF; /* u[16] | v[16], 16-B aligned, behind the spectrum */
 		if (lane < 16) { Lb[lane] = llo + lhi; Lb[16 + lane] = llo - lhi; }
 		ed_wave_sync();
 		const float4 *L4 = reinterpret_cast<const float4 *>(Lb + 16 * (lane & 1) + 8 * (lane >> 5));

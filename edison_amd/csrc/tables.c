@@ -64,6 +64,9 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 	const int nbins = (variant == EDISON_MFCC_A) ? EDISON_FRAME_LEN / 2 : EDISON_FRAME_LEN / 2 + 1;
 	if (variant != EDISON_MFCC_A && variant != EDISON_MFCC_B) return EDISON_E_ARGUMENT;
 	memset(out, 0, sizeof(*out));
+	/* scale of the reference's spectrogram relative to the kernel's 2|X[k]|: A |X| (mfcc_utils.py:174),
+	 * B |X/1024|/sqrt2 (mfcc_utils.py:297-300) */
+	const double spec_scale = (variant == EDISON_MFCC_A) ? 0.5 : 0.5 / 1024.0 / sqrt(2.0);
 
 	/* --- FFT twiddles, rounded once from float64 */
 	for (int l = 0; l < 64; l++)
@@ -77,8 +80,7 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 	for (int m = 0; m < 4; m++)
 		for (int l = 0; l < 64; l++)
 		{
-			/* after the two in-register transposes lane (p = l>>3, q = l&7) holds Z[k0 + 64r], k0 = p + 8q */
-			const int k0 = (l >> 3) + 8 * (l & 7);
+			const int k0 = ED_K0(l); /* lane l holds Z[k0 + 64r] after the last FFT pass */
 			double a = -2.0 * M_PI * (double)(k0 + 64 * m) / 1024.0;
 			out->twp[m][l][0] = (float)cos(a); out->twp[m][l][1] = (float)sin(a);
 		}
@@ -141,7 +143,8 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 				{
 					const int q = s4 + t, k = 4 * q + c;
 					const int mine = q >= pq0 && q < pq1 && k >= ks[j] && k < ke[j] && k < nbins;
-					out->mel_w4[(part == 0 ? 0 : NLO) + t][l][c] = mine ? (float)W[(size_t)k * NMEL + j] : 0.0f;
+					/* the kernel's spectrum is 2|X[k]|: the factor 1/2 and the variant's normalisation ride on the weights */
+					out->mel_w4[(part == 0 ? 0 : NLO) + t][l][c] = mine ? (float)(spec_scale * W[(size_t)k * NMEL + j]) : 0.0f;
 				}
 		}
 	}
@@ -159,7 +162,7 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 			    (float)(dscale * 2.0 * cos(M_PI * (double)c * (double)(2 * nn + 1) / (double)(2 * NMEL)));
 		}
 	}
-	out->spec_scale = (variant == EDISON_MFCC_A) ? 0.5f : (float)(0.5 / 1024.0 / sqrt(2.0));
+	out->spec_scale = (float)spec_scale;
 	out->log_offset = 1e-6f;
 	out->always_log = (variant == EDISON_MFCC_A) ? 1 : 0;
 	return EDISON_OK;
