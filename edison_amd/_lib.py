@@ -69,6 +69,8 @@ SIGNATURES = {
     "aiNnomGetOutputBuffer": (c_void_p, []),
     "mfccToNetInput": (None, [c_void_p, ctypes.c_uint16, ctypes.c_uint16, ctypes.c_uint32]),
     "mfccToNetInputPush": (None, [c_void_p, ctypes.c_uint16, ctypes.c_uint16]),
+    "audioInit": (None, []),
+    "audioCalcMFCCs": (None, [c_void_p, ctypes.POINTER(c_void_p)]),
     "edison_mfcc_frame": (c_int, [c_void_p, c_int, c_void_p]),
     "edison_global_ctx": (c_void_p, []),
 }

@@ -186,6 +186,11 @@ int8_t *aiNnomGetOutputBuffer(void);
  * (clip to [-128,127] after integer division by NNOM_INPUT_SCALE = 1, app.c:685-693).                    */
 void mfccToNetInput(int16_t *mfcc, uint16_t in_x, uint16_t in_y, uint32_t xoffset);
 void mfccToNetInputPush(int16_t *mfcc, uint16_t in_x, uint16_t in_y);
+/* firmware/src/audioprocessing.h:21-22: one 1024-sample frame -> pointer to a callee-owned static buffer of 32
+ * int16 (valid until the next call). CALL SURFACE of the firmware's Q15 MFCC; the numbers come from variant B, the
+ * reference's float model of that path, rounded -- the bit-exact Q15 restatement (variant C) is not built yet. */
+void audioInit(void);
+void audioCalcMFCCs(int16_t *inp, int16_t **oup);
 /* One 1024-sample frame through the GPU MFCC (variant B float model of the firmware's Q15 path); out32 fp32. */
 int edison_mfcc_frame(const int16_t *frame1024, int variant, float *out32);
 edison_ctx *edison_global_ctx(void);

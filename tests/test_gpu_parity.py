@@ -230,6 +230,30 @@ def test_legacy_frame_and_push_flow(built_lib, ctx, kws_golden):
     assert np.array_equal(out, kws_golden["kws_zero_softmax"])
 
 
+def test_legacy_audio_calc_mfccs_flow(built_lib, ctx, kws_golden, mfcc_golden):
+    """app.c:190-203 with the firmware's own names: audioCalcMFCCs -> mfccToNetInput -> aiRunInference. The int16
+    coefficients are variant B rounded (the call surface of the Q15 path; its bit-exact numerics are a later row)."""
+    L = built_lib
+    L.audioInit()
+    a = kws_golden["kws_zero_audio"]
+    out = ctypes.c_void_p()
+    rows = []
+    for i in range(31):
+        fr = np.ascontiguousarray(a[i * 1024:(i + 1) * 1024])
+        L.audioCalcMFCCs(fr.ctypes.data_as(ctypes.c_void_p), ctypes.byref(out))
+        m16 = np.frombuffer((ctypes.c_int16 * 32).from_address(out.value), dtype=np.int16).copy()
+        rows.append(m16)
+        L.mfccToNetInput(m16.ctypes.data_as(ctypes.c_void_p), 13, 31, i)
+    rows = np.stack(rows)
+    ref = kws_golden["kws_zero_mfcc"]                       # float64 variant B of the reference, [31, 13]
+    assert np.abs(rows[:, :13] - np.round(ref)).max() <= 1  # rounding of fp32 vs float64 may differ on x.5
+    net_in = np.frombuffer((ctypes.c_int8 * 403).from_address(L.aiNnomGetInputBuffer()), dtype=np.int8).copy()
+    assert np.abs(net_in.reshape(31, 13).astype(int) - kws_golden["kws_zero_feat"].astype(int)).max() <= 1
+    res = np.zeros(10, np.int8)
+    assert L.aiRunInference(net_in.ctypes.data_as(ctypes.c_void_p), res.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert int(np.argmax(res)) == 0                          # "edison"
+
+
 # ---------------------------------------------------------------------------------------------- Python mirror / CLI
 
 def test_python_mirror_mfcc_utils(ctx, mfcc_golden):
