@@ -9,11 +9,13 @@
  * Pipeline per wavefront (lane = 0..63):
  *   1. load      z[n] = x[2n] + i*x[2n+1], n = lane + 64a (a = 0..7): 8 coalesced 256-B wave loads, issued one
  *                frame ahead (software prefetch) so HBM latency hides under the previous frame's arithmetic
- *   2. FFT512    3 radix-8 passes over the digits of n = 64a + 8b + c, k = p + 8q + 64r, ENTIRELY IN REGISTERS:
- *                the two digit transposes (register index <-> three lane-index bits) are butterfly exchanges on
- *                the VALU -- v_permlane32_swap / v_permlane16_swap for lane bits 5 / 4, DPP row_shr/row_shl with
- *                bank masks for bits 3 / 2, DPP quad_perm + select for bits 1 / 0. The LDS pipe, which a
- *                write-then-read transpose saturates first on this chip, carries none of the FFT.
+ *   2. FFT512    3 radix-8 passes over the digits of n = 64a + 8b + c, k = p + 8q + 64r. Each of the two digit
+ *                transposes swaps the register index with three lane-index bits. Transpose 1 (lane bits 3-5) is a
+ *                butterfly exchange on the VALU: v_permlane32_swap / v_permlane16_swap for bits 5 / 4, DPP
+ *                row_shr/row_shl:8 with bank masks for bit 3. Transpose 2 (lane bits 0-2) goes through a padded
+ *                wave-private LDS buffer (ED_T2_LDS = 1, default) -- with both transposes in LDS the write-heavy
+ *                LDS pipe saturates, with both on the VALU (ED_T2_LDS = 0: DPP row_shr/shl:4 and quad_perm +
+ *                select) the VALU does; split, the two pipes are about equally loaded.
  *   3. split     X[k] = E[k] + W1024^k O[k] from Z[k], conj Z[512-k]; lane handles the pair (k, 512-k); the
  *                partner value comes through ds_bpermute (LDS crossbar, no LDS memory)
  *   4. |X|       -> wave-private LDS spectrum S[0..512] (+3 pad)
@@ -169,7 +171,8 @@ __device__ __forceinline__ void ed_radix8(float (&r)[8], float (&i)[8])
 	/* odd outputs: DFT4 of (v0, v1*(1-i)/sqrt2, v2*(-i), v3*(-1-i)/sqrt2). The 1/sqrt2 of the two rotated
 	 * inputs is not applied to them but carried into the last butterfly as an FMA coefficient:
 	 *   y1 = h*t1, t1 = (v1r+v1i, v1i-v1r);   y3 = h*t3, t3 = (v3i-v3r, -(v3i+v3r));   y2 = (v2i, -v2r)
-	 *   X1 = a1 + h*w, X5 = a1 - h*w, X3... with u = t1+t3, w = -i*(t1-t3), a0 = v0+y2, a1 = v0-y2           */
+	 *   with u = t1+t3, w = -i*(t1-t3), a0 = v0+y2, a1 = v0-y2:  X1 = a0 + h*u, X5 = a0 - h*u, X3 = a1 + h*w,
+	 *   X7 = a1 - h*w                                                                                          */
 	const float t1r = vr[1] + vi[1], t1i = vi[1] - vr[1];
 	const float t3r = vi[3] - vr[3], t3i = -(vi[3] + vr[3]);
 	const float a0r = vr[0] + vi[2], a0i = vi[0] - vr[2];

@@ -20,11 +20,11 @@ __device__ __forceinline__ unsigned long long ed_now()
 '''
 s = s.replace('__device__ __forceinline__ void ed_wave_sync()', stamp + '__device__ __forceinline__ void ed_wave_sync()')
 s = s.replace('	for (; f < n_frames; f += stride)\n	{', '	unsigned long long ph[ED_NPH]; for (int i_ = 0; i_ < ED_NPH; i_++) ph[i_] = 0;\n	unsigned long long tlast = ed_now();\n	for (; f < n_frames; f += stride)\n	{\n		ED_STAMP(11)')
-marks = ['		/* ---- 2a. pass 1', '		/* transpose 1:', '		/* ---- 2b. pass 2', '		/* transpose 2:', '		/* ---- 2c. pass 3',
+marks = ['		/* ---- 2a. pass 1', '		/* transpose 1:', '		/* ---- 2b. pass 2', '#if ED_T2_LDS\n		/* transpose 2 through', '		/* ---- 2c. pass 3',
          '		/* ---- 3. real-FFT split.', '		/* ---- 4. spectrum to LDS', '		/* ---- 5. mel filterbank', '		/* ---- 6. DCT-II', '		/* ---- 7. store */']
 for i, m in enumerate(marks):
     assert s.count(m) == 1, m
-    s = s.replace(m, '		ED_STAMP(%d)\n%s' % (i, m))
+    s = s.replace(m, '		ED_STAMP(%d)\n%s' % (i, m)) if not m.startswith('#if') else s.replace(m, '		ED_STAMP(%d)\n%s' % (i, m))
 tail = '''				args.feat[(int64_t)f * args.n_coef + lane] = (int8_t)__float2int_rn(q);
 			}
 		}

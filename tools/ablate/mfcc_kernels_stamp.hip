@@ -9,13 +9,20 @@
  * Pipeline per wavefront (lane = 0..63):
  *   1. load      z[n] = x[2n] + i*x[2n+1], n = lane + 64a (a = 0..7): 8 coalesced 256-B wave loads, issued one
  *                frame ahead (software prefetch) so HBM latency hides under the previous frame's arithmetic
- *   2. FFT512    3 radix-8 passes over the digits of n = 64a + 8b + c, k = p + 8q + 64r; the two digit
- *                transposes go through a wave-private, padded LDS buffer (conflict-free ds_*_b64)
- *   3. split     X[k] = E[k] + W1024^k O[k] from Z[k], conj Z[512-k]; lane handles the pair (k, 512-k)
+ *   2. FFT512    3 radix-8 passes over the digits of n = 64a + 8b + c, k = p + 8q + 64r. Each of the two digit
+ *                transposes swaps the register index with three lane-index bits. Transpose 1 (lane bits 3-5) is a
+ *                butterfly exchange on the VALU: v_permlane32_swap / v_permlane16_swap for bits 5 / 4, DPP
+ *                row_shr/row_shl:8 with bank masks for bit 3. Transpose 2 (lane bits 0-2) goes through a padded
+ *                wave-private LDS buffer (ED_T2_LDS = 1, default) -- with both transposes in LDS the write-heavy
+ *                LDS pipe saturates, with both on the VALU (ED_T2_LDS = 0: DPP row_shr/shl:4 and quad_perm +
+ *                select) the VALU does; split, the two pipes are about equally loaded.
+ *   3. split     X[k] = E[k] + W1024^k O[k] from Z[k], conj Z[512-k]; lane handles the pair (k, 512-k); the
+ *                partner value comes through ds_bpermute (LDS crossbar, no LDS memory)
  *   4. |X|       -> wave-private LDS spectrum S[0..512] (+3 pad)
- *   5. mel       32 banded dot products: lane (band j = lane&31, half h = lane>>5) reads its taps as 16-byte
- *                quads (ds_read_b128 for spectrum and weights), halves combined with one cross-lane shuffle
- *   6. ln / DCT  optional ln(x+1e-6); DCT-II against a per-lane LDS table, halves combined by shuffle
+ *   5. mel       32 banded dot products, balanced: lane (b = lane&15, r = lane>>4) sums quarter r of the narrow
+ *                band b and of the wide band 31-b as 16-byte quads (ds_read_b128 spectrum + weights); quarters are
+ *                summed over the lane rows with VALU row swaps
+ *   6. ln / DCT  optional ln(x+1e-6); DCT-II through cos symmetry against a per-lane LDS table
  *   7. store     n_coef fp32 and/or int8 (clip, round-half-even) per frame
  *
  * Waves never share LDS data, so there is no workgroup barrier inside the frame loop. The constant tables
@@ -24,14 +31,28 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "edison_internal.h"
 
 #ifndef ED_WPB
 #define ED_WPB 8                 /* waves (= frames in flight) per workgroup                               */
 #endif
-#define ED_XBUF_FLOATS 1160      /* per-wave LDS: 576 complex exchange slots (also Pz + S + L) + pad        */
-#define ED_FIXTAB_FLOATS (4 * 64 * 4 + 4 * 64 * 2) /* dct | split twiddles, then mel_T4 x 64 weight quads   */
+#if ED_T2_LDS
+#define ED_XBUF_FLOATS 1160      /* per-wave LDS: 526 complex transpose slots | spectrum S[516] at 576 | u,v at 1104 */
+#define ED_S_OFF 576
+#define ED_L_OFF 1104
+#else
+#define ED_XBUF_FLOATS 576       /* per-wave LDS: spectrum S[516] | DCT input u[16], v[16] | pad            */
+#define ED_S_OFF 0
+#define ED_L_OFF 528
+#endif
+#define ED_FIXTAB_FLOATS (2 * 64 * 4 + 4 * 64 * 2) /* dct | split twiddles, then (NLO+NHI) x 64 weight quads */
+
+#ifndef ED_TW_LDS
+#define ED_TW_LDS 0              /* 1: pass-1/2 twiddles read from LDS instead of living in 28 registers      */
+#endif
+#define ED_TWTAB_FLOATS (ED_TW_LDS ? 2048 : 0)
 
 #ifdef ED_MIN_WAVES
 #define ED_MFCC_BOUNDS __launch_bounds__(64 * ED_WPB, ED_MIN_WAVES)
@@ -60,6 +81,80 @@ __device__ __forceinline__ void ed_wave_sync()
 	__builtin_amdgcn_wave_barrier();
 }
 
+/* x[lane] + x[lane ^ 32] in every lane: v_permlane32_swap exchanges the upper half of one register with the
+ * lower half of another, so swapping a register with a copy of itself leaves (lo,lo) and (hi,hi). */
+__device__ __forceinline__ float ed_sum_halves(float x)
+{
+	const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+	return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+/* sum over the four 16-lane rows, result in every lane: v_permlane16_swap (odd rows of one register <-> even rows
+ * of the other) gives the row-pair sums, ed_sum_halves finishes. */
+__device__ __forceinline__ float ed_sum_rows(float x)
+{
+	const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+	return ed_sum_halves(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+}
+
+/*
+ * One butterfly stage of an in-register transpose: for the register pair (A: register-index bit 0, B: bit 1) and lane
+ * bit LB, exchange A at lanes whose bit LB is 1 with B at the partner lanes (lane ^ (1 << LB)) whose bit LB is 0.
+ * Three such stages (three register-index bits against three lane bits) swap a 3-bit register index with a 3-bit
+ * lane-index field: element (lane field = u, register = v) moves to (lane field = v, register = u).
+ */
+template <int LB>
+__device__ __forceinline__ void ed_xchg(float &A, float &B, int lane)
+{
+	const unsigned a = __float_as_uint(A), b = __float_as_uint(B);
+	if (LB == 5)
+	{
+		const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); /* A.upper half <-> B.lower half */
+		A = __uint_as_float(r[0]); B = __uint_as_float(r[1]);
+	}
+	else if (LB == 4)
+	{
+		const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); /* A.odd rows <-> B.even rows */
+		A = __uint_as_float(r[0]); B = __uint_as_float(r[1]);
+	}
+	else if (LB == 3)
+	{
+		/* row_shr:8 -> lanes 8..15 of a row (banks 2,3) read lane-8; row_shl:8 -> lanes 0..7 (banks 0,1) read lane+8 */
+		const unsigned na = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x118, 0xf, 0xc, false);
+		const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x108, 0xf, 0x3, false);
+		A = __uint_as_float(na); B = __uint_as_float(nb);
+	}
+	else if (LB == 2)
+	{
+		/* row_shr:4 into banks 1,3 (lane bit 2 set); row_shl:4 into banks 0,2 */
+		const unsigned na = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x114, 0xf, 0xa, false);
+		const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x104, 0xf, 0x5, false);
+		A = __uint_as_float(na); B = __uint_as_float(nb);
+	}
+	else
+	{
+		/* inside a quad no mask applies: pull the partner lane with quad_perm, select on the lane bit */
+		constexpr int ctrl = (LB == 1) ? 0x4E /* [2,3,0,1] */ : 0xB1 /* [1,0,3,2] */;
+		const unsigned pb = (unsigned)__builtin_amdgcn_mov_dpp((int)b, ctrl, 0xf, 0xf, false);
+		const unsigned pa = (unsigned)__builtin_amdgcn_mov_dpp((int)a, ctrl, 0xf, 0xf, false);
+		const bool up = (lane >> LB) & 1;
+		A = __uint_as_float(up ? pb : a);
+		B = __uint_as_float(up ? b : pa);
+	}
+}
+
+/* swap the 3-bit register index of x[0..7] with lane bits LB0 (register bit 0), LB1 (bit 1), LB2 (bit 2) */
+template <int LB0, int LB1, int LB2>
+__device__ __forceinline__ void ed_transpose8(float (&x)[8], int lane)
+{
+#pragma unroll
+	for (int i = 0; i < 8; i += 2) ed_xchg<LB0>(x[i], x[i + 1], lane);
+#pragma unroll
+	for (int i = 0; i < 8; i++) if (!(i & 2)) ed_xchg<LB1>(x[i], x[i + 2], lane);
+#pragma unroll
+	for (int i = 0; i < 4; i++) ed_xchg<LB2>(x[i], x[i + 4], lane);
+}
+
 __device__ __forceinline__ void ed_dft4(float y0r, float y0i, float y1r, float y1i, float y2r, float y2i, float y3r,
                                         float y3i, float &o0r, float &o0i, float &o1r, float &o1i, float &o2r,
                                         float &o2i, float &o3r, float &o3i)
@@ -85,12 +180,22 @@ __device__ __forceinline__ void ed_radix8(float (&r)[8], float (&i)[8])
 		ur[a] = r[a] + r[a + 4]; ui[a] = i[a] + i[a + 4];
 		vr[a] = r[a] - r[a + 4]; vi[a] = i[a] - i[a + 4];
 	}
-	float t;
-	t = vr[1]; vr[1] = h * (vr[1] + vi[1]); vi[1] = h * (vi[1] - t);   /* * (1 - i)/sqrt2  */
-	t = vr[2]; vr[2] = vi[2]; vi[2] = -t;                               /* * (-i)           */
-	t = vr[3]; vr[3] = h * (vi[3] - vr[3]); vi[3] = -h * (vi[3] + t);   /* * (-1 - i)/sqrt2 */
 	ed_dft4(ur[0], ui[0], ur[1], ui[1], ur[2], ui[2], ur[3], ui[3], r[0], i[0], r[2], i[2], r[4], i[4], r[6], i[6]);
-	ed_dft4(vr[0], vi[0], vr[1], vi[1], vr[2], vi[2], vr[3], vi[3], r[1], i[1], r[3], i[3], r[5], i[5], r[7], i[7]);
+	/* odd outputs: DFT4 of (v0, v1*(1-i)/sqrt2, v2*(-i), v3*(-1-i)/sqrt2). The 1/sqrt2 of the two rotated
+	 * inputs is not applied to them but carried into the last butterfly as an FMA coefficient:
+	 *   y1 = h*t1, t1 = (v1r+v1i, v1i-v1r);   y3 = h*t3, t3 = (v3i-v3r, -(v3i+v3r));   y2 = (v2i, -v2r)
+	 *   with u = t1+t3, w = -i*(t1-t3), a0 = v0+y2, a1 = v0-y2:  X1 = a0 + h*u, X5 = a0 - h*u, X3 = a1 + h*w,
+	 *   X7 = a1 - h*w                                                                                          */
+	const float t1r = vr[1] + vi[1], t1i = vi[1] - vr[1];
+	const float t3r = vi[3] - vr[3], t3i = -(vi[3] + vr[3]);
+	const float a0r = vr[0] + vi[2], a0i = vi[0] - vr[2];
+	const float a1r = vr[0] - vi[2], a1i = vi[0] + vr[2];
+	const float u_r = t1r + t3r, u_i = t1i + t3i;
+	const float w_r = t1i - t3i, w_i = t3r - t1r;
+	r[1] = fmaf(h, u_r, a0r);  i[1] = fmaf(h, u_i, a0i);   /* Y0 = a0 + a2 */
+	r[5] = fmaf(-h, u_r, a0r); i[5] = fmaf(-h, u_i, a0i);  /* Y2 = a0 - a2 */
+	r[3] = fmaf(h, w_r, a1r);  i[3] = fmaf(h, w_i, a1i);   /* Y1 = a1 + a3 */
+	r[7] = fmaf(-h, w_r, a1r); i[7] = fmaf(-h, w_i, a1i);  /* Y3 = a1 - a3 */
 }
 
 /* First sample of frame f: (f / fpg) * group_stride + (f % fpg) * frame_step (f is wave-uniform, < 2^31). */
@@ -123,25 +228,40 @@ __device__ __forceinline__ void ed_load_frame(const int16_t *fp, int lane, uint3
 	}
 }
 
-template <bool STAGES, bool ALIGNED>
+template <bool STAGES, bool ALIGNED, int NLO, int NHI>
 __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
 {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int T4 = args.mel_T4;                                                  /* == tab->mel_T4          */
-	const float4 *dctl = reinterpret_cast<const float4 *>(smem);                 /* [4][64] x 4 coefficients */
-	const float2 *tpl = reinterpret_cast<const float2 *>(smem + 1024);           /* [4][64] W1024^(lane+64m) */
-	const float4 *melw4 = reinterpret_cast<const float4 *>(smem + ED_FIXTAB_FLOATS); /* [T4][64] weight quads */
-	float *xbuf = smem + ED_FIXTAB_FLOATS + T4 * 256 + wave * ED_XBUF_FLOATS;    /* wave-private            */
-	float2 *xc = reinterpret_cast<float2 *>(xbuf);
+	const float4 *dctl = reinterpret_cast<const float4 *>(smem);                 /* [2][64] x 4 coefficients */
+	const float2 *tpl = reinterpret_cast<const float2 *>(smem + 512);            /* [4][64] split twiddles   */
+	const float4 *melw4 = reinterpret_cast<const float4 *>(smem + ED_FIXTAB_FLOATS); /* [NLO+NHI][64] quads   */
+	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED_TWTAB_FLOATS + wave * ED_XBUF_FLOATS; /* wave-private */
 
-	{ /* the table block [dct4 | twp | mel_w4(T4 rows)] is laid out in global memory exactly as in LDS */
+	/* the first frame's samples go in flight before anything else: their HBM latency hides under the table staging */
+	const uint32_t n_frames = (uint32_t)args.n_frames;
+	const uint32_t stride = gridDim.x * ED_WPB;
+	uint32_t f = blockIdx.x * ED_WPB + wave;
+	uint32_t raw[8];
+	if (f < n_frames) ed_load_frame<ALIGNED>(ed_frame_ptr(args, f), lane, raw);
+
+	{ /* the table block [dct4 | twp | mel_w4(NLO+NHI rows)] is laid out in global memory exactly as in LDS */
 		const float4 *src = reinterpret_cast<const float4 *>(&tab->dct4[0][0][0]);
 		float4 *dst = reinterpret_cast<float4 *>(smem);
-		for (int t = threadIdx.x; t < (ED_FIXTAB_FLOATS + T4 * 256) / 4; t += blockDim.x) dst[t] = src[t];
+		for (int t = threadIdx.x; t < (ED_FIXTAB_FLOATS + (NLO + NHI) * 256) / 4; t += blockDim.x) dst[t] = src[t];
 	}
 
+#if ED_TW_LDS
+	/* pass-1/2 twiddles: per-lane LDS tables [p][lane] (conflict-free ds_read_b64), 28 registers saved */
+	const float2 *tw1l = reinterpret_cast<const float2 *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256) + lane;
+	const float2 *tw2l = tw1l + 512;
+	{
+		const float4 *src = reinterpret_cast<const float4 *>(&tab->tw1[0][0][0]); /* tw1 | tw2 are adjacent */
+		float4 *dst = reinterpret_cast<float4 *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256);
+		for (int t = threadIdx.x; t < 2048 / 4; t += blockDim.x) dst[t] = src[t];
+	}
+#else
 	/* pass-1/2 twiddles: resident in registers for the whole persistent loop */
 	float t1r[8], t1i[8], t2r[8], t2i[8];
 #pragma unroll
@@ -151,23 +271,21 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		const float2 b = *reinterpret_cast<const float2 *>(&tab->tw2[p][lane][0]);
 		t1r[p] = a.x; t1i[p] = a.y; t2r[p] = b.x; t2i[p] = b.y;
 	}
-	__syncthreads();
-#ifdef ED_STAGGER
-	/* Waves that share a SIMD (w, w+4 of a workgroup; the workgroups of a CU) run the same program; start
-	 * them a fraction of a frame apart so that one wave's LDS-heavy transposes overlap another's arithmetic. */
-	for (int s = ((wave >> 2) * 2 + (blockIdx.x & 1)); s > 0; s--) __builtin_amdgcn_s_sleep(ED_STAGGER);
 #endif
-	const int mel_start4 = tab->mel_start4[lane];
+	__syncthreads();
+	const int mel_slo4 = tab->mel_slo4[lane], mel_shi4 = tab->mel_shi4[lane];
 	const float spec_scale = tab->spec_scale;
 	const float log_offset = tab->log_offset;
 	const bool do_log = tab->always_log || args.use_log;
+	/* after the two transposes this lane holds Z[k0 + 64r] in register r (ED_K0: natural order with the LDS
+	 * transpose, octal-digit-swapped with the DPP one) */
+	const int k0 = ED_K0(lane);
+	const int k0p = (64 - k0) & 63;                          /* low 6 bits of the partner index 512 - k    */
+	const int pull = (ED_T2_LDS ? k0p : (((k0p & 7) << 3) | (k0p >> 3))) << 2; /* lane that holds it, as a byte address */
 	const int hi3 = lane >> 3, lo3 = lane & 7;
-
-	const uint32_t n_frames = (uint32_t)args.n_frames;
-	const uint32_t stride = gridDim.x * ED_WPB;
-	uint32_t f = blockIdx.x * ED_WPB + wave;
-	uint32_t raw[8];
-	if (f < n_frames) ed_load_frame<ALIGNED>(ed_frame_ptr(args, f), lane, raw);
+	float2 *xc = reinterpret_cast<float2 *>(xbuf);
+	(void)hi3; (void)lo3; (void)xc;
+	if (lane < 3) xbuf[ED_S_OFF + 513 + lane] = 0.0f;        /* spectrum padding: read by the last quad only */
 
 	unsigned long long ph[ED_NPH]; for (int i_ = 0; i_ < ED_NPH; i_++) ph[i_] = 0;
 	unsigned long long tlast = ed_now();
@@ -185,40 +303,46 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		if (f + stride < n_frames) ed_load_frame<ALIGNED>(ed_frame_ptr(args, f + stride), lane, raw);
 
 		ED_STAMP(0)
-		/* ---- 2a. pass 1: DFT over a, twiddle W512^(lane*p) */
+		/* ---- 2a. pass 1: DFT over a (registers), twiddle W512^(lane*p); lane = 8b + c */
 		ed_radix8(re, im);
 #pragma unroll
 		for (int p = 1; p < 8; p++)
 		{
+#if ED_TW_LDS
+			const float2 w = tw1l[64 * p];
+			const float wr = w.x, wi = w.y;
+#else
+			const float wr = t1r[p], wi = t1i[p];
+#endif
 			float xr = re[p], xi = im[p];
-			re[p] = xr * t1r[p] - xi * t1i[p];
-			im[p] = xr * t1i[p] + xi * t1r[p];
+			re[p] = xr * wr - xi * wi;
+			im[p] = xr * wi + xi * wr;
 		}
 		ED_STAMP(1)
-		/* transpose 1: (lane = 8b+c, reg p) -> (lane = 8p+c, reg b); slot = 72p + 8b + c */
-#pragma unroll
-		for (int p = 0; p < 8; p++) xc[72 * p + lane] = make_float2(re[p], im[p]);
-		ed_wave_sync();
-#pragma unroll
-		for (int b = 0; b < 8; b++)
-		{
-			float2 v = xc[72 * hi3 + 8 * b + lo3];
-			re[b] = v.x; im[b] = v.y;
-		}
-		ed_wave_sync();
+		/* transpose 1: register p <-> lane bits 3..5 (b): (lane 8b+c, reg p) -> (lane 8p+c, reg b) */
+		ed_transpose8<3, 4, 5>(re, lane);
+		ed_transpose8<3, 4, 5>(im, lane);
 
 		ED_STAMP(2)
-		/* ---- 2b. pass 2: DFT over b, twiddle W64^(c*q) */
+		/* ---- 2b. pass 2: DFT over b, twiddle W64^(c*q); lane = 8p + c */
 		ed_radix8(re, im);
 #pragma unroll
 		for (int q = 1; q < 8; q++)
 		{
+#if ED_TW_LDS
+			const float2 w = tw2l[64 * q];
+			const float wr = w.x, wi = w.y;
+#else
+			const float wr = t2r[q], wi = t2i[q];
+#endif
 			float xr = re[q], xi = im[q];
-			re[q] = xr * t2r[q] - xi * t2i[q];
-			im[q] = xr * t2i[q] + xi * t2r[q];
+			re[q] = xr * wr - xi * wi;
+			im[q] = xr * wi + xi * wr;
 		}
 		ED_STAMP(3)
-		/* transpose 2: (lane = 8p+c, reg q) -> (lane = p+8q, reg c); slot = 66c + p + 8q */
+#if ED_T2_LDS
+		/* transpose 2 through the wave-private LDS buffer: (lane 8p+c, reg q) -> (lane p+8q, reg c); slot
+		 * 66c + p + 8q is conflict-free for the ds_write_b64 (16-lane groups) and the ds_read_b64 alike */
 #pragma unroll
 		for (int q = 0; q < 8; q++) xc[66 * lo3 + hi3 + 8 * q] = make_float2(re[q], im[q]);
 		ed_wave_sync();
@@ -229,46 +353,53 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 			re[c] = v.x; im[c] = v.y;
 		}
 		ed_wave_sync();
+#else
+		/* transpose 2: register q <-> lane bits 0..2 (c): (lane 8p+c, reg q) -> (lane 8p+q, reg c) */
+		ed_transpose8<0, 1, 2>(re, lane);
+		ed_transpose8<0, 1, 2>(im, lane);
+#endif
 
 		ED_STAMP(4)
-		/* ---- 2c. pass 3: DFT over c  ->  reg r holds Z[lane + 64r] */
+		/* ---- 2c. pass 3: DFT over c  ->  reg r holds Z[k0 + 64r], k0 = p + 8q */
 		ed_radix8(re, im);
 
 		ED_STAMP(5)
-		/* ---- 3. real-FFT split. Partner buffer Pz[j] = Z[256 + j] (regs 4..7), read back reversed. */
-#pragma unroll
-		for (int r = 4; r < 8; r++) xc[lane + 64 * (r - 4)] = make_float2(re[r], im[r]);
-		ed_wave_sync();
+		/* ---- 3. real-FFT split. The partner Z[512-k] of k = k0 + 64m (m < 4) is register 7-m of the lane whose
+		 *         k0 is (64 - k0) % 64: pulled through the LDS crossbar (ds_bpermute, no LDS memory, one trip).
+		 *         Lane 0 (k0 = 0) is its own partner, one register further up: Z[512 - 64m] = its register 8-m. */
 		float slo[4], shi[4];
 		float flr[4], fli[4], fhr[4], fhi[4]; /* X[k], X[512-k] for the stage dump */
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 		{
-			float2 pz = xc[256 - lane - 64 * m]; /* Z[512 - k]; slot 256 (lane 0, m 0) is Z[512] = Z[0] */
-			if (m == 0 && lane == 0) pz = make_float2(re[0], im[0]);
-			const float2 tw = tpl[64 * m + lane];
+			float2 pz;
+			pz.x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m])));
+			pz.y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m])));
+			if (lane == 0) pz = make_float2(re[(8 - m) & 7], im[(8 - m) & 7]);
+			const float2 tw = tpl[64 * m + lane];       /* W1024^(k0 + 64m)                                  */
 			float ar = re[m] + pz.x, ai = im[m] - pz.y; /* A  = Z[k] + conj Z[512-k]          = 2 E[k]      */
 			float br = re[m] - pz.x, bi = im[m] + pz.y; /* B  = Z[k] - conj Z[512-k]; O2 = -i*B = 2 O[k]    */
 			float tr = tw.x * bi + tw.y * br;           /* T  = W1024^k * (bi - i*br)                        */
 			float ti = tw.y * bi - tw.x * br;
 			float xr = ar + tr, xi = ai + ti;           /* 2 X[k]                                            */
 			float yr = ar - tr, yi = ai - ti;           /* conj(2 X[512-k])                                  */
-			slo[m] = __fsqrt_rn(xr * xr + xi * xi) * spec_scale;
-			shi[m] = __fsqrt_rn(yr * yr + yi * yi) * spec_scale;
+			/* |2X| by v_sqrt_f32 (1 ulp). The spectrum's scale (1/2 and the variant's normalisation) is folded
+			 * into the mel weights; it is applied explicitly only where the spectrum itself is dumped. */
+			slo[m] = __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
+			shi[m] = __builtin_amdgcn_sqrtf(yr * yr + yi * yi);
 			if (STAGES) { flr[m] = 0.5f * xr; fli[m] = 0.5f * xi; fhr[m] = 0.5f * yr; fhi[m] = -0.5f * yi; }
 		}
 		/* k = 256 pairs with itself: X[256] = conj(Z[256]) (lane 0, reg 4) */
-		const float s256 = 2.0f * __fsqrt_rn(re[4] * re[4] + im[4] * im[4]) * spec_scale;
+		const float s256 = 2.0f * __builtin_amdgcn_sqrtf(re[4] * re[4] + im[4] * im[4]);
 
 		ED_STAMP(6)
-		/* ---- 4. spectrum to LDS (floats 576..1091 of the wave buffer: disjoint from Pz; S[513..515] hold
-		 *         finite leftovers of the transposes and only ever meet zero weights) */
-		float *S = xbuf + 576;
+		/* ---- 4. spectrum to LDS; S[513..515] were zeroed before the loop and only ever meet zero weights */
+		float *S = xbuf + ED_S_OFF; /* disjoint from the transpose slots 0..525 */
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 		{
-			S[lane + 64 * m] = slo[m];
-			S[512 - lane - 64 * m] = shi[m];
+			S[k0 + 64 * m] = slo[m];
+			S[512 - k0 - 64 * m] = shi[m];
 		}
 		if (lane == 0) S[256] = s256;
 		if (STAGES)
@@ -279,8 +410,8 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 #pragma unroll
 				for (int m = 0; m < 4; m++)
 				{
-					F[lane + 64 * m] = make_float2(flr[m], fli[m]);
-					F[512 - lane - 64 * m] = make_float2(fhr[m], fhi[m]);
+					F[k0 + 64 * m] = make_float2(flr[m], fli[m]);
+					F[512 - k0 - 64 * m] = make_float2(fhr[m], fhi[m]);
 				}
 				if (lane == 0) F[256] = make_float2(re[4], -im[4]);
 			}
@@ -288,47 +419,54 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		ed_wave_sync();
 		if (STAGES && args.spec)
 		{
-			for (int k = lane; k < 513; k += 64) args.spec[(int64_t)f * 513 + k] = S[k];
+			for (int k = lane; k < 513; k += 64) args.spec[(int64_t)f * 513 + k] = S[k] * spec_scale;
 		}
 
 		ED_STAMP(7)
-		/* ---- 5. mel filterbank: lane (band, half) walks its taps a quad at a time */
-		const float4 *S4 = reinterpret_cast<const float4 *>(S) + mel_start4;
-		float acc0 = 0.0f, acc1 = 0.0f;
-		for (int t = 0; t < T4; t++)
+		/* ---- 5. mel filterbank, balanced: lane (b = lane&15, r = lane>>4) sums quarter r of the narrow band b
+		 *         and of the wide band 31-b; all quad reads of a part are issued before the first use */
+		const float4 *S4 = reinterpret_cast<const float4 *>(S);
+		float alo0 = 0.0f, alo1 = 0.0f, ahi0 = 0.0f, ahi1 = 0.0f;
+#pragma unroll
+		for (int t = 0; t < NLO; t++)
 		{
-			const float4 s = S4[t], w = melw4[t * 64 + lane];
-			acc0 = fmaf(s.x, w.x, acc0);
-			acc1 = fmaf(s.y, w.y, acc1);
-			acc0 = fmaf(s.z, w.z, acc0);
-			acc1 = fmaf(s.w, w.w, acc1);
+			const float4 s = S4[mel_slo4 + t], w = melw4[t * 64 + lane];
+			alo0 = fmaf(s.x, w.x, alo0); alo1 = fmaf(s.y, w.y, alo1);
+			alo0 = fmaf(s.z, w.z, alo0); alo1 = fmaf(s.w, w.w, alo1);
 		}
-		const float acc = acc0 + acc1;
-		float e = acc + __shfl_xor(acc, 32);
-		float lm = do_log ? logf(e + log_offset) : e;
-		if (STAGES && lane < 32)
+#pragma unroll
+		for (int t = 0; t < NHI; t++)
 		{
-			if (args.mel) args.mel[(int64_t)f * 32 + lane] = e;
-			if (args.logmel) args.logmel[(int64_t)f * 32 + lane] = lm;
+			/* at most three quad pairs (24 registers) in flight: bounds the register footprint of this stage */
+			if (t % 3 == 0) __builtin_amdgcn_sched_barrier(0);
+			const float4 s = S4[mel_shi4 + t], w = melw4[(NLO + t) * 64 + lane];
+			ahi0 = fmaf(s.x, w.x, ahi0); ahi1 = fmaf(s.y, w.y, ahi1);
+			ahi0 = fmaf(s.z, w.z, ahi0); ahi1 = fmaf(s.w, w.w, ahi1);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		/* the four quarters live in the four 16-lane rows: sum them with VALU row swaps (no LDS trip) */
+		const float elo = ed_sum_rows(alo0 + alo1), ehi = ed_sum_rows(ahi0 + ahi1);
+		const float llo = do_log ? __logf(elo + log_offset) : elo; /* band b    */
+		const float lhi = do_log ? __logf(ehi + log_offset) : ehi; /* band 31-b */
+		if (STAGES && lane < 16)
+		{
+			if (args.mel) { args.mel[(int64_t)f * 32 + lane] = elo; args.mel[(int64_t)f * 32 + 31 - lane] = ehi; }
+			if (args.logmel) { args.logmel[(int64_t)f * 32 + lane] = llo; args.logmel[(int64_t)f * 32 + 31 - lane] = lhi; }
 		}
 
 		ED_STAMP(8)
-		/* ---- 6. DCT-II: lane (c = lane&31, h) sums n = 16h..16h+15 */
-		float *Lb = xbuf + 1104; /* 32 floats, 16-B aligned */
-		if (lane < 32) Lb[lane] = lm;
+		/* ---- 6. DCT-II through cos symmetry: y[c] = sum_{n<16} D[n][c] * (L[n] + (-1)^c L[31-n]);
+		 *         lane (c = lane&31, h = lane>>5) sums n = 8h..8h+7 */
+		float *Lb = xbuf + ED_L_OFF; /* u[16] | v[16], 16-B aligned, behind the spectrum */
+		if (lane < 16) { Lb[lane] = llo + lhi; Lb[16 + lane] = llo - lhi; }
 		ed_wave_sync();
-		const float4 *L4 = reinterpret_cast<const float4 *>(Lb + 16 * (lane >> 5));
-		float d = 0.0f;
-#pragma unroll
-		for (int n4 = 0; n4 < 4; n4++)
-		{
-			const float4 v = L4[n4], w = dctl[64 * n4 + lane];
-			d = fmaf(v.x, w.x, d);
-			d = fmaf(v.y, w.y, d);
-			d = fmaf(v.z, w.z, d);
-			d = fmaf(v.w, w.w, d);
-		}
-		d += __shfl_xor(d, 32);
+		const float4 *L4 = reinterpret_cast<const float4 *>(Lb + 16 * (lane & 1) + 8 * (lane >> 5));
+		const float4 v0 = L4[0], v1 = L4[1], w0 = dctl[lane], w1 = dctl[64 + lane];
+		float d = v0.x * w0.x, d1 = v1.x * w1.x;
+		d = fmaf(v0.y, w0.y, d); d1 = fmaf(v1.y, w1.y, d1);
+		d = fmaf(v0.z, w0.z, d); d1 = fmaf(v1.z, w1.z, d1);
+		d = fmaf(v0.w, w0.w, d); d1 = fmaf(v1.w, w1.w, d1);
+		d = ed_sum_halves(d + d1);
 		ed_wave_sync(); /* Lb / S are rewritten by the next frame */
 
 		ED_STAMP(9)
@@ -352,24 +490,25 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 	}
 }
 
-static int g_mfcc_blocks_per_cu = -1;
+static int g_mfcc_blocks_per_cu[2] = {-1, -1};
 
-extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
-                              hipStream_t stream)
+template <int NLO, int NHI>
+static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
+                                hipStream_t stream, int *blocks_per_cu)
 {
-	if (args->n_frames <= 0) return 0;
-	if (args->mel_T4 < 1 || args->mel_T4 > ED_MEL_T4_MAX) return (int)hipErrorInvalidValue;
-	const size_t lds = sizeof(float) * (ED_FIXTAB_FLOATS + args->mel_T4 * 256 + ED_WPB * ED_XBUF_FLOATS);
-	if (g_mfcc_blocks_per_cu < 0)
+	const size_t lds = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED_TWTAB_FLOATS + ED_WPB * ED_XBUF_FLOATS);
+	if (*blocks_per_cu < 0)
 	{
 		/* persistent grid = exactly what is resident; sized once from the fast kernel's occupancy */
 		int nb = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ed_mfcc_kernel<false, true>, 64 * ED_WPB, lds) != hipSuccess || nb < 1)
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ed_mfcc_kernel<false, true, NLO, NHI>, 64 * ED_WPB, lds) != hipSuccess || nb < 1)
 			nb = 1;
-		g_mfcc_blocks_per_cu = nb;
+		const char *env = getenv("ED_MFCC_BLOCKS_PER_CU"); /* tuning knob: cap the persistent grid */
+		if (env && atoi(env) > 0 && atoi(env) < nb) nb = atoi(env);
+		*blocks_per_cu = nb;
 	}
 	int64_t blocks = (args->n_frames + ED_WPB - 1) / ED_WPB;
-	const int64_t cap = (int64_t)n_cu * g_mfcc_blocks_per_cu;
+	const int64_t cap = (int64_t)n_cu * *blocks_per_cu;
 	if (blocks > cap) blocks = cap;
 	/* 4-byte loads need every frame start 4-byte aligned */
 	const bool aligned = ((reinterpret_cast<uintptr_t>(args->audio) & 3) == 0) && (args->frame_step % 2 == 0) &&
@@ -377,13 +516,25 @@ extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t
 	dim3 grid((unsigned)blocks), block(64 * ED_WPB);
 	if (stages)
 	{
-		if (aligned) hipLaunchKernelGGL((ed_mfcc_kernel<true, true>), grid, block, lds, stream, *args, dev_tab);
-		else hipLaunchKernelGGL((ed_mfcc_kernel<true, false>), grid, block, lds, stream, *args, dev_tab);
+		if (aligned) hipLaunchKernelGGL((ed_mfcc_kernel<true, true, NLO, NHI>), grid, block, lds, stream, *args, dev_tab);
+		else hipLaunchKernelGGL((ed_mfcc_kernel<true, false, NLO, NHI>), grid, block, lds, stream, *args, dev_tab);
 	}
 	else
 	{
-		if (aligned) hipLaunchKernelGGL((ed_mfcc_kernel<false, true>), grid, block, lds, stream, *args, dev_tab);
-		else hipLaunchKernelGGL((ed_mfcc_kernel<false, false>), grid, block, lds, stream, *args, dev_tab);
+		if (aligned) hipLaunchKernelGGL((ed_mfcc_kernel<false, true, NLO, NHI>), grid, block, lds, stream, *args, dev_tab);
+		else hipLaunchKernelGGL((ed_mfcc_kernel<false, false, NLO, NHI>), grid, block, lds, stream, *args, dev_tab);
 	}
 	return (int)hipGetLastError();
+}
+
+extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
+                              hipStream_t stream)
+{
+	if (args->n_frames <= 0) return 0;
+	/* the two table shapes tables.c produces */
+	if (args->mel_NLO == 2 && args->mel_NHI == 5)
+		return ed_launch_mfcc_shape<2, 5>(args, dev_tab, stages, n_cu, stream, &g_mfcc_blocks_per_cu[0]);
+	if (args->mel_NLO == ED_MEL_NLO_MAX && args->mel_NHI == ED_MEL_NHI_MAX)
+		return ed_launch_mfcc_shape<ED_MEL_NLO_MAX, ED_MEL_NHI_MAX>(args, dev_tab, stages, n_cu, stream, &g_mfcc_blocks_per_cu[1]);
+	return (int)hipErrorInvalidValue;
 }
