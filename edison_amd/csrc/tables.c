@@ -122,7 +122,10 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 		return EDISON_E_NO_IMPL;
 	}
 	/* the kernel is compiled for two table shapes: 2+5 quads per lane (the shipped filterbank) and 3+6 */
-	if (NLO <= 2 && NHI <= 5) { NLO = 2; NHI = 5; } else { NLO = ED_MEL_NLO_MAX; NHI = ED_MEL_NHI_MAX; }
+	/* EDISON_FORCE_WIDE_MEL=1 selects the larger shape regardless (lets the tests cover that kernel instance) */
+	const char *force_wide = getenv("EDISON_FORCE_WIDE_MEL");
+	if (NLO <= 2 && NHI <= 5 && !(force_wide && force_wide[0] == '1')) { NLO = 2; NHI = 5; }
+	else { NLO = ED_MEL_NLO_MAX; NHI = ED_MEL_NHI_MAX; }
 	out->mel_NLO = NLO; out->mel_NHI = NHI;
 	for (int l = 0; l < 64; l++)
 	{

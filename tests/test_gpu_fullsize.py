@@ -92,3 +92,29 @@ def test_kws_full_size_262144_utterances(ctx, oracle_mod, oracle_model):
     assert d.max() <= 1 and (d != 0).sum() <= 3
     counts = np.bincount(am.cpu().numpy(), minlength=10)
     print("class histogram over 262144 utterances:", counts.tolist())
+
+
+def test_mfcc_full_size_scaling_property(ctx):
+    """Variant B without the log is homogeneous: every stage (FFT, |.|, mel dot, DCT) is linear or a magnitude, so
+    doubling the samples doubles every coefficient -- and in binary floating point a factor 2 is exact at every
+    step, so the two launches must agree BIT FOR BIT. Independent of the oracle, at the full 65 536-frame size."""
+    import torch
+    from edison_amd import _lib
+    dev = torch.device("cuda", ctx.device)
+    ctx.use_torch_stream()
+    N = 65536
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    x = (torch.randn((N, 1024), generator=g, device=dev) * 2500.0).clamp_(-16000, 16000).to(torch.int16)
+    a = torch.empty((N, 32), dtype=torch.float32, device=dev)
+    b = torch.empty((N, 32), dtype=torch.float32, device=dev)
+    ctx.mfcc_t(x, N, 1024, _lib.MFCC_B, 32, out=a)
+    ctx.mfcc_t(x * 2, N, 1024, _lib.MFCC_B, 32, out=b)
+    torch.cuda.synchronize()
+    assert torch.equal(b, a * 2)
+    assert torch.isfinite(a).all() and float(a.abs().max()) > 10.0
+    # silence in, zeros out (no log, no offset)
+    z = torch.zeros((4096, 1024), dtype=torch.int16, device=dev)
+    ctx.mfcc_t(z, 4096, 1024, _lib.MFCC_B, 32, out=a[:4096])
+    torch.cuda.synchronize()
+    assert float(a[:4096].abs().max()) == 0.0

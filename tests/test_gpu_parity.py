@@ -86,6 +86,33 @@ def test_mfcc_overlap_unaligned_ncoef_log(ctx, oracle_mod, mfcc_golden):
     _close(got, mfcc_golden["Blog_mfcc_edison"], "A")
 
 
+def test_mfcc_other_filterbanks_and_wide_tables(built_lib, oracle_mod, mfcc_golden, monkeypatch):
+    """gen_mel_weight_matrix takes the band edges and the sample rate as arguments (mfcc_utils.py:36); the device
+    tap tables are rebuilt by edison_mfcc_configure. Also runs the shipped filterbank through the kernel instance
+    compiled for the larger (3+6 quads per lane) table shape, which the shipped edges never select on their own."""
+    from edison_amd import _lib
+    from edison_amd.context import Context
+    x = np.concatenate([mfcc_golden["in_edison"], mfcc_golden["in_noise"]])
+    c = Context(0)
+    try:
+        for fs, lo, hi in ((16000, 20.0, 8000.0), (16000, 300.0, 3400.0), (8000, 80.0, 3800.0), (44100, 80.0, 7600.0)):
+            c.configure_mfcc(fs, lo, hi)
+            for variant, ov in (("A", 0), ("B", 1)):
+                got = c.mfcc(x, variant=_variant(variant), n_coef=32)
+                ref = oracle_mod.mfcc(x, ov, sample_rate=fs, lower_edge_hertz=lo, upper_edge_hertz=hi, n_threads=4)
+                _close(got, ref, variant)
+    finally:
+        c.close()
+    monkeypatch.setenv("EDISON_FORCE_WIDE_MEL", "1")
+    c = Context(0)
+    try:
+        for variant in ("A", "B"):
+            got = c.mfcc(mfcc_golden["in_edison"], variant=_variant(variant), n_coef=32)
+            _close(got, mfcc_golden["%s_mfcc_edison" % variant], variant)
+    finally:
+        c.close()
+
+
 def test_mfcc_empty_and_ragged(ctx, built_lib):
     from edison_amd import _lib
     assert ctx.mfcc(np.zeros(0, np.int16)).shape == (0, 32)
@@ -292,3 +319,24 @@ def test_cli_entry_points(ctx, kws_golden, mfcc_golden, tmp_path, capsys):
     out = capsys.readouterr().out
     assert "edison" in out.splitlines()[-2]
     assert cli.main(["main.py", "kws", "mcu", "frame", wav]) == 0
+
+
+def test_c_program_links_against_the_abi(built_lib, ctx, kws_golden, tmp_path):
+    """A plain C translation unit written with the reference's own function names builds against include/edison_hip.h,
+    links libedison_hip.so and classifies the reference wav (examples/host_kws.c)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler on this box")
+    exe = str(tmp_path / "host_kws")
+    libdir = os.path.join(root, "edison_amd", "csrc")
+    subprocess.check_call([cc, "-O1", "-Wall", os.path.join(root, "examples", "host_kws.c"), "-I", os.path.join(root, "include"),
+                           "-L", libdir, "-ledison_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    pcm = str(tmp_path / "edison.pcm")
+    kws_golden["kws_zero_audio"].astype("<i2").tofile(pcm)
+    out = subprocess.run([exe, pcm], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "firmware-style: edison" in out.stdout and "batched:        edison" in out.stdout
