@@ -46,6 +46,27 @@ int oracle_mfcc(const int16_t *x, int64_t n_frames, int frame_len, int64_t frame
 void oracle_net_input(const double *mfcc, int64_t n_rows, int stride, int n_coef, double scale,
                       double clip_lo, double clip_hi, int8_t *out);
 
+/* ---- MFCC variant C: the firmware's Q15 pipeline (mfcc_q15_ref.c; tables regenerated, see its header) ---- */
+
+typedef struct oracle_q15_tables oracle_q15_tables_t;
+
+/* tw_mode / rc_mode: float -> Q15 conversion of the CMSIS twiddle / real-FFT split tables (0 floor, 1 round).
+ * The mel tables follow audio/edison/mfcc/mfcc_on_mcu.py:26-145. num_mel_bins must be 32. */
+oracle_q15_tables_t *oracle_q15_tables_new(int tw_mode, int rc_mode, int num_mel_bins, double sample_rate,
+                                           double lower_edge_hertz, double upper_edge_hertz, int mel_mtx_scale);
+void oracle_q15_tables_free(oracle_q15_tables_t *t);
+/* copies out (each pointer may be NULL): tw1024[1536], tw16[24], rfa[32], rfb[32], mel_coef[<=2048],
+ * mel_start[32], mel_count[32]; returns the number of compact mel coefficients */
+int oracle_q15_tables_get(const oracle_q15_tables_t *t, int16_t *tw1024, int16_t *tw16, int16_t *rfa, int16_t *rfb,
+                          int16_t *mel_coef, int16_t *mel_start, int16_t *mel_count);
+/* audioCalcMFCCs per frame (firmware/src/audioprocessing.c:116-215). Outputs (fft/spec/mel may be NULL):
+ * fft [n][2048] (re,im of X[0..1023] in natural order), spec [n][513], mel [n][32], mfcc [n][32], all int16. */
+int oracle_mfcc_q15(const oracle_q15_tables_t *t, const int16_t *x, int64_t n_frames, int64_t frame_step,
+                    int mel_mtx_scale, int16_t *fft, int16_t *spec, int16_t *mel, int16_t *mfcc, int n_threads);
+/* mfccToNetInput, NNoM branch (firmware/src/app.c:686-694) */
+void oracle_net_input_q15(const int16_t *mfcc, int64_t n_rows, int stride, int n_coef, int scale, int clip_lo,
+                          int clip_hi, int8_t *out);
+
 /* ---- int8 CNN (NNoM/CMSIS-NN arithmetic) -------------------------------------------------------- */
 
 #define ORACLE_L_CONV 1

@@ -35,7 +35,7 @@ def build(force=False):
     """Compile the restatement (always possible: gcc only) and, when the reference is mounted, the reference."""
     if force or not os.path.exists(PORT_SO) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(PORT_SO)
-            for f in ("mfcc_ref.c", "kws_cnn_ref.c", "oracle.h")):
+            for f in ("mfcc_ref.c", "mfcc_q15_ref.c", "kws_cnn_ref.c", "oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "-B", "port"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/firmware") and (force or not os.path.exists(REF_SO)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -74,6 +74,19 @@ def port():
                                      ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_q15_tables_new.restype = ctypes.c_void_p
+        L.oracle_q15_tables_new.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                            ctypes.c_double, ctypes.c_double, ctypes.c_int]
+        L.oracle_q15_tables_free.restype = None
+        L.oracle_q15_tables_free.argtypes = [ctypes.c_void_p]
+        L.oracle_q15_tables_get.restype = ctypes.c_int
+        L.oracle_q15_tables_get.argtypes = [ctypes.c_void_p] * 8
+        L.oracle_mfcc_q15.restype = ctypes.c_int
+        L.oracle_mfcc_q15.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.oracle_net_input_q15.restype = None
+        L.oracle_net_input_q15.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         _port = L
     return _port
 
@@ -145,6 +158,74 @@ def net_input(mfcc_rows, n_coef=NUM_MFCC, scale=1.0, clip_lo=-128.0, clip_hi=127
     n, stride = m.shape
     out = np.zeros((n, n_coef), np.int8)
     port().oracle_net_input(_p(m), n, stride, n_coef, float(scale), float(clip_lo), float(clip_hi), _p(out))
+    return out
+
+
+# ------------------------------------------------------------------ MFCC variant C (firmware Q15)
+
+# Float -> Q15 conversion of the regenerated CMSIS tables that reproduces the reference's published
+# host-vs-board statistics (README.md:121-139; tests/golden/gen_fixtures_q15.py): twiddles floor, split tables round.
+Q15_TW_MODE, Q15_RC_MODE = 0, 1
+
+
+class Q15Tables:
+    def __init__(self, tw_mode=Q15_TW_MODE, rc_mode=Q15_RC_MODE, sample_rate=FS, lower_edge_hertz=MEL_LO,
+                 upper_edge_hertz=MEL_HI, mel_mtx_scale=MEL_SCALE):
+        self.scale = int(mel_mtx_scale)
+        self.h = port().oracle_q15_tables_new(tw_mode, rc_mode, NUM_MEL, float(sample_rate), float(lower_edge_hertz),
+                                              float(upper_edge_hertz), self.scale)
+        if not self.h:
+            raise RuntimeError("oracle_q15_tables_new failed")
+
+    def arrays(self):
+        tw1024, tw16 = np.zeros(1536, np.int16), np.zeros(24, np.int16)
+        rfa, rfb = np.zeros(32, np.int16), np.zeros(32, np.int16)
+        coef, start, count = np.zeros(2048, np.int16), np.zeros(32, np.int16), np.zeros(32, np.int16)
+        n = port().oracle_q15_tables_get(self.h, _p(tw1024), _p(tw16), _p(rfa), _p(rfb), _p(coef), _p(start), _p(count))
+        return dict(tw1024=tw1024, tw16=tw16, rfa=rfa, rfb=rfb, mel_coef=coef[:n].copy(), mel_start=start,
+                    mel_count=count)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            port().oracle_q15_tables_free(self.h)
+            self.h = None
+
+
+_q15_default = None
+
+
+def mfcc_q15(x, n_frames=None, frame_step=FRAME_LEN, stages=False, n_threads=1, tables=None):
+    """audioCalcMFCCs on every frame of the int16 stream x -> int16 [n_frames, 32] (plus stage arrays)."""
+    global _q15_default
+    if tables is None:
+        if _q15_default is None:
+            _q15_default = Q15Tables()
+        tables = _q15_default
+    x = np.ascontiguousarray(x, dtype=np.int16).ravel()
+    if n_frames is None:
+        n_frames = 1 + (x.shape[0] - FRAME_LEN) // frame_step if x.shape[0] >= FRAME_LEN else 0
+    out = np.zeros((max(n_frames, 0), NUM_MEL), np.int16)
+    if n_frames <= 0:
+        return (out, dict(fft=np.zeros((0, 1024, 2), np.int16), spectrogram=np.zeros((0, 513), np.int16),
+                          mel_spectrogram=np.zeros((0, 32), np.int16))) if stages else out
+    assert (n_frames - 1) * frame_step + FRAME_LEN <= x.shape[0]
+    fft = np.zeros((n_frames, 1024, 2), np.int16) if stages else None
+    sp = np.zeros((n_frames, 513), np.int16) if stages else None
+    me = np.zeros((n_frames, NUM_MEL), np.int16) if stages else None
+    r = port().oracle_mfcc_q15(tables.h, _p(x), n_frames, frame_step, tables.scale, _p(fft), _p(sp), _p(me), _p(out),
+                               int(n_threads))
+    if r != 0:
+        raise RuntimeError("oracle_mfcc_q15 failed: %d" % r)
+    if stages:
+        return out, dict(fft=fft, spectrogram=sp, mel_spectrogram=me)
+    return out
+
+
+def net_input_q15(mfcc_rows, n_coef=NUM_MFCC, scale=1, clip_lo=-128, clip_hi=127):
+    m = np.ascontiguousarray(mfcc_rows, dtype=np.int16)
+    n, stride = m.shape
+    out = np.zeros((n, n_coef), np.int8)
+    port().oracle_net_input_q15(_p(m), n, stride, n_coef, scale, clip_lo, clip_hi, _p(out))
     return out
 
 

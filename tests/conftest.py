@@ -30,6 +30,12 @@ def kws_golden():
 
 
 @pytest.fixture(scope="session")
+def q15_golden():
+    """Variant C (firmware Q15 MFCC): tests/golden/gen_fixtures_q15.py"""
+    return np.load(os.path.join(GOLDEN, "mfccq15_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def oracle_mod():
     from oracle import oracle
     oracle.build()

@@ -91,6 +91,59 @@ def test_oracle_net_input_rounding(oracle_mod, kws_golden):
     assert oracle_mod.net_input(m).tolist() == [[0, 2, 2, 0, -2, 126, 127, 127, -128, -128, -128, 0, 0]]
 
 
+def _readme_compare(a, b):
+    """compare() of the reference's kws_on_mcu.py:159-168 on float32 arrays, formatted the way it prints."""
+    dev = 100.0 * (1.0 - (b.ravel() + 1e-9) / (a.ravel() + 1e-9))
+    return ["%.3f" % dev.max(), "%.3f" % dev.min(), "%.3f" % np.mean(dev),
+            "%.3f" % np.sqrt(np.mean((b.ravel() - a.ravel()) ** 2)), "%.3f" % (b.max() / a.max()),
+            "%.3f" % np.corrcoef(a.ravel(), b.ravel())[0, 1]]
+
+
+def test_oracle_q15_reproduces_published_board_comparison(oracle_mod, q15_golden):
+    """Variant C's pin: README.md:121-139 prints six statistics of (host variant B) vs (board variant C) on
+    edison_16k_16b.wav. host32 in the fixture is the reference's own mfcc_mcu output; the Q15 oracle must give
+    every printed digit, and only with the frozen table conversion."""
+    host32 = q15_golden["host32_edison_edge"]
+    x = q15_golden["in_edison_edge"]
+    want = q15_golden["readme"].tolist()
+    assert want == ["5873.424", "-51588.922", "-105.840", "2.036", "0.959", "0.997"]
+    got = oracle_mod.mfcc_q15(x)[:, :13].astype(np.float32)
+    assert _readme_compare(host32, got) == want
+    for tw, rc in ((0, 0), (1, 0), (1, 1)):
+        other = oracle_mod.mfcc_q15(x, tables=oracle_mod.Q15Tables(tw_mode=tw, rc_mode=rc))[:, :13].astype(np.float32)
+        assert _readme_compare(host32, other) != want
+
+
+def test_oracle_q15_tables_and_golden(oracle_mod, q15_golden, mfcc_golden):
+    arr = oracle_mod.Q15Tables().arrays()
+    for k in ("mel_coef", "mel_start", "mel_count", "tw1024", "tw16", "rfa", "rfb"):
+        assert np.array_equal(arr[k], q15_golden["tbl_" + k]), k
+    # spot values of the regenerated CMSIS tables: cos/sin(pi/8) as the top halfword of their Q31 value
+    assert arr["tw16"][:4].tolist() == [0x7FFF, 0, 0x7641, 0x30FB]
+    assert arr["rfa"][:2].tolist() == [0x4000, -0x4000] and arr["rfb"][:2].tolist() == [0x4000, 0x4000]
+    for name in ("edison", "hey", "two_tone", "noise", "quiet", "extremes"):
+        m, st = oracle_mod.mfcc_q15(mfcc_golden["in_" + name], stages=True, n_threads=2)
+        assert np.array_equal(m, q15_golden["C_mfcc_" + name])
+        if name in ("edison", "two_tone", "extremes"):
+            assert np.array_equal(st["spectrogram"], q15_golden["C_spec_" + name])
+            assert np.array_equal(st["mel_spectrogram"], q15_golden["C_mel_" + name])
+    assert np.array_equal(oracle_mod.mfcc_q15(mfcc_golden["in_noise"][:4096], frame_step=512),
+                          q15_golden["C_mfcc_overlap512"])
+    assert np.array_equal(oracle_mod.net_input_q15(q15_golden["C_mfcc_edison_edge"]), q15_golden["C_feat_edison_edge"])
+
+
+def test_oracle_q15_is_a_scaled_fft(oracle_mod, mfcc_golden):
+    """Independent sanity of the restated radix-4 stages: the five stages scale by 1/8, 1/4, 1/4, 1/4, 1/2, so the
+    Q15 spectrum must sit within a few LSB of FFT(x)/1024, and the magnitude within a few LSB of |.|."""
+    x = mfcc_golden["in_noise"][:8 * 1024]
+    _, st = oracle_mod.mfcc_q15(x, stages=True)
+    f = np.fft.fft(x.reshape(8, 1024).astype(np.float64)) / 1024.0
+    got = st["fft"][..., 0].astype(np.float64) + 1j * st["fft"][..., 1]
+    assert np.abs(got - f).max() < 8.0          # five truncating stages: a few LSB of downward bias
+    assert np.abs(st["spectrogram"] - np.abs(got[:, :513])).max() <= 1.0
+    assert oracle_mod.mfcc_q15(np.zeros(2048, np.int16)).tolist() == [[0] * 32] * 2
+
+
 def test_softmax_saturation_cases(oracle_mod, oracle_model, cnn_golden):
     """arm_softmax_q7 portable branch: the class more than 136 below the maximum comes out 0."""
     i = 1  # all +127 input: logits 89 and -55
