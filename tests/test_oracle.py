@@ -141,7 +141,7 @@ def test_oracle_q15_is_a_scaled_fft(oracle_mod, mfcc_golden):
     got = st["fft"][..., 0].astype(np.float64) + 1j * st["fft"][..., 1]
     assert np.abs(got - f).max() < 8.0          # five truncating stages: a few LSB of downward bias
     # sqrt of a Q31 fraction, top halfword: sqrt(s / 2^31) * 2^15 = sqrt(s) / sqrt(2) -- the 1/sqrt2 of variant B
-    assert np.abs(st["spectrogram"] - np.abs(got[:, :513]) / np.sqrt(2.0)).max() <= 1.0
+    assert np.abs(st["spectrogram"] - np.abs(got[:, :513]) / np.sqrt(2.0)).max() < 1.001
     assert oracle_mod.mfcc_q15(np.zeros(2048, np.int16)).tolist() == [[0] * 32] * 2
 
 
