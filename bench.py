@@ -176,6 +176,15 @@ def cpu_baseline(n_threads):
     dt = (time.perf_counter() - t0) / reps
     res["mfcc"] = dict(value=n / dt, unit="frames/s", cores=n_threads, kind="port",
                        sample="%d frames x %d passes, oracle/mfcc_ref.c variant B float64, %d OpenMP threads" % (n, reps, n_threads))
+    # MFCC variant C (Q15), ~4 s
+    oracle.mfcc_q15(x[:4096 * 1024], n_threads=n_threads)
+    reps, t0 = 0, time.perf_counter()
+    while reps < 1 or (time.perf_counter() - t0 < 4.0 and reps < 200):
+        oracle.mfcc_q15(x, n_threads=n_threads)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    res["q15"] = dict(value=n / dt, unit="frames/s", cores=n_threads, kind="port",
+                      sample="%d frames x %d passes, oracle/mfcc_q15_ref.c, %d OpenMP threads" % (n, reps, n_threads))
     # full KWS: MFCC B + int8 CNN restatement, all threads
     nu = 2048
     a = np.clip(rng.normal(0, 3000, nu * 31744), -32768, 32767).astype(np.int16)
@@ -212,6 +221,7 @@ def main():
     ap.add_argument("--skip-kws", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-stream", action="store_true")
+    ap.add_argument("--skip-q15", action="store_true")
     args = ap.parse_args()
 
     from edison_amd import parallel, _lib
@@ -244,6 +254,24 @@ def main():
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, bytes_per_unit=MFCC_BYTES_PER_FRAME,
                     units_per_launch=nf, kernel_ms=round(ev_ms, 4))
     checksum = float(out.double().sum().item())
+
+    # ------------------------------------------------------------------ variant C: the firmware's Q15 MFCC, same batch
+    q15 = None
+    if not args.skip_q15:
+        out16 = torch.empty((nf, 13), dtype=torch.int16, device=dev)
+
+        def q15_step(i):
+            ctx.mfcc_q15_t(bufs[i % len(bufs)], nf, 1024, 13, out=out16)
+        q_ms, qev_ms = timed_region(q15_step, args.steps, args.warmup, world)
+        qbytes = 2048 + 13 * 2
+        qach = qbytes * nf / (qev_ms * 1e-3) / 1e9
+        q15 = dict(metric="MFCC frames/sec, variant C (firmware Q15 arithmetic, bit-exact)", unit="frames/s",
+                   value=round(world * nf / (q_ms * 1e-3), 1), ms_per_step=round(q_ms, 4), dtype="q15/q31",
+                   config=dict(workload="mfcc_batch_%dx1024_int16_per_gpu_variantC_13coef" % nf, global_batch=world * nf),
+                   roofline=dict(bound="hbm", kernel="ed_mfcc_q15_kernel<false>", achieved=round(qach, 1), peak=HBM_PEAK_GBS,
+                                 unit="GB/s", frac=round(qach / HBM_PEAK_GBS, 4), traffic=None, bytes_per_unit=qbytes,
+                                 units_per_launch=nf, kernel_ms=round(qev_ms, 4)),
+                   checksum=int(out16.to(torch.int64).sum().item()))
     del bufs
     # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
     # this command, FETCH_SIZE doubled as the gfx950 guide prescribes); only valid for the default batch size
@@ -303,6 +331,10 @@ def main():
                     config=dict(workload="mfcc_batch_%dx1024_int16_per_gpu_variantB_13coef" % nf, global_batch=world * nf,
                                 frame_len=1024, parallelism="dp%d" % world, rotate_buffers=args.rotate),
                     roofline=roofline, device=info["name"], checksum=checksum)
+        if q15 is not None:
+            line["mfcc_q15"] = q15
+            if cpu is not None and "q15" in cpu:
+                q15["cpu_baseline"] = cpu["q15"]
         if kws is not None:
             line["kws"] = kws
         if streaming is not None:

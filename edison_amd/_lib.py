@@ -13,7 +13,7 @@ DEFAULT_MODEL = os.path.join(_HERE, "data", "kws_nnom.ednn")
 OK = 0
 E_ARGUMENT, E_LENGTH, E_SIZE, E_NO_MEMORY, E_MORE_TODO = -1, -2, -3, -7, -8
 E_RUNTIME, E_NO_IMPL, E_NO_DEVICE, E_NO_MODEL = -16, -17, -18, -19
-MFCC_A, MFCC_B, MFCC_USE_LOG = 0, 1, 0x100
+MFCC_A, MFCC_B, MFCC_C, MFCC_USE_LOG = 0, 1, 2, 0x100
 
 FS, FRAME_LEN, NUM_MEL, NUM_MFCC, UTT_FRAMES, NET_IN, NET_OUT = 16000, 1024, 32, 13, 31, 403, 10
 CNN_ACT_BYTES = 10420
@@ -50,6 +50,12 @@ SIGNATURES = {
     "edison_cnn_batch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "edison_cnn_layers": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "edison_kws_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_mfcc_q15_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "edison_mfcc_q15_stages_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_kws_batch_q15_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_mfcc_q15_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "edison_mfcc_q15_stages": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_kws_batch_q15": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "edison_stream_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "edison_stream_destroy": (None, [c_void_p]),
     "edison_stream_reset": (c_int, [c_void_p]),
@@ -84,6 +90,29 @@ class EdisonError(RuntimeError):
         self.code = code
 
 
+def _share_torch_hip_runtime():
+    """A PyTorch-ROCm wheel bundles its own libamdhip64.so.7. Two HIP runtimes in one process cannot both own the
+    GPU (whichever comes second reports "No HIP GPUs are available"), so when torch is installed but not imported
+    yet, map ITS runtime first: libedison_hip.so's DT_NEEDED then binds to it by soname and a later `import torch`
+    finds it already loaded. No torch import, no torch dependency; EDISON_NO_TORCH_HIP=1 skips this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("EDISON_NO_TORCH_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libedison_hip.so (once). Raises if it has not been built: there is nothing to fall back to."""
     global _lib
@@ -92,6 +121,7 @@ def lib():
             raise FileNotFoundError(
                 "%s is missing -- build it with `python -m edison_amd.build` (hipcc, gfx950). "
                 "edison_amd has no CPU implementation." % LIB_PATH)
+        _share_torch_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header and library out of sync

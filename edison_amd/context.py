@@ -137,8 +137,37 @@ class Context:
             off += sz
         return out
 
-    def kws(self, audio, n_utt=None, utt_stride=32000):
-        """audio: int16, utterance u starts at u*utt_stride and uses 31*1024 samples."""
+    def _frames(self, x, n_frames, frame_step):
+        if n_frames is None:
+            n_frames = 1 + (x.shape[0] - FRAME_LEN) // frame_step if x.shape[0] >= FRAME_LEN else 0
+        if n_frames > 0 and (n_frames - 1) * frame_step + FRAME_LEN > x.shape[0]:
+            raise ValueError("audio too short for %d frames" % n_frames)
+        return max(n_frames, 0)
+
+    def mfcc_q15(self, audio, n_frames=None, frame_step=FRAME_LEN, n_coef=NUM_MEL, want_feat=False):
+        """Variant C, the firmware's audioCalcMFCCs: int16 [n_frames, n_coef] (and the NNoM int8 net input)."""
+        x = np.ascontiguousarray(audio, dtype=np.int16).ravel()
+        n = self._frames(x, n_frames, frame_step)
+        out = np.zeros((n, n_coef), np.int16)
+        feat = np.zeros((n, n_coef), np.int8) if want_feat else None
+        self._check(self._L.edison_mfcc_q15_batch(self._h, _np_ptr(x), n, frame_step, n_coef, _np_ptr(out), _np_ptr(feat)))
+        return (out, feat) if want_feat else out
+
+    def mfcc_q15_stages(self, audio, n_frames=None, frame_step=FRAME_LEN):
+        """What the firmware's audioDumpToHost sends: FFT, spectrum, mel spectrum and DCT output, all int16."""
+        x = np.ascontiguousarray(audio, dtype=np.int16).ravel()
+        n = self._frames(x, n_frames, frame_step)
+        fft = np.zeros((n, 513, 2), np.int16)
+        spec = np.zeros((n, 513), np.int16)
+        mel = np.zeros((n, 32), np.int16)
+        mfcc = np.zeros((n, 32), np.int16)
+        self._check(self._L.edison_mfcc_q15_stages(self._h, _np_ptr(x), n, frame_step, _np_ptr(fft), _np_ptr(spec),
+                                                   _np_ptr(mel), _np_ptr(mfcc)))
+        return dict(fft=fft, spectrogram=spec, mel_spectrogram=mel, mfcc=mfcc)
+
+    def kws(self, audio, n_utt=None, utt_stride=32000, q15=False):
+        """audio: int16, utterance u starts at u*utt_stride and uses 31*1024 samples. q15: the firmware's own
+        features (variant C) instead of the host float model (variant B)."""
         x = np.ascontiguousarray(audio, dtype=np.int16).ravel()
         used = UTT_FRAMES * FRAME_LEN
         if n_utt is None:
@@ -149,8 +178,8 @@ class Context:
         logits = np.zeros((n_utt, NET_OUT), np.int8)
         soft = np.zeros((n_utt, NET_OUT), np.int8)
         am = np.zeros(n_utt, np.int32)
-        self._check(self._L.edison_kws_batch(self._h, _np_ptr(x), n_utt, utt_stride, _np_ptr(feat), _np_ptr(logits),
-                                             _np_ptr(soft), _np_ptr(am)))
+        fn = self._L.edison_kws_batch_q15 if q15 else self._L.edison_kws_batch
+        self._check(fn(self._h, _np_ptr(x), n_utt, utt_stride, _np_ptr(feat), _np_ptr(logits), _np_ptr(soft), _np_ptr(am)))
         return dict(feat=feat, logits=logits, softmax=soft, argmax=am)
 
     # ------------------------------------------------------------------ device (torch tensor) entry points
@@ -165,9 +194,15 @@ class Context:
         self._check(self._L.edison_cnn_batch_dev(self._h, _t_ptr(feat), int(n_utt), _t_ptr(logits), _t_ptr(softmax),
                                                  _t_ptr(argmax)))
 
-    def kws_t(self, audio, n_utt, utt_stride, feat=None, logits=None, softmax=None, argmax=None):
-        self._check(self._L.edison_kws_batch_dev(self._h, _t_ptr(audio), int(n_utt), int(utt_stride), _t_ptr(feat),
-                                                 _t_ptr(logits), _t_ptr(softmax), _t_ptr(argmax)))
+    def kws_t(self, audio, n_utt, utt_stride, feat=None, logits=None, softmax=None, argmax=None, q15=False):
+        fn = self._L.edison_kws_batch_q15_dev if q15 else self._L.edison_kws_batch_dev
+        self._check(fn(self._h, _t_ptr(audio), int(n_utt), int(utt_stride), _t_ptr(feat), _t_ptr(logits),
+                       _t_ptr(softmax), _t_ptr(argmax)))
+
+    def mfcc_q15_t(self, audio, n_frames, frame_step=FRAME_LEN, n_coef=NUM_MFCC, out=None, feat=None):
+        """audio: int16 CUDA tensor; out: int16 [n_frames, n_coef] CUDA tensor or None; feat: int8 or None."""
+        self._check(self._L.edison_mfcc_q15_batch_dev(self._h, _t_ptr(audio), int(n_frames), int(frame_step), int(n_coef),
+                                                      _t_ptr(out), _t_ptr(feat)))
 
 
 _default = None

@@ -19,8 +19,13 @@ extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const in
                                   int64_t feat_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu,
                                   hipStream_t stream);
 
+extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int stages, int n_cu,
+                                  hipStream_t stream);
+
 struct edison_ctx
 {
+	ed_q15_tables_t *d_q15; /* variant C (firmware Q15); NULL when the configured filterbank does not fit it */
+	char q15_err[160];
 	int device;
 	int n_cu;
 	size_t hbm_bytes;
@@ -59,5 +64,12 @@ static inline int ed_set_err(edison_ctx *ctx, int code, const char *msg)
 int ed_ctx_mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
                        int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
                        int stages, float *fft, float *spec, float *mel, float *logmel);
+/* Variant C: same frame addressing, int16 / float / int8 outputs and int16 stage dumps (edison_q15.hip). */
+int ed_ctx_mfcc_q15_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
+                           int64_t frame_step, int n_coef, int16_t *mfcc_i16, float *mfcc_f32, int8_t *feat, int stages,
+                           int16_t *fft, int16_t *spec, int16_t *mel);
+int ed_ctx_ensure_scratch(edison_ctx *ctx, size_t bytes);
+int ed_ctx_cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *logits, int8_t *softmax,
+                      int32_t *argmax);
 
 #endif

@@ -34,6 +34,27 @@ static int upload_tables(edison_ctx *ctx, double fs, double lo, double hi, doubl
 		free(h);
 		ED_HIP(ctx, e);
 	}
+	/* variant C: a filterbank / scale it cannot express only switches variant C off (EDISON_E_NO_IMPL on use) */
+	{
+		ed_q15_tables_t *h = (ed_q15_tables_t *)malloc(sizeof(ed_q15_tables_t));
+		if (!h) return set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed");
+		ctx->q15_err[0] = 0;
+		int r = ed_build_q15_tables(fs, lo, hi, scale, h, ctx->q15_err, sizeof(ctx->q15_err));
+		ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (r == EDISON_OK)
+		{
+			if (!ctx->d_q15) ED_HIP(ctx, hipMalloc((void **)&ctx->d_q15, sizeof(ed_q15_tables_t)));
+			hipError_t e = hipMemcpy(ctx->d_q15, h, sizeof(ed_q15_tables_t), hipMemcpyHostToDevice);
+			free(h);
+			ED_HIP(ctx, e);
+		}
+		else
+		{
+			free(h);
+			if (r != EDISON_E_NO_IMPL) return r;
+			if (ctx->d_q15) { (void)hipFree(ctx->d_q15); ctx->d_q15 = NULL; }
+		}
+	}
 	return EDISON_OK;
 }
 
@@ -95,6 +116,7 @@ extern "C" void edison_shutdown(edison_ctx *ctx)
 	(void)hipSetDevice(ctx->device);
 	(void)hipDeviceSynchronize();
 	for (int v = 0; v < 2; v++) if (ctx->d_tab[v]) (void)hipFree(ctx->d_tab[v]);
+	if (ctx->d_q15) (void)hipFree(ctx->d_q15);
 	if (ctx->d_model) (void)hipFree(ctx->d_model);
 	if (ctx->d_model_mfma) (void)hipFree(ctx->d_model_mfma);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -258,6 +280,15 @@ static int mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, 
 {
 	const int v = variant & 0xff;
 	if (!ctx || (!audio && n_frames > 0)) return EDISON_E_ARGUMENT;
+	if (v == EDISON_MFCC_C)
+	{
+		/* the firmware's integers through the float interface: mfcc = (float)int16 like the Cube branch of
+		 * mfccToNetInput (app.c:680-683), feat = its NNoM branch (app.c:686-694, NNOM_INPUT_SCALE 1) */
+		if ((variant & EDISON_MFCC_USE_LOG) || stages || feat_scale != 1.0f)
+			return set_err(ctx, EDISON_E_NO_IMPL, "variant C: no log, feat_scale 1, stages through edison_mfcc_q15_stages");
+		return ed_ctx_mfcc_q15_launch(ctx, audio, n_frames, fpg, group_stride, frame_step, n_coef, NULL, mfcc, feat, 0,
+		                              NULL, NULL, NULL);
+	}
 	if (v != EDISON_MFCC_A && v != EDISON_MFCC_B) return set_err(ctx, EDISON_E_ARGUMENT, "unknown MFCC variant");
 	if (n_coef < 1 || n_coef > EDISON_NUM_MEL) return set_err(ctx, EDISON_E_ARGUMENT, "n_coef must be 1..32");
 	if (n_frames < 0 || n_frames >= ((int64_t)1 << 31) || frame_step < 0 || fpg < 1)
@@ -323,8 +354,14 @@ extern "C" int edison_cnn_layers_dev(edison_ctx *ctx, const int8_t *feat, int64_
 	return cnn_launch(ctx, feat, n_utt, NULL, NULL, NULL, acts);
 }
 
-extern "C" int edison_kws_batch_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride,
-                                    int8_t *feat, int8_t *logits, int8_t *softmax, int32_t *argmax)
+int ed_ctx_ensure_scratch(edison_ctx *ctx, size_t bytes) { return ensure_scratch(ctx, bytes); }
+int ed_ctx_cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *logits, int8_t *softmax, int32_t *argmax)
+{
+	return cnn_launch(ctx, feat, n_utt, logits, softmax, argmax, NULL);
+}
+
+static int kws_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride, int variant, int8_t *feat,
+                   int8_t *logits, int8_t *softmax, int32_t *argmax)
 {
 	if (!ctx || n_utt < 0 || (!audio && n_utt > 0)) return EDISON_E_ARGUMENT;
 	if (!ctx->have_model) return set_err(ctx, EDISON_E_NO_MODEL, "no CNN model loaded (edison_model_load)");
@@ -338,11 +375,23 @@ extern "C" int edison_kws_batch_dev(edison_ctx *ctx, const int16_t *audio, int64
 		if (r != EDISON_OK) return r;
 		f = (int8_t *)ctx->scratch;
 	}
-	/* variant B, first 13 coefficients, scale 1 (nnom_net_input_scale, audio/config.py:41) */
+	/* first 13 coefficients, scale 1 (nnom_net_input_scale, audio/config.py:41; NNOM_INPUT_SCALE, weights.h:162) */
 	int r = mfcc_launch(ctx, audio, n_utt * EDISON_UTT_FRAMES, EDISON_UTT_FRAMES, utt_stride, EDISON_FRAME_LEN,
-	                    EDISON_MFCC_B, EDISON_NUM_MFCC, NULL, f, 1.0f, 0, NULL, NULL, NULL, NULL);
+	                    variant, EDISON_NUM_MFCC, NULL, f, 1.0f, 0, NULL, NULL, NULL, NULL);
 	if (r != EDISON_OK) return r;
 	return cnn_launch(ctx, f, n_utt, logits, softmax, argmax, NULL);
+}
+
+extern "C" int edison_kws_batch_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride,
+                                    int8_t *feat, int8_t *logits, int8_t *softmax, int32_t *argmax)
+{
+	return kws_dev(ctx, audio, n_utt, utt_stride, EDISON_MFCC_B, feat, logits, softmax, argmax);
+}
+
+extern "C" int edison_kws_batch_q15_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride,
+                                        int8_t *feat, int8_t *logits, int8_t *softmax, int32_t *argmax)
+{
+	return kws_dev(ctx, audio, n_utt, utt_stride, EDISON_MFCC_C, feat, logits, softmax, argmax);
 }
 
 /* ---------------------------------------------------------------------------------------- hot path, host  */
@@ -446,8 +495,8 @@ extern "C" int edison_cnn_layers(edison_ctx *ctx, const int8_t *feat, int64_t n_
 	return cnn_host(ctx, feat, n_utt, NULL, NULL, NULL, acts);
 }
 
-extern "C" int edison_kws_batch(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride,
-                                int8_t *feat, int8_t *logits, int8_t *softmax, int32_t *argmax)
+static int kws_host(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride, int variant, int8_t *feat,
+                    int8_t *logits, int8_t *softmax, int32_t *argmax)
 {
 	if (!ctx || n_utt < 0 || (!audio && n_utt > 0) || utt_stride < 0) return EDISON_E_ARGUMENT;
 	if (n_utt == 0) return EDISON_OK;
@@ -461,8 +510,8 @@ extern "C" int edison_kws_batch(edison_ctx *ctx, const int16_t *audio, int64_t n
 	if (softmax) ED_HIP(ctx, s.alloc(n * EDISON_NET_OUT));
 	if (argmax) ED_HIP(ctx, a.alloc(n * sizeof(int32_t)));
 	ED_UP(ctx, au.p, audio, na);
-	int r = edison_kws_batch_dev(ctx, (const int16_t *)au.p, n_utt, utt_stride, (int8_t *)f.p, (int8_t *)l.p,
-	                             (int8_t *)s.p, (int32_t *)a.p);
+	int r = kws_dev(ctx, (const int16_t *)au.p, n_utt, utt_stride, variant, (int8_t *)f.p, (int8_t *)l.p, (int8_t *)s.p,
+	                (int32_t *)a.p);
 	if (r != EDISON_OK) return r;
 	ED_DOWN(ctx, feat, f.p, n * EDISON_NET_IN);
 	ED_DOWN(ctx, logits, l.p, n * EDISON_NET_OUT);
@@ -470,4 +519,16 @@ extern "C" int edison_kws_batch(edison_ctx *ctx, const int16_t *audio, int64_t n
 	ED_DOWN(ctx, argmax, a.p, n * sizeof(int32_t));
 	ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return EDISON_OK;
+}
+
+extern "C" int edison_kws_batch(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride,
+                                int8_t *feat, int8_t *logits, int8_t *softmax, int32_t *argmax)
+{
+	return kws_host(ctx, audio, n_utt, utt_stride, EDISON_MFCC_B, feat, logits, softmax, argmax);
+}
+
+extern "C" int edison_kws_batch_q15(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride,
+                                    int8_t *feat, int8_t *logits, int8_t *softmax, int32_t *argmax)
+{
+	return kws_host(ctx, audio, n_utt, utt_stride, EDISON_MFCC_C, feat, logits, softmax, argmax);
 }

@@ -57,6 +57,41 @@ int ed_gen_mel_weight_matrix(int num_mel_bins, int num_spectrogram_bins, double 
 int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hertz, double upper_edge_hertz,
                          double mel_mtx_scale, ed_mfcc_tables_t *out, char *err, size_t err_cap);
 
+/* ------------------------------------------------------------------ MFCC variant C (firmware Q15) tables */
+#define ED_Q15_MEL_COEF_MAX 1024 /* shipped filterbank: 915 (mel_constants.h: melMtxCompact[915])              */
+
+typedef struct {
+	/* complex Q15 coefficients as the two packed operands of v_dot2_i32_i16 (see tables_q15.c):
+	 * tw*[i] = (cos, sin), tw*x[i] = (-sin, cos) of 2 pi i / N                                                */
+	uint32_t tw1024[768], tw1024x[768];
+	uint32_t tw16[12], tw16x[12];
+	uint32_t rfa[16], rfb[16]; /* real-FFT split of the DCT stage, pair 256*i of realCoefA/BQ15: (A.re,-A.im), (B.re,B.im) */
+	int32_t mel_start[32], mel_count[32], mel_off[32]; /* band m: spectrum bins [start, start+count), coefficients at off */
+	int32_t mel_coef[ED_Q15_MEL_COEF_MAX];
+	int32_t mel_scale, n_mel_coef;
+	int32_t need_nyquist; /* some band reads spectrum bin 512 */
+	int32_t pad_;
+} ed_q15_tables_t;
+
+int ed_build_q15_tables(double sample_rate, double lower_edge_hertz, double upper_edge_hertz, double mel_mtx_scale,
+                        ed_q15_tables_t *out, char *err, size_t err_cap);
+
+typedef struct {
+	const int16_t *audio;
+	int64_t n_frames;
+	int64_t frames_per_group; /* as ed_mfcc_args_t */
+	int64_t group_stride;
+	int64_t frame_step;
+	int n_coef;
+	int16_t *mfcc_i16; /* [n_frames][n_coef] or NULL: bufDctInline                                              */
+	float *mfcc_f32;   /* [n_frames][n_coef] or NULL: the same numbers as float (Cube branch of mfccToNetInput)   */
+	int8_t *feat;      /* [n_frames][n_coef] or NULL: NNoM branch of mfccToNetInput (app.c:686-694), scale 1      */
+	/* stage dumps (diagnostic kernel only): what audioDumpToHost sends (audioprocessing.c:221-231)              */
+	int16_t *fft;  /* [n][513][2] */
+	int16_t *spec; /* [n][513]    */
+	int16_t *mel;  /* [n][32]     */
+} ed_mfcc_q15_args_t;
+
 /* ------------------------------------------------------------------ int8 CNN model (kws_conv topology)   */
 /* Geometry of the one network this path accelerates (weights.h:138-161).                    */
 #define ED_IN_H 31

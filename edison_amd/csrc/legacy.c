@@ -143,32 +143,25 @@ void mfccToNetInputPush(int16_t *mfcc, uint16_t in_x, uint16_t in_y)
 }
 
 /*
- * firmware/src/audioprocessing.h:21-22. The firmware computes these 32 coefficients in Q15/Q31 integer arithmetic
- * (audioprocessing.c:116-215, "variant C"); its bit-exact restatement needs CMSIS-DSP tables that are missing from
- * the reference snapshot and is a later row of the plan. Until then this entry point keeps the CALL SURFACE --
- * caller-owned 1024-sample frame in, pointer to a callee-owned static buffer of 32 int16 out, valid until the next
- * call -- and fills it from the GPU's variant B, the reference's own float model of the Q15 path
- * (mfcc_utils.py:255-323; README.md:131-136 reports correlation 0.997 between the two), rounded to nearest.
+ * firmware/src/audioprocessing.h:21-22. Caller-owned 1024-sample frame in, pointer to a callee-owned static buffer
+ * of 32 int16 out, valid until the next call (bufDctInline, audioprocessing.c:80,210). The numbers are the
+ * firmware's own: MFCC variant C, the Q15/Q31 integer pipeline of audioprocessing.c:116-215 on the GPU
+ * (mfcc_q15_kernels.hip).
  */
-static int16_t g_mfcc_q15_out[EDISON_NUM_MEL]; /* bufDctInline (audioprocessing.c:80,210) */
+static int16_t g_mfcc_q15_out[EDISON_NUM_MEL];
 
 void audioInit(void) { (void)aiInitialize(); }
 
 void audioCalcMFCCs(int16_t *inp, int16_t **oup)
 {
-	float m[EDISON_NUM_MEL];
 	*oup = g_mfcc_q15_out;
-	if (edison_mfcc_frame(inp, EDISON_MFCC_B, m) != EDISON_OK)
+	int r = g_ctx ? EDISON_OK : aiInitialize();
+	if (r == EDISON_OK) r = edison_mfcc_q15_batch(g_ctx, inp, 1, EDISON_FRAME_LEN, EDISON_NUM_MEL, g_mfcc_q15_out, NULL);
+	if (r != EDISON_OK)
 	{
 		/* the firmware calls Error_Handler() on failure (audioprocessing.c:105,200); here: report and zero */
 		fprintf(stderr, "audioCalcMFCCs: GPU MFCC failed: %s\n", edison_last_error(g_ctx));
 		memset(g_mfcc_q15_out, 0, sizeof(g_mfcc_q15_out));
-		return;
-	}
-	for (int i = 0; i < EDISON_NUM_MEL; i++)
-	{
-		float v = m[i] < -32768.0f ? -32768.0f : (m[i] > 32767.0f ? 32767.0f : m[i]);
-		g_mfcc_q15_out[i] = (int16_t)(v < 0 ? v - 0.5f : v + 0.5f);
 	}
 }
 

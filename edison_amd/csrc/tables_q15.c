@@ -1,0 +1,106 @@
+/*
+ * tables_q15.c -- host-side construction of the constant tables of MFCC variant C, the firmware's fixed-point
+ * pipeline (firmware/src/audioprocessing.c:116-215 over CMSIS-DSP).
+ *
+ *   twiddleCoef_1024_q15 / twiddleCoef_16_q15   cos, sin of 2*pi*i/N for i < 3N/4 (arm_cfft_radix4_q15.c reads pairs
+ *                                               ic, 2ic, 3ic of them, :236-288)
+ *   realCoefAQ15 / realCoefBQ15                 0.5(1 -/+ sin), -/+0.5 cos of 2*pi*i/8192, read with stride
+ *                                               twidCoefRModifier = 256 for the 32-point real FFT of the DCT stage
+ *                                               (arm_rfft_init_q15.c:213-214, arm_rfft_q15.c:260-320)
+ *   melMtxCompact / melCompFStarts / melCompFCount   int16(mel_mtx_scale * W) without its zeros
+ *                                               (audio/edison/mfcc/mfcc_on_mcu.py:26-62,82-113)
+ *
+ * CMSIS-DSP's arm_common_tables.c is not part of the reference snapshot, so the first two groups are regenerated
+ * from their documented formulas. The float -> Q15 step is: twiddles = top halfword of the Q31 value, i.e.
+ * floor(x * 2^15); split coefficients = round(x * 2^15). That is the one combination that reproduces the
+ * host-vs-board statistics the reference publishes (README.md:121-139) digit for digit; see DESIGN.md and
+ * tests/golden/gen_fixtures_q15.py.
+ *
+ * Every coefficient is stored twice, as the two packed operands of v_dot2_i32_i16:
+ *   x * conj(w):  re = w.cos*x.re + w.sin*x.im  -> (lo = cos, hi = sin)
+ *                 im = w.cos*x.im - w.sin*x.re  -> (lo = -sin, hi = cos)
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/edison_hip.h"
+#include "edison_internal.h"
+
+static int q15_floor(double x)
+{
+	double v = floor(x * 32768.0);
+	return v > 32767.0 ? 32767 : (v < -32768.0 ? -32768 : (int)v);
+}
+
+static int q15_round(double x)
+{
+	double v = x * 32768.0;
+	v = v >= 0 ? floor(v + 0.5) : -floor(-v + 0.5);
+	return v > 32767.0 ? 32767 : (v < -32768.0 ? -32768 : (int)v);
+}
+
+static uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+
+int ed_build_q15_tables(double sample_rate, double lower_edge_hertz, double upper_edge_hertz, double mel_mtx_scale,
+                        ed_q15_tables_t *out, char *err, size_t err_cap)
+{
+	memset(out, 0, sizeof(*out));
+	for (int n = 0; n < 2; n++)
+	{
+		const int N = n == 0 ? 1024 : 16, cnt = 3 * N / 4;
+		uint32_t *w = n == 0 ? out->tw1024 : out->tw16, *wx = n == 0 ? out->tw1024x : out->tw16x;
+		for (int i = 0; i < cnt; i++)
+		{
+			const int c = q15_floor(cos(2.0 * M_PI * i / N)), s = q15_floor(sin(2.0 * M_PI * i / N));
+			w[i] = pack16(c, s);
+			/* -sin must fit a halfword: sin = -1 is pair 3N/4, one past the last pair the transform reads */
+			wx[i] = pack16(s == -32768 ? 32767 : -s, c);
+		}
+	}
+	for (int i = 0; i < 16; i++)
+	{
+		const double a = 2.0 * M_PI * (256.0 * i) / 8192.0;
+		const int are = q15_round(0.5 * (1.0 - sin(a))), aim = q15_round(-0.5 * cos(a));
+		const int bre = q15_round(0.5 * (1.0 + sin(a))), bim = q15_round(0.5 * cos(a));
+		out->rfa[i] = pack16(are, -aim); /* outR = p.re*A.re - p.im*A.im + q.re*B.re + q.im*B.im */
+		out->rfb[i] = pack16(bre, bim);
+	}
+
+	const int nbins = EDISON_FRAME_LEN / 2 + 1, NMEL = EDISON_NUM_MEL;
+	const int scale = (int)mel_mtx_scale;
+	if ((double)scale != mel_mtx_scale || scale < 1 || scale > 32767)
+	{
+		if (err) snprintf(err, err_cap, "variant C needs an integer mel_mtx_scale in 1..32767");
+		return EDISON_E_NO_IMPL;
+	}
+	double *W = (double *)malloc(sizeof(double) * (size_t)nbins * NMEL);
+	if (!W) return EDISON_E_NO_MEMORY;
+	int r = ed_gen_mel_weight_matrix(NMEL, nbins, sample_rate, lower_edge_hertz, upper_edge_hertz, W);
+	if (r != EDISON_OK) { free(W); return r; }
+	int pos = 0;
+	for (int m = 0; m < NMEL; m++)
+	{
+		int first = -1, cnt = 0;
+		for (int k = 0; k < nbins; k++)
+			if ((int16_t)(scale * W[(size_t)k * NMEL + m]) != 0) { if (first < 0) first = k; cnt++; }
+		if (first < 0) first = 0;
+		if (pos + cnt > ED_Q15_MEL_COEF_MAX || first + cnt > nbins)
+		{
+			if (err) snprintf(err, err_cap, "variant C: compact mel matrix does not fit (%d coefficients)", pos + cnt);
+			free(W);
+			return EDISON_E_NO_IMPL;
+		}
+		out->mel_start[m] = first;
+		out->mel_count[m] = cnt;
+		out->mel_off[m] = pos;
+		if (first + cnt > nbins - 1) out->need_nyquist = 1;
+		/* the generator takes `count` consecutive entries from the first non-zero one (mfcc_on_mcu.py:44-48) */
+		for (int k = first; k < first + cnt; k++) out->mel_coef[pos++] = (int16_t)(scale * W[(size_t)k * NMEL + m]);
+	}
+	free(W);
+	out->mel_scale = scale;
+	out->n_mel_coef = pos;
+	return EDISON_OK;
+}

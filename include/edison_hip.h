@@ -59,6 +59,11 @@ extern "C" {
 /* ---- MFCC variants ----------------------------------------------------------- */
 #define EDISON_MFCC_A 0 /* mfcc_utils.mfcc    : fft[:512] -> |.| -> mel(512x32) -> ln(x+1e-6) -> dct2/sqrt(64) */
 #define EDISON_MFCC_B 1 /* mfcc_utils.mfcc_mcu: fft/1024 -> |.|/sqrt2 -> mel(513x32) -> [ln] -> dct2/64        */
+#define EDISON_MFCC_C 2 /* audioCalcMFCCs, the firmware's Q15 pipeline (firmware/src/audioprocessing.c:116-215):
+                         * arm_cfft_q15(1024) -> arm_sqrt_q31 magnitude -> compact int16 mel / 128 -> RFFT-based dct2_q15.
+                         * Integer-exact. Through the fp32 entry points below the outputs are the int16 values as
+                         * floats (Cube branch of mfccToNetInput, app.c:680-683) and feat is the NNoM branch
+                         * (app.c:686-694); feat_scale must be 1, no log. Native int16 interface: edison_mfcc_q15_*.  */
 #define EDISON_MFCC_USE_LOG 0x100 /* OR into variant: mfcc_mcu(..., use_log=True)                       */
 
 typedef struct edison_ctx edison_ctx;
@@ -140,7 +145,29 @@ int edison_cnn_layers_dev(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, in
 int edison_kws_batch_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride,
                          int8_t *feat, int8_t *logits, int8_t *softmax, int32_t *argmax);
 
+/*
+ * Variant C with its native types: what the firmware keeps in bufDctInline / sends with audioDumpToHost
+ * (audioprocessing.c:221-231). mfcc [n_frames][n_coef] int16; feat [n_frames][n_coef] int8 = mfccToNetInput's NNoM
+ * branch (C division by NNOM_INPUT_SCALE = 1, clip to [-128,127], app.c:686-694). Stage dumps, all int16:
+ *   fft [n][513][2] X[k] (re,im), k = 0..512, natural order     spec [n][513] bufSpect     mel [n][32] bufMelSpect
+ * EDISON_E_NO_IMPL when the configured filterbank cannot be expressed as the firmware's compact tables.
+ */
+int edison_mfcc_q15_batch_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step, int n_coef,
+                              int16_t *mfcc, int8_t *feat);
+int edison_mfcc_q15_stages_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step,
+                               int16_t *fft, int16_t *spec, int16_t *mel, int16_t *mfcc32);
+/* edison_kws_batch_dev with the firmware's own features: variant C -> NNoM clip -> CNN, i.e. what the board
+ * answers for the same samples (appHifMfccAndInference, app.c:167-221). */
+int edison_kws_batch_q15_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride, int8_t *feat,
+                             int8_t *logits, int8_t *softmax, int32_t *argmax);
+
 /* ---- the same with HOST pointers (upload, run, download, synchronise) -------------------------------- */
+int edison_mfcc_q15_batch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step, int n_coef,
+                          int16_t *mfcc, int8_t *feat);
+int edison_mfcc_q15_stages(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step, int16_t *fft,
+                           int16_t *spec, int16_t *mel, int16_t *mfcc32);
+int edison_kws_batch_q15(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride, int8_t *feat,
+                         int8_t *logits, int8_t *softmax, int32_t *argmax);
 int edison_mfcc_batch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step, int variant,
                       int n_coef, float *mfcc, int8_t *feat, float feat_scale);
 int edison_mfcc_stages(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step, int variant,
@@ -187,11 +214,10 @@ int8_t *aiNnomGetOutputBuffer(void);
 void mfccToNetInput(int16_t *mfcc, uint16_t in_x, uint16_t in_y, uint32_t xoffset);
 void mfccToNetInputPush(int16_t *mfcc, uint16_t in_x, uint16_t in_y);
 /* firmware/src/audioprocessing.h:21-22: one 1024-sample frame -> pointer to a callee-owned static buffer of 32
- * int16 (valid until the next call). CALL SURFACE of the firmware's Q15 MFCC; the numbers come from variant B, the
- * reference's float model of that path, rounded -- the bit-exact Q15 restatement (variant C) is not built yet. */
+ * int16 (valid until the next call): MFCC variant C, the firmware's own Q15 arithmetic. */
 void audioInit(void);
 void audioCalcMFCCs(int16_t *inp, int16_t **oup);
-/* One 1024-sample frame through the GPU MFCC (variant B float model of the firmware's Q15 path); out32 fp32. */
+/* One 1024-sample frame through the GPU MFCC, any variant; out32 fp32. */
 int edison_mfcc_frame(const int16_t *frame1024, int variant, float *out32);
 edison_ctx *edison_global_ctx(void);
 

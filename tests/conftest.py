@@ -50,6 +50,13 @@ def oracle_model(oracle_mod):
 @pytest.fixture(scope="session")
 def built_lib():
     """The C-ABI shared library (built with hipcc if the tree does not hold it yet)."""
+    # torch ships its own copy of the HIP runtime; a process that also uses torch tensors must load torch's copy
+    # FIRST, or torch later finds "No HIP GPUs" (two runtimes cannot both own the device). The library itself
+    # never needs torch.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     from edison_amd import build as edbuild, _lib
     edbuild.build()
     return _lib.lib()

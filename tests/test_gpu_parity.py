@@ -257,9 +257,9 @@ def test_legacy_frame_and_push_flow(built_lib, ctx, kws_golden):
     assert np.array_equal(out, kws_golden["kws_zero_softmax"])
 
 
-def test_legacy_audio_calc_mfccs_flow(built_lib, ctx, kws_golden, mfcc_golden):
+def test_legacy_audio_calc_mfccs_flow(built_lib, ctx, kws_golden, oracle_mod, oracle_model):
     """app.c:190-203 with the firmware's own names: audioCalcMFCCs -> mfccToNetInput -> aiRunInference. The int16
-    coefficients are variant B rounded (the call surface of the Q15 path; its bit-exact numerics are a later row)."""
+    coefficients are the firmware's Q15 arithmetic (variant C), bit for bit against the oracle."""
     L = built_lib
     L.audioInit()
     a = kws_golden["kws_zero_audio"]
@@ -272,13 +272,15 @@ def test_legacy_audio_calc_mfccs_flow(built_lib, ctx, kws_golden, mfcc_golden):
         rows.append(m16)
         L.mfccToNetInput(m16.ctypes.data_as(ctypes.c_void_p), 13, 31, i)
     rows = np.stack(rows)
-    ref = kws_golden["kws_zero_mfcc"]                       # float64 variant B of the reference, [31, 13]
-    assert np.abs(rows[:, :13] - np.round(ref)).max() <= 1  # rounding of fp32 vs float64 may differ on x.5
+    ref = oracle_mod.mfcc_q15(a[:31 * 1024])
+    assert np.array_equal(rows, ref)
     net_in = np.frombuffer((ctypes.c_int8 * 403).from_address(L.aiNnomGetInputBuffer()), dtype=np.int8).copy()
-    assert np.abs(net_in.reshape(31, 13).astype(int) - kws_golden["kws_zero_feat"].astype(int)).max() <= 1
+    assert np.array_equal(net_in.reshape(31, 13), oracle_mod.net_input_q15(ref))
     res = np.zeros(10, np.int8)
     assert L.aiRunInference(net_in.ctypes.data_as(ctypes.c_void_p), res.ctypes.data_as(ctypes.c_void_p)) == 0
-    assert int(np.argmax(res)) == 0                          # "edison"
+    o = oracle_mod.cnn(oracle_model, net_in.reshape(1, 403))
+    assert np.array_equal(res, o["softmax"][0])
+    assert int(np.argmax(res)) == 0                          # "edison", as the board answers (README.md:124-125)
 
 
 # ---------------------------------------------------------------------------------------------- Python mirror / CLI

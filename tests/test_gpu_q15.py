@@ -1,0 +1,151 @@
+"""GPU parity tests of MFCC variant C (the firmware's Q15 audioCalcMFCCs, firmware/src/audioprocessing.c:116-215).
+
+Integer pipeline => every comparison is bit for bit. The oracle (oracle/mfcc_q15_ref.c) is pinned by the
+host-vs-board statistics the reference publishes (README.md:121-139), which the GPU output must reproduce too.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+STREAMS = ["edison", "hey", "two_tone", "noise", "quiet", "extremes"]
+
+
+def _readme_compare(a, b):
+    dev = 100.0 * (1.0 - (b.ravel() + 1e-9) / (a.ravel() + 1e-9))         # kws_on_mcu.py:159-168
+    return ["%.3f" % dev.max(), "%.3f" % dev.min(), "%.3f" % np.mean(dev),
+            "%.3f" % np.sqrt(np.mean((b.ravel() - a.ravel()) ** 2)), "%.3f" % (b.max() / a.max()),
+            "%.3f" % np.corrcoef(a.ravel(), b.ravel())[0, 1]]
+
+
+@pytest.mark.parametrize("name", STREAMS)
+def test_q15_golden(ctx, mfcc_golden, q15_golden, name):
+    got = ctx.mfcc_q15(mfcc_golden["in_" + name])
+    assert got.dtype == np.int16 and np.array_equal(got, q15_golden["C_mfcc_" + name])
+
+
+def test_q15_stages_golden(ctx, mfcc_golden, q15_golden):
+    for name in ("edison", "two_tone", "extremes"):
+        st = ctx.mfcc_q15_stages(mfcc_golden["in_" + name])
+        assert np.array_equal(st["fft"], q15_golden["C_fft_" + name])
+        assert np.array_equal(st["spectrogram"], q15_golden["C_spec_" + name])
+        assert np.array_equal(st["mel_spectrogram"], q15_golden["C_mel_" + name])
+        assert np.array_equal(st["mfcc"], q15_golden["C_mfcc_" + name])
+
+
+def test_q15_reproduces_published_board_comparison(ctx, q15_golden):
+    """README.md:121-139: the six printed statistics of host (variant B) vs board (variant C) on edison_16k_16b.wav."""
+    x = q15_golden["in_edison_edge"]
+    got, feat = ctx.mfcc_q15(x, n_coef=13, want_feat=True)
+    assert _readme_compare(q15_golden["host32_edison_edge"], got.astype(np.float32)) == q15_golden["readme"].tolist()
+    assert np.array_equal(got, q15_golden["C_mfcc_edison_edge"][:, :13])
+    assert np.array_equal(feat, q15_golden["C_feat_edison_edge"])
+
+
+def test_q15_vs_oracle_seeded(ctx, oracle_mod, mfcc_golden):
+    rng = np.random.default_rng(31)
+    t = np.arange(1024) / 16000.0
+    frames = []
+    for i in range(192):
+        amp = 10.0 ** rng.uniform(0.5, 4.5)                               # quiet to clipping
+        f = rng.normal(0, amp, 1024) + 0.5 * amp * np.cos(2 * np.pi * rng.uniform(50, 7900) * t + rng.uniform(0, 6.28))
+        frames.append(np.clip(f, -32768, 32767))
+    frames.append(np.full(1024, -32768.0))
+    frames.append(np.tile([32767.0, -32768.0], 512))
+    frames.append(np.tile([-32768.0, -32768.0, 32767.0, 32767.0], 256))   # energy at fs/4: saturating butterflies
+    x = np.concatenate(frames).astype(np.int16)
+    ref, rst = oracle_mod.mfcc_q15(x, stages=True, n_threads=4)
+    st = ctx.mfcc_q15_stages(x)
+    assert np.array_equal(st["fft"], rst["fft"][:, :513])
+    assert np.array_equal(st["spectrogram"], rst["spectrogram"])
+    assert np.array_equal(st["mel_spectrogram"], rst["mel_spectrogram"])
+    assert np.array_equal(st["mfcc"], ref)
+    got, feat = ctx.mfcc_q15(x, want_feat=True)
+    assert np.array_equal(got, ref) and np.array_equal(feat, oracle_mod.net_input_q15(ref, n_coef=32))
+    # hops, odd offsets, coefficient subsets
+    n = mfcc_golden["in_noise"]
+    for step in (512, 333, 1):
+        assert np.array_equal(ctx.mfcc_q15(n[:6000], frame_step=step), oracle_mod.mfcc_q15(n[:6000], frame_step=step, n_threads=4))
+    assert np.array_equal(ctx.mfcc_q15(n[1:]), oracle_mod.mfcc_q15(n[1:]))
+    full = ctx.mfcc_q15(n)
+    for nc in (1, 13, 31):
+        assert np.array_equal(ctx.mfcc_q15(n, n_coef=nc), full[:, :nc])
+
+
+def test_q15_through_the_float_interface(ctx, oracle_mod, mfcc_golden):
+    """EDISON_MFCC_C through edison_mfcc_batch: the int16 values as floats, feat = the firmware's clip."""
+    from edison_amd import _lib
+    x = mfcc_golden["in_edison"]
+    ref = oracle_mod.mfcc_q15(x)
+    out, feat = ctx.mfcc(x, variant=_lib.MFCC_C, n_coef=13, want_feat=True)
+    assert out.dtype == np.float32 and np.array_equal(out, ref[:, :13].astype(np.float32))
+    assert np.array_equal(feat, oracle_mod.net_input_q15(ref))
+    with pytest.raises(_lib.EdisonError):
+        ctx.mfcc(x, variant=_lib.MFCC_C, use_log=True)
+    with pytest.raises(_lib.EdisonError):
+        ctx.mfcc(x, variant=_lib.MFCC_C, want_feat=True, feat_scale=0.5)
+    assert ctx.mfcc_q15(np.zeros(100, np.int16)).shape == (0, 32)
+    assert ctx.mfcc_q15(np.zeros(2048, np.int16)).tolist() == [[0] * 32] * 2
+
+
+def test_q15_kws_is_what_the_board_answers(ctx, oracle_mod, oracle_model, q15_golden, kws_golden):
+    """edison_kws_batch_q15 = variant C -> NNoM clip -> int8 CNN (appHifMfccAndInference, app.c:167-221)."""
+    rng = np.random.default_rng(32)
+    L = 31 * 1024
+    utts = [q15_golden["in_edison_edge"][:L], kws_golden["kws_zero_audio"][:L]]
+    utts += [np.clip(rng.normal(0, s, L), -32768, 32767).astype(np.int16) for s in (30, 300, 3000, 12000)]
+    x = np.concatenate(utts)
+    r = ctx.kws(x, utt_stride=L, q15=True)
+    feat = np.stack([oracle_mod.net_input_q15(oracle_mod.mfcc_q15(u)).reshape(-1) for u in utts])
+    assert np.array_equal(r["feat"], feat)
+    o = oracle_mod.cnn(oracle_model, feat)
+    assert np.array_equal(r["logits"], o["logits"]) and np.array_equal(r["softmax"], o["softmax"])
+    assert np.array_equal(r["argmax"], o["argmax"])
+    assert r["argmax"][0] == 0 and r["argmax"][1] == 0                    # "edison" (README.md:124-125: the board agrees)
+
+
+def test_q15_other_filterbanks(built_lib, oracle_mod, mfcc_golden):
+    """edison_mfcc_configure rebuilds the compact mel tables; a band that reaches bin 512 switches the Nyquist bin on;
+    a scale the firmware format cannot hold switches variant C off without touching A/B."""
+    from edison_amd import _lib
+    from edison_amd.context import Context
+    x = np.concatenate([mfcc_golden["in_edison"], mfcc_golden["in_extremes"]])
+    c = Context(0)
+    try:
+        for fs, lo, hi, scale in ((16000, 20.0, 8000.0, 128), (16000, 300.0, 3400.0, 64), (8000, 80.0, 3800.0, 128),
+                                  (16000, 80.0, 7600.0, 1000)):
+            c.configure_mfcc(fs, lo, hi, scale)
+            t = oracle_mod.Q15Tables(sample_rate=fs, lower_edge_hertz=lo, upper_edge_hertz=hi, mel_mtx_scale=scale)
+            assert np.array_equal(c.mfcc_q15(x), oracle_mod.mfcc_q15(x, tables=t)), (fs, lo, hi, scale)
+        c.configure_mfcc(16000, 80.0, 7600.0, 0.5)
+        with pytest.raises(_lib.EdisonError):
+            c.mfcc_q15(x)
+        assert c.mfcc(x, variant=_lib.MFCC_B).shape == (x.shape[0] // 1024, 32)
+    finally:
+        c.close()
+
+
+def test_q15_full_size_65536_frames(ctx, oracle_mod):
+    """BASELINE config 2's frame count: position independence over the persistent grid + the base set vs the oracle."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    ctx.use_torch_stream()
+    B, N = 64, 65536
+    rng = np.random.default_rng(33)
+    base = np.clip(rng.normal(0, 4000, (B, 1024)), -32768, 32767).astype(np.int16)
+    base[0] = 0
+    base[1] = 32767
+    base[2] = -32768
+    tb = torch.from_numpy(base).to(dev)
+    i = torch.arange(N, device=dev, dtype=torch.int64)
+    idx = (i + i // B) % B
+    audio = tb[idx].contiguous()
+    small = torch.empty((B, 13), dtype=torch.int16, device=dev)
+    ctx.mfcc_q15_t(tb, B, 1024, 13, out=small)
+    big = torch.empty((N, 13), dtype=torch.int16, device=dev)
+    feat = torch.empty((N, 13), dtype=torch.int8, device=dev)
+    ctx.mfcc_q15_t(audio, N, 1024, 13, out=big, feat=feat)
+    torch.cuda.synchronize()
+    assert torch.equal(big, small[idx])
+    assert torch.equal(feat, big.clamp(-128, 127).to(torch.int8))
+    assert np.array_equal(small.cpu().numpy(), oracle_mod.mfcc_q15(base.reshape(-1), n_threads=4)[:, :13])
