@@ -19,12 +19,13 @@ extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const in
                                   int64_t feat_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu,
                                   hipStream_t stream);
 
-extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int stages, int n_cu,
-                                  hipStream_t stream);
+extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int mel_nlo, int mel_nhi,
+                                  int stages, int n_cu, hipStream_t stream);
 
 struct edison_ctx
 {
 	ed_q15_tables_t *d_q15; /* variant C (firmware Q15); NULL when the configured filterbank does not fit it */
+	int q15_nlo, q15_nhi;   /* host copy of the table shape: selects the kernel instance */
 	char q15_err[160];
 	int device;
 	int n_cu;

@@ -45,6 +45,8 @@ static int upload_tables(edison_ctx *ctx, double fs, double lo, double hi, doubl
 		{
 			if (!ctx->d_q15) ED_HIP(ctx, hipMalloc((void **)&ctx->d_q15, sizeof(ed_q15_tables_t)));
 			hipError_t e = hipMemcpy(ctx->d_q15, h, sizeof(ed_q15_tables_t), hipMemcpyHostToDevice);
+			ctx->q15_nlo = h->mel_nlo;
+			ctx->q15_nhi = h->mel_nhi;
 			free(h);
 			ED_HIP(ctx, e);
 		}

@@ -58,7 +58,13 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
                          double mel_mtx_scale, ed_mfcc_tables_t *out, char *err, size_t err_cap);
 
 /* ------------------------------------------------------------------ MFCC variant C (firmware Q15) tables */
-#define ED_Q15_MEL_COEF_MAX 1024 /* shipped filterbank: 915 (mel_constants.h: melMtxCompact[915])              */
+/* The compact mel matrix (mel_constants.h: melMtxCompact[915] + per-band first bin and count) is spread over the
+ * wavefront like the float kernel's filterbank: lane (b = lane&15, r = lane>>4) sums quarter r of the narrow band b
+ * (mel_nlo taps) and quarter r of the wide band 31-b (mel_nhi taps); 32-bit wrap-around addition is associative, so
+ * the split does not change the firmware's result. The kernel is compiled for two shapes: 6+18 (shipped) and 8+24. */
+#define ED_Q15_NLO_MAX 8
+#define ED_Q15_NHI_MAX 24
+#define ED_Q15_TAPS_MAX (ED_Q15_NLO_MAX + ED_Q15_NHI_MAX)
 
 typedef struct {
 	/* complex Q15 coefficients as the two packed operands of v_dot2_i32_i16 (see tables_q15.c):
@@ -66,8 +72,9 @@ typedef struct {
 	uint32_t tw1024[768], tw1024x[768];
 	uint32_t tw16[12], tw16x[12];
 	uint32_t rfa[16], rfb[16]; /* real-FFT split of the DCT stage, pair 256*i of realCoefA/BQ15: (A.re,-A.im), (B.re,B.im) */
-	int32_t mel_start[32], mel_count[32], mel_off[32]; /* band m: spectrum bins [start, start+count), coefficients at off */
-	int32_t mel_coef[ED_Q15_MEL_COEF_MAX];
+	int32_t mel_tap[ED_Q15_TAPS_MAX][64]; /* [t][lane]: t < mel_nlo narrow-band taps, then mel_nhi wide-band taps (0 = padding) */
+	int32_t mel_lo_bin[64], mel_hi_bin[64]; /* first spectrum bin of the lane's two runs (every read stays below 513) */
+	int32_t mel_nlo, mel_nhi;
 	int32_t mel_scale, n_mel_coef;
 	int32_t need_nyquist; /* some band reads spectrum bin 512 */
 	int32_t pad_;

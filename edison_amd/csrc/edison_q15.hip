@@ -30,7 +30,7 @@ int ed_ctx_mfcc_q15_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_fram
 	a.frame_step = frame_step; a.n_coef = n_coef;
 	a.mfcc_i16 = mfcc_i16; a.mfcc_f32 = mfcc_f32; a.feat = feat;
 	a.fft = fft; a.spec = spec; a.mel = mel;
-	int e = ed_launch_mfcc_q15(&a, ctx->d_q15, stages, ctx->n_cu, ctx->stream);
+	int e = ed_launch_mfcc_q15(&a, ctx->d_q15, ctx->q15_nlo, ctx->q15_nhi, stages, ctx->n_cu, ctx->stream);
 	if (e != 0)
 	{
 		snprintf(ctx->err, sizeof(ctx->err), "Q15 MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)e));

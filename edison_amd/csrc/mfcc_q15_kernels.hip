@@ -13,7 +13,7 @@
  * read_q15x2), so the Cortex-M4 SIMD instructions of the DSP branch have direct CDNA4 counterparts:
  *   __QADD16/__QSUB16 -> v_pk_add_i16/v_pk_sub_i16 clamp      __SHADD16(x,0) -> v_pk_ashrrev_i16
  *   __SHADD16/__SHSUB16 -> and/xor + v_pk_ashrrev_i16 + v_pk_add/sub_u16 (overflow-free floor average)
- *   __SMUAD/__SMUSDX -> v_dot2_i32_i16 against the two pre-packed forms of the twiddle
+ *   __SMUAD/__SMUSDX -> v_dot2_i32_i16 against the two pre-packed forms of the twiddle, v_perm_b32 packs bits 31..16
  * The five radix-4 stages of the 1024-point transform are grouped so that a lane always owns whole butterflies:
  *   stage 1        lane l owns butterflies j = l + 64u (elements j + 256q), samples straight from HBM
  *   stages 2 + 3   lane (U = l>>4, j3 = l&15) owns the 16 elements 256U + j3 + 16a + 64b: four stage-2 butterflies
@@ -23,7 +23,13 @@
  * access patterns above bank-conflict free. The output of the radix-4 routine is in bit-reversed order, so after
  * stage 5 register m of lane l is X[64*bitrev4(m) + bitrev6(l)]: the even registers are exactly the bins below 512.
  *
- * HBM traffic per frame: 2048 B of samples in, n_coef * (2 + 4 + 1) B out at most; the tables (8 KB) stay in L2.
+ * arm_sqrt_q31's 64-bit products (a*b)>>31 are single v_mul_hi_u32 with one operand pre-doubled; that this is the
+ * same function on all 2^31-1 positive inputs is checked by enumeration (tools/verify/sqrt_q31_equiv.c).
+ * The mel sums are spread over the wavefront (see edison_internal.h) and the small DCT stage -- a 16-point complex
+ * FFT that would keep 4 of 64 lanes busy -- is deferred: a wavefront parks the 32 mel values of each frame in LDS and
+ * runs the DCT stage for 16 frames at once.
+ *
+ * HBM traffic per frame: 2048 B of samples in, n_coef * (2 + 4 + 1) B out at most; the tables (15 KB) stay in L2.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,6 +41,12 @@
 #define EQ_WPB 4                 /* wavefronts (= frames in flight) per workgroup                     */
 #define EQ_BUF 1088              /* 1024 complex values + one pad dword per 16                        */
 #define EQ_P(p) ((p) + ((p) >> 4))
+#define EQ_NB 16                 /* frames whose DCT stage a wavefront runs together                  */
+/* timing-only ablations for A/B work (results are WRONG when non-zero): 1 no sqrt, 2 no DCT stage, 4 no mel taps,
+ * 8 no FFT stages 2-5, 16 no stage-1 butterflies */
+#ifndef EQ_ABLATE
+#define EQ_ABLATE 0
+#endif
 
 typedef unsigned int u32;
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -53,12 +65,23 @@ __device__ __forceinline__ u32 eq_hsub(u32 a, u32 b) { return eq_u((eq_s(a ^ b) 
 __device__ __forceinline__ u32 eq_swap(u32 a) { return __builtin_amdgcn_alignbit(a, a, 16); }
 __device__ __forceinline__ u32 eq_lohi(u32 lo_from, u32 hi_from) { return (lo_from & 0xffffu) | (hi_from & 0xffff0000u); }
 
+/* a.lo*b.lo + a.hi*b.hi, 32-bit wrap-around. The VOP3P form with an inline 0 accumulator: the builtin selects the
+ * accumulating VOP2 form and spends a v_mov on the zero. UNIFORM = the coefficient lives in an SGPR. */
+template <bool UNIFORM>
+__device__ __forceinline__ int eq_dot2(u32 coef, u32 x)
+{
+	int r;
+	if (UNIFORM) asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "s"(coef), "v"(x));
+	else asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(coef), "v"(x));
+	return r;
+}
+
 /* x * conj(w): bits 31..16 of the two dual 16x16 multiply-accumulates */
+template <bool UNIFORM>
 __device__ __forceinline__ u32 eq_twiddle(u32 x, u32 w, u32 wx)
 {
-	const int re = __builtin_amdgcn_sdot2(eq_s(w), eq_s(x), 0, false);
-	const int im = __builtin_amdgcn_sdot2(eq_s(wx), eq_s(x), 0, false);
-	return ((u32)re >> 16) | ((u32)im & 0xffff0000u);
+	const u32 re = (u32)eq_dot2<UNIFORM>(w, x), im = (u32)eq_dot2<UNIFORM>(wx, x);
+	return __builtin_amdgcn_perm(im, re, 0x07060302u); /* (re >> 16) | (im & 0xffff0000) */
 }
 
 struct eq_tw3 { u32 w[3], wx[3]; }; /* pairs ic, 2ic, 3ic */
@@ -81,27 +104,28 @@ __device__ __forceinline__ void eq_bf_first(u32 &a, u32 &b, u32 &c, u32 &d, cons
 	a = eq_asr2(a); b = eq_asr2(b); c = eq_asr2(c); d = eq_asr2(d);
 	const u32 r = eq_qadd(a, c), s = eq_qsub(a, c), tt = eq_qadd(b, d);
 	const u32 x0 = eq_hadd(r, tt);
-	const u32 x1 = eq_twiddle(eq_qsub(r, tt), t.w[1], t.wx[1]);
+	const u32 x1 = eq_twiddle<false>(eq_qsub(r, tt), t.w[1], t.wx[1]);
 	const u32 rt = eq_swap(eq_qsub(b, d));
 	u32 plus, minus;
 	EQ_PLUS_MINUS_I(eq_qadd(s, rt), eq_qsub(s, rt), plus, minus);
 	a = x0; b = x1;
-	c = eq_twiddle(minus, t.w[0], t.wx[0]);
-	d = eq_twiddle(plus, t.w[2], t.wx[2]);
+	c = eq_twiddle<false>(minus, t.w[0], t.wx[0]);
+	d = eq_twiddle<false>(plus, t.w[2], t.wx[2]);
 }
 
 /* middle stages (:335-455) */
+template <bool UNIFORM>
 __device__ __forceinline__ void eq_bf_mid(u32 &a, u32 &b, u32 &c, u32 &d, const eq_tw3 &t)
 {
 	const u32 r = eq_qadd(a, c), s = eq_qsub(a, c), tt = eq_qadd(b, d);
 	const u32 x0 = eq_asr1(eq_hadd(r, tt));
-	const u32 x1 = eq_twiddle(eq_hsub(r, tt), t.w[1], t.wx[1]);
+	const u32 x1 = eq_twiddle<UNIFORM>(eq_hsub(r, tt), t.w[1], t.wx[1]);
 	const u32 rt = eq_swap(eq_qsub(b, d));
 	u32 plus, minus;
 	EQ_PLUS_MINUS_I(eq_hadd(s, rt), eq_hsub(s, rt), plus, minus);
 	a = x0; b = x1;
-	c = eq_twiddle(minus, t.w[0], t.wx[0]);
-	d = eq_twiddle(plus, t.w[2], t.wx[2]);
+	c = eq_twiddle<UNIFORM>(minus, t.w[0], t.wx[0]);
+	d = eq_twiddle<UNIFORM>(plus, t.w[2], t.wx[2]);
 }
 
 /* last stage, no twiddles (:470-561) */
@@ -113,44 +137,153 @@ __device__ __forceinline__ void eq_bf_last(u32 &a, u32 &b, u32 &c, u32 &d)
 	a = eq_hadd(r, tt); b = eq_hsub(r, tt); c = minus; d = plus;
 }
 
-/* arm_sqrt_q31: float seed from the exponent trick, three Newton steps on 1/sqrt, one multiply back */
+/* arm_sqrt_q31: float seed from the exponent trick, three Newton steps on 1/sqrt, one multiply back. Every
+ * intermediate stays in [0, 2^31), so (a*b)>>31 == mulhi(2a, b) (tools/verify/sqrt_q31_equiv.c enumerates it). */
 __device__ __forceinline__ int eq_sqrt_q31(int in)
 {
 	if (in <= 0) return 0;
 	const int sh = (__builtin_clz((u32)in) - 1) & ~1;
-	const int number = (int)((u32)in << sh), half = number >> 1;
-	const float seed = (float)number * 4.6566128731e-010f;
+	const u32 number = (u32)in << sh, number2 = number & ~1u;
+	const float seed = (float)(int)number * 4.6566128731e-010f;
 	const float guess = __int_as_float(0x5f3759df - (__float_as_int(seed) >> 1)) * 1073741824.0f;
-	int v = (int)guess;
+	u32 v = (u32)(int)guess;
 #pragma unroll
 	for (int it = 0; it < 3; it++)
 	{
-		const int vv = (int)(((long long)v * v) >> 31);
-		const int hv = (int)(((long long)vv * half) >> 31);
-		v = (int)((u32)(int)(((long long)v * (0x30000000 - hv)) >> 31) << 2);
+		const u32 vv = __umulhi(v << 1, v);
+		const u32 hv = __umulhi(vv, number2);
+		v = __umulhi(v, (0x30000000u - hv) << 1) << 2;
 	}
-	v = (int)((u32)(int)(((long long)number * v) >> 31) << 1);
-	return v >> (sh >> 1);
+	v = __umulhi(number << 1, v) << 1;
+	return (int)v >> (sh >> 1);
 }
 
 __device__ __forceinline__ int eq_re(u32 x) { return (int)(short)(x & 0xffffu); }
 __device__ __forceinline__ int eq_im(u32 x) { return (int)x >> 16; }
 __device__ __forceinline__ int eq_bitrev(int v, int bits) { return (int)(__builtin_bitreverse32((u32)v) >> (32 - bits)); }
 
+/* Orders this wave's LDS writes before its following LDS reads for the compiler; the hardware services a wave's DS
+ * instructions in order. */
 __device__ __forceinline__ void eq_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
-template <bool STAGES>
+/* sum over the four 16-lane rows in every lane (wrap-around): v_permlane16_swap, then v_permlane32_swap */
+__device__ __forceinline__ u32 eq_sum_rows(u32 x)
+{
+	const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+	const u32 y = r[0] + r[1];
+	const auto q = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+	return q[0] + q[1];
+}
+
+/* First sample of frame f: (f / fpg) * group_stride + (f % fpg) * frame_step (f is wave-uniform, < 2^31). */
+__device__ __forceinline__ const int16_t *eq_frame_ptr(const ed_mfcc_q15_args_t &a, uint32_t f)
+{
+	uint32_t g = 0, i = f;
+	if (a.frames_per_group < a.n_frames)
+	{
+		g = f / (uint32_t)a.frames_per_group;
+		i = f - g * (uint32_t)a.frames_per_group;
+	}
+	return a.audio + ((int64_t)g * a.group_stride + (int64_t)i * a.frame_step);
+}
+
+/*
+ * dct2_q15 for nb <= 16 parked frames of this wavefront (mel rows in melb[s][32]): v[i] = mel[2i], v[31-i] = mel[2i+1];
+ * z[n] = (v[2n], v[2n+1]); 16-point radix-4 transform (first + last stage); real-FFT split; real parts. Frame s of the
+ * batch is frame f0 + s * fstride of the launch. The output rows overwrite the mel rows.
+ */
+__device__ __forceinline__ void eq_dct_batch(const ed_mfcc_q15_args_t &a, int *melb, u32 *zb, int nb, uint32_t f0,
+                                             uint32_t fstride, int lane, const eq_tw3 &t16, u32 rfa_l, u32 rfb_l)
+{
+	{
+		const int s = lane >> 2, j = lane & 3;
+		const int *mel = melb + 32 * s;
+		u32 *zs = zb + 16 * s;
+		if (s < nb)
+		{
+			u32 z[4];
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+			{
+				const int n = j + 4 * q;
+				const int re = n < 8 ? mel[4 * n] : mel[63 - 4 * n];
+				const int im = n < 8 ? mel[4 * n + 2] : mel[61 - 4 * n];
+				z[q] = ((u32)re & 0xffffu) | ((u32)im << 16);
+			}
+			eq_bf_first(z[0], z[1], z[2], z[3], t16);
+#pragma unroll
+			for (int q = 0; q < 4; q++) zs[j + 4 * q] = z[q];
+		}
+		eq_wave_sync();
+		if (s < nb)
+		{
+			u32 z0 = zs[4 * j], z1 = zs[4 * j + 1], z2 = zs[4 * j + 2], z3 = zs[4 * j + 3];
+			eq_bf_last(z0, z1, z2, z3);
+			zs[4 * j] = z0; zs[4 * j + 1] = z1; zs[4 * j + 2] = z2; zs[4 * j + 3] = z3;
+		}
+		eq_wave_sync();
+	}
+	{
+		const int i = lane & 15;
+#pragma unroll
+		for (int p = 0; p < EQ_NB / 4; p++)
+		{
+			const int s = 4 * p + (lane >> 4);
+			if (s < nb)
+			{
+				const u32 *zs = zb + 16 * s;
+				int *out = melb + 32 * s;
+				if (i == 0)
+				{
+					const u32 z0 = zs[0];
+					out[0] = (int)(short)((eq_re(z0) + eq_im(z0)) >> 1);
+					out[16] = (int)(short)((eq_re(z0) - eq_im(z0)) >> 1);
+				}
+				else
+				{
+					const u32 pz = zs[eq_bitrev(i, 4)], qz = zs[eq_bitrev(16 - i, 4)];
+					const u32 r = (u32)eq_dot2<false>(rfa_l, pz) + (u32)eq_dot2<false>(rfb_l, qz);
+					const int o = (int)(short)(r >> 16);
+					out[i] = o;
+					out[32 - i] = o;
+				}
+			}
+		}
+		eq_wave_sync();
+	}
+	{
+		const int c = lane & 31;
+#pragma unroll
+		for (int p = 0; p < EQ_NB / 2; p++)
+		{
+			const int s = 2 * p + (lane >> 5);
+			if (s < nb && c < a.n_coef)
+			{
+				const int o = melb[32 * s + c];
+				const int64_t at = (int64_t)(f0 + (uint32_t)s * fstride) * a.n_coef + c;
+				if (a.mfcc_i16) a.mfcc_i16[at] = (int16_t)o;
+				if (a.mfcc_f32) a.mfcc_f32[at] = (float)o;
+				if (a.feat) a.feat[at] = (int8_t)(o > 127 ? 127 : (o < -128 ? -128 : o));
+			}
+		}
+		eq_wave_sync();
+	}
+}
+
+template <bool STAGES, int NLO, int NHI>
 __global__ __launch_bounds__(64 * EQ_WPB) void ed_mfcc_q15_kernel(ed_mfcc_q15_args_t a, const ed_q15_tables_t *__restrict__ T)
 {
 	__shared__ u32 s_buf[EQ_WPB][EQ_BUF];
-	__shared__ int s_coef[ED_Q15_MEL_COEF_MAX];
-	__shared__ int s_small[EQ_WPB][96]; /* mel[32] | z[16] (packed) | out[32] */
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	__shared__ int s_tap[NLO + NHI][64];
+	__shared__ int s_melb[EQ_WPB][EQ_NB * 32];
+	__shared__ u32 s_zb[EQ_WPB][EQ_NB * 16];
+	const int lane = threadIdx.x & 63;
+	const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	u32 *buf = s_buf[w];
-	int *sm_mel = s_small[w], *sm_out = s_small[w] + 64;
-	u32 *sm_z = (u32 *)(s_small[w] + 32);
+	int *melb = s_melb[w];
+	u32 *zb = s_zb[w];
 
-	for (int i = threadIdx.x; i < ED_Q15_MEL_COEF_MAX; i += 64 * EQ_WPB) s_coef[i] = T->mel_coef[i];
+	for (int i = threadIdx.x; i < (NLO + NHI) * 64; i += 64 * EQ_WPB) (&s_tap[0][0])[i] = (&T->mel_tap[0][0])[i];
 	__syncthreads();
 
 	/* per-lane constants of the whole run */
@@ -162,21 +295,27 @@ __global__ __launch_bounds__(64 * EQ_WPB) void ed_mfcc_q15_kernel(ed_mfcc_q15_ar
 		t1[u] = eq_load_tw(T->tw1024, T->tw1024x, lane + 64 * u);     /* stage 1: ic = j                  */
 		t2[u] = eq_load_tw(T->tw1024, T->tw1024x, 4 * (j3 + 16 * u)); /* stage 2: ic = 4 j, j = j3 + 16a  */
 		t4[u] = eq_load_tw(T->tw1024, T->tw1024x, 64 * u);            /* stage 4: ic = 64 j (uniform)     */
+#pragma unroll
+		for (int i = 0; i < 3; i++)
+		{
+			t4[u].w[i] = __builtin_amdgcn_readfirstlane(t4[u].w[i]);
+			t4[u].wx[i] = __builtin_amdgcn_readfirstlane(t4[u].wx[i]);
+		}
 	}
 	const eq_tw3 t3 = eq_load_tw(T->tw1024, T->tw1024x, 16 * j3);     /* stage 3: ic = 16 j               */
-	const int band = lane & 31, bhalf = lane >> 5;
-	const int m_cnt = T->mel_count[band], m_first = (m_cnt + 1) >> 1;
-	const int m_lo = bhalf ? m_first : 0, m_hi = bhalf ? m_cnt : m_first;
-	const int m_spec = T->mel_start[band], m_off = T->mel_off[band];
+	const int mel_lo_bin = T->mel_lo_bin[lane], mel_hi_bin = T->mel_hi_bin[lane];
 	const int mel_scale = T->mel_scale;
 	const bool need_nyquist = STAGES || T->need_nyquist != 0; /* a band that reaches bin 512 (not the shipped filterbank) */
 	const int rev6 = eq_bitrev(lane, 6);
 	const eq_tw3 t16 = eq_load_tw(T->tw16, T->tw16x, lane & 3);
 	const u32 rfa_l = T->rfa[lane & 15], rfb_l = T->rfb[lane & 15];
 
-	for (int64_t f = (int64_t)blockIdx.x * EQ_WPB + w; f < a.n_frames; f += (int64_t)gridDim.x * EQ_WPB)
+	const uint32_t n_frames = (uint32_t)a.n_frames, fstride = gridDim.x * EQ_WPB;
+	const uint32_t f_first = blockIdx.x * EQ_WPB + (uint32_t)w;
+	int slot = 0;
+	for (uint32_t f = f_first; f < n_frames; f += fstride)
 	{
-		const int16_t *src = a.audio + (f / a.frames_per_group) * a.group_stride + (f % a.frames_per_group) * a.frame_step;
+		const int16_t *src = eq_frame_ptr(a, f);
 		u32 e[16];
 
 		/* ---- stage 1: real samples become (re, 0) */
@@ -187,35 +326,37 @@ __global__ __launch_bounds__(64 * EQ_WPB) void ed_mfcc_q15_kernel(ed_mfcc_q15_ar
 #pragma unroll
 		for (int u = 0; u < 4; u++)
 		{
-			eq_bf_first(e[4 * u], e[4 * u + 1], e[4 * u + 2], e[4 * u + 3], t1[u]);
+			if (!(EQ_ABLATE & 16)) eq_bf_first(e[4 * u], e[4 * u + 1], e[4 * u + 2], e[4 * u + 3], t1[u]);
 #pragma unroll
 			for (int q = 0; q < 4; q++) buf[EQ_P(lane + 64 * u + 256 * q)] = e[4 * u + q];
 		}
 		eq_wave_sync();
 
-		/* ---- stages 2 + 3 on the 4x4 block e[a][b] = element 256U + j3 + 16a + 64b */
+		if (!(EQ_ABLATE & 8))
+		{
+			/* ---- stages 2 + 3 on the 4x4 block e[a][b] = element 256U + j3 + 16a + 64b */
 #pragma unroll
-		for (int aa = 0; aa < 4; aa++)
+			for (int aa = 0; aa < 4; aa++)
 #pragma unroll
-			for (int b = 0; b < 4; b++) e[4 * aa + b] = buf[EQ_P(256 * U + j3 + 16 * aa + 64 * b)];
+				for (int b = 0; b < 4; b++) e[4 * aa + b] = buf[EQ_P(256 * U + j3 + 16 * aa + 64 * b)];
 #pragma unroll
-		for (int aa = 0; aa < 4; aa++) eq_bf_mid(e[4 * aa], e[4 * aa + 1], e[4 * aa + 2], e[4 * aa + 3], t2[aa]);
+			for (int aa = 0; aa < 4; aa++) eq_bf_mid<false>(e[4 * aa], e[4 * aa + 1], e[4 * aa + 2], e[4 * aa + 3], t2[aa]);
 #pragma unroll
-		for (int b = 0; b < 4; b++) eq_bf_mid(e[b], e[4 + b], e[8 + b], e[12 + b], t3);
-		eq_wave_sync();
+			for (int b = 0; b < 4; b++) eq_bf_mid<false>(e[b], e[4 + b], e[8 + b], e[12 + b], t3);
 #pragma unroll
-		for (int aa = 0; aa < 4; aa++)
+			for (int aa = 0; aa < 4; aa++)
 #pragma unroll
-			for (int b = 0; b < 4; b++) buf[EQ_P(256 * U + j3 + 16 * aa + 64 * b)] = e[4 * aa + b];
-		eq_wave_sync();
+				for (int b = 0; b < 4; b++) buf[EQ_P(256 * U + j3 + 16 * aa + 64 * b)] = e[4 * aa + b];
+			eq_wave_sync();
 
-		/* ---- stages 4 + 5 on the 16 consecutive elements of this lane */
+			/* ---- stages 4 + 5 on the 16 consecutive elements of this lane */
 #pragma unroll
-		for (int m = 0; m < 16; m++) e[m] = buf[17 * lane + m]; /* EQ_P(16 lane + m) */
+			for (int m = 0; m < 16; m++) e[m] = buf[17 * lane + m]; /* EQ_P(16 lane + m) */
 #pragma unroll
-		for (int j = 0; j < 4; j++) eq_bf_mid(e[j], e[4 + j], e[8 + j], e[12 + j], t4[j]);
+			for (int j = 0; j < 4; j++) eq_bf_mid<true>(e[j], e[4 + j], e[8 + j], e[12 + j], t4[j]);
 #pragma unroll
-		for (int g = 0; g < 4; g++) eq_bf_last(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]);
+			for (int g = 0; g < 4; g++) eq_bf_last(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]);
+		}
 		eq_wave_sync();
 
 		/* ---- magnitudes: register m = X[64 bitrev4(m) + bitrev6(lane)]; bins 0..511 are the even registers */
@@ -225,13 +366,14 @@ __global__ __launch_bounds__(64 * EQ_WPB) void ed_mfcc_q15_kernel(ed_mfcc_q15_ar
 		{
 			const int m = ((kk & 1) << 3) | ((kk & 2) << 1) | ((kk & 4) >> 1); /* bitrev4(kk), kk < 8 */
 			const int re = eq_re(e[m]), im = eq_im(e[m]);
-			const int mag = (int)(short)(eq_sqrt_q31((int)((u32)(re * re) + (u32)(im * im))) >> 16);
+			const int mag = (EQ_ABLATE & 1) ? (re ^ im) & 0x7fff
+			                                : (int)(short)(eq_sqrt_q31((int)((u32)(re * re) + (u32)(im * im))) >> 16);
 			spec[64 * kk + rev6] = mag;
 			if (STAGES)
 			{
 				const int64_t k = 64 * kk + rev6;
-				if (a.fft) { a.fft[(f * 513 + k) * 2] = (int16_t)re; a.fft[(f * 513 + k) * 2 + 1] = (int16_t)im; }
-				if (a.spec) a.spec[f * 513 + k] = (int16_t)mag;
+				if (a.fft) { a.fft[((int64_t)f * 513 + k) * 2] = (int16_t)re; a.fft[((int64_t)f * 513 + k) * 2 + 1] = (int16_t)im; }
+				if (a.spec) a.spec[(int64_t)f * 513 + k] = (int16_t)mag;
 			}
 		}
 		if (need_nyquist && lane == 0)
@@ -239,98 +381,81 @@ __global__ __launch_bounds__(64 * EQ_WPB) void ed_mfcc_q15_kernel(ed_mfcc_q15_ar
 			const int re = eq_re(e[1]), im = eq_im(e[1]); /* X[512] */
 			const int mag = (int)(short)(eq_sqrt_q31((int)((u32)(re * re) + (u32)(im * im))) >> 16);
 			spec[512] = mag;
-			if (STAGES && a.fft) { a.fft[(f * 513 + 512) * 2] = (int16_t)re; a.fft[(f * 513 + 512) * 2 + 1] = (int16_t)im; }
-			if (STAGES && a.spec) a.spec[f * 513 + 512] = (int16_t)mag;
+			if (STAGES && a.fft) { a.fft[((int64_t)f * 513 + 512) * 2] = (int16_t)re; a.fft[((int64_t)f * 513 + 512) * 2 + 1] = (int16_t)im; }
+			if (STAGES && a.spec) a.spec[(int64_t)f * 513 + 512] = (int16_t)mag;
 		}
 		eq_wave_sync();
 
-		/* ---- compact mel matrix: lane (band, half) sums half of the band's run; 32-bit wrap-around like the MCU */
-		u32 acc = 0;
-		for (int i = m_lo; i < m_hi; i++) acc += (u32)(spec[m_spec + i] * s_coef[m_off + i]);
-		acc += (u32)__shfl_xor((int)acc, 32);
-		const int melv = (int)(short)((int)acc / mel_scale);
+		/* ---- compact mel matrix: lane (b, r) sums quarter r of band b and of band 31-b; 32-bit wrap-around like the MCU */
+		u32 acc_lo = 0, acc_hi = 0;
+		if (EQ_ABLATE & 4) { acc_lo = (u32)spec[mel_lo_bin]; acc_hi = (u32)spec[mel_hi_bin]; }
+		else
+		{
+#pragma unroll
+			for (int t = 0; t < NLO; t++) acc_lo += (u32)(spec[mel_lo_bin + t] * s_tap[t][lane]);
+#pragma unroll
+			for (int t = 0; t < NHI; t++) acc_hi += (u32)(spec[mel_hi_bin + t] * s_tap[NLO + t][lane]);
+		}
+		acc_lo = eq_sum_rows(acc_lo);
+		acc_hi = eq_sum_rows(acc_hi);
 		if (lane < 32)
 		{
-			sm_mel[lane] = melv;
-			if (STAGES && a.mel) a.mel[f * 32 + lane] = (int16_t)melv;
+			const int band = lane < 16 ? lane : 47 - lane; /* lanes 16..31 hold band 31 - (lane & 15) */
+			const int melv = (int)(short)((int)(lane < 16 ? acc_lo : acc_hi) / mel_scale);
+			melb[32 * slot + band] = melv;
+			if (STAGES && a.mel) a.mel[(int64_t)f * 32 + band] = (int16_t)melv;
 		}
 		eq_wave_sync();
 
-		/* ---- dct2_q15: v[i] = mel[2i], v[31-i] = mel[2i+1]; z[n] = (v[2n], v[2n+1]); 16-point radix-4; split */
-		if (lane < 4)
+		/* ---- dct2_q15, deferred: run it when 16 frames are parked or the wave has no frame left */
+		const bool last = f + fstride >= n_frames || f + fstride < f;
+		if (slot == EQ_NB - 1 || last)
 		{
-			u32 z[4];
-#pragma unroll
-			for (int q = 0; q < 4; q++)
+			if (EQ_ABLATE & 2)
 			{
-				const int n = lane + 4 * q;
-				const int re = n < 8 ? sm_mel[4 * n] : sm_mel[63 - 4 * n];
-				const int im = n < 8 ? sm_mel[4 * n + 2] : sm_mel[61 - 4 * n];
-				z[q] = ((u32)re & 0xffffu) | ((u32)im << 16);
-			}
-			eq_bf_first(z[0], z[1], z[2], z[3], t16);
-#pragma unroll
-			for (int q = 0; q < 4; q++) sm_z[lane + 4 * q] = z[q];
-		}
-		eq_wave_sync();
-		if (lane < 4)
-		{
-			u32 z0 = sm_z[4 * lane], z1 = sm_z[4 * lane + 1], z2 = sm_z[4 * lane + 2], z3 = sm_z[4 * lane + 3];
-			eq_bf_last(z0, z1, z2, z3);
-			sm_z[4 * lane] = z0; sm_z[4 * lane + 1] = z1; sm_z[4 * lane + 2] = z2; sm_z[4 * lane + 3] = z3;
-		}
-		eq_wave_sync();
-		if (lane < 16)
-		{
-			if (lane == 0)
-			{
-				const u32 z0 = sm_z[0];
-				sm_out[0] = (int)(short)((eq_re(z0) + eq_im(z0)) >> 1);
-				sm_out[16] = (int)(short)((eq_re(z0) - eq_im(z0)) >> 1);
+				if (lane < a.n_coef && a.mfcc_i16) a.mfcc_i16[(int64_t)f * a.n_coef + lane] = (int16_t)melb[32 * slot + lane];
 			}
 			else
-			{
-				const u32 p = sm_z[eq_bitrev(lane, 4)], q = sm_z[eq_bitrev(16 - lane, 4)];
-				const u32 r = (u32)__builtin_amdgcn_sdot2(eq_s(rfa_l), eq_s(p), 0, false) +
-				              (u32)__builtin_amdgcn_sdot2(eq_s(rfb_l), eq_s(q), 0, false);
-				const int o = (int)(short)(r >> 16);
-				sm_out[lane] = o;
-				sm_out[32 - lane] = o;
-			}
+				eq_dct_batch(a, melb, zb, slot + 1, f - (uint32_t)slot * fstride, fstride, lane, t16, rfa_l, rfb_l);
+			slot = 0;
 		}
-		eq_wave_sync();
-		if (lane < a.n_coef)
-		{
-			const int o = sm_out[lane];
-			const int64_t at = f * a.n_coef + lane;
-			if (a.mfcc_i16) a.mfcc_i16[at] = (int16_t)o;
-			if (a.mfcc_f32) a.mfcc_f32[at] = (float)o;
-			if (a.feat) a.feat[at] = (int8_t)(o > 127 ? 127 : (o < -128 ? -128 : o));
-		}
-		eq_wave_sync();
+		else
+			slot++;
 	}
 }
 
-static int g_q15_blocks_per_cu = -1;
+static int g_q15_blocks_per_cu[2] = {-1, -1};
 
-extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int stages, int n_cu,
-                                  hipStream_t stream)
+template <int NLO, int NHI>
+static int ed_launch_q15_shape(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int stages, int n_cu,
+                               hipStream_t stream, int *blocks_per_cu)
 {
-	if (g_q15_blocks_per_cu < 0)
+	if (*blocks_per_cu < 0)
 	{
 		int nb = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ed_mfcc_q15_kernel<false>, 64 * EQ_WPB, 0) != hipSuccess || nb < 1)
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ed_mfcc_q15_kernel<false, NLO, NHI>, 64 * EQ_WPB, 0) != hipSuccess || nb < 1)
 			nb = 2;
 		const char *env = getenv("ED_Q15_BLOCKS_PER_CU"); /* tuning knob: cap the persistent grid */
 		if (env && atoi(env) > 0 && atoi(env) < nb) nb = atoi(env);
-		g_q15_blocks_per_cu = nb;
+		*blocks_per_cu = nb;
 	}
 	int64_t blocks = (args->n_frames + EQ_WPB - 1) / EQ_WPB;
-	const int64_t cap = (int64_t)n_cu * g_q15_blocks_per_cu;
+	const int64_t cap = (int64_t)n_cu * *blocks_per_cu;
 	if (blocks > cap) blocks = cap;
 	if (blocks < 1) return 0;
 	dim3 grid((unsigned)blocks), block(64 * EQ_WPB);
-	if (stages) hipLaunchKernelGGL(ed_mfcc_q15_kernel<true>, grid, block, 0, stream, *args, dev_tab);
-	else hipLaunchKernelGGL(ed_mfcc_q15_kernel<false>, grid, block, 0, stream, *args, dev_tab);
+	if (stages) hipLaunchKernelGGL((ed_mfcc_q15_kernel<true, NLO, NHI>), grid, block, 0, stream, *args, dev_tab);
+	else hipLaunchKernelGGL((ed_mfcc_q15_kernel<false, NLO, NHI>), grid, block, 0, stream, *args, dev_tab);
 	return (int)hipGetLastError();
+}
+
+/* mel_nlo / mel_nhi: the host's copy of the table shape (tables_q15.c picks 6+18 or 8+24) */
+extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int mel_nlo, int mel_nhi,
+                                  int stages, int n_cu, hipStream_t stream)
+{
+	if (mel_nlo == 6 && mel_nhi == 18)
+		return ed_launch_q15_shape<6, 18>(args, dev_tab, stages, n_cu, stream, &g_q15_blocks_per_cu[0]);
+	if (mel_nlo == ED_Q15_NLO_MAX && mel_nhi == ED_Q15_NHI_MAX)
+		return ed_launch_q15_shape<ED_Q15_NLO_MAX, ED_Q15_NHI_MAX>(args, dev_tab, stages, n_cu, stream, &g_q15_blocks_per_cu[1]);
+	return (int)hipErrorInvalidValue;
 }

@@ -79,28 +79,65 @@ int ed_build_q15_tables(double sample_rate, double lower_edge_hertz, double uppe
 	if (!W) return EDISON_E_NO_MEMORY;
 	int r = ed_gen_mel_weight_matrix(NMEL, nbins, sample_rate, lower_edge_hertz, upper_edge_hertz, W);
 	if (r != EDISON_OK) { free(W); return r; }
-	int pos = 0;
+	/* the firmware's compact form: per band the first non-zero bin and the number of non-zero entries; the generator
+	 * takes `count` consecutive entries from the first one (mfcc_on_mcu.py:44-48) */
+	int first[EDISON_NUM_MEL], cnt[EDISON_NUM_MEL], total = 0;
 	for (int m = 0; m < NMEL; m++)
 	{
-		int first = -1, cnt = 0;
+		first[m] = -1; cnt[m] = 0;
 		for (int k = 0; k < nbins; k++)
-			if ((int16_t)(scale * W[(size_t)k * NMEL + m]) != 0) { if (first < 0) first = k; cnt++; }
-		if (first < 0) first = 0;
-		if (pos + cnt > ED_Q15_MEL_COEF_MAX || first + cnt > nbins)
+			if ((int16_t)(scale * W[(size_t)k * NMEL + m]) != 0) { if (first[m] < 0) first[m] = k; cnt[m]++; }
+		if (first[m] < 0) first[m] = 0;
+		if (first[m] + cnt[m] > nbins)
 		{
-			if (err) snprintf(err, err_cap, "variant C: compact mel matrix does not fit (%d coefficients)", pos + cnt);
+			if (err) snprintf(err, err_cap, "variant C: band %d of the compact mel matrix runs past the spectrum", m);
 			free(W);
 			return EDISON_E_NO_IMPL;
 		}
-		out->mel_start[m] = first;
-		out->mel_count[m] = cnt;
-		out->mel_off[m] = pos;
-		if (first + cnt > nbins - 1) out->need_nyquist = 1;
-		/* the generator takes `count` consecutive entries from the first non-zero one (mfcc_on_mcu.py:44-48) */
-		for (int k = first; k < first + cnt; k++) out->mel_coef[pos++] = (int16_t)(scale * W[(size_t)k * NMEL + m]);
+		total += cnt[m];
+	}
+	int nlo = 1, nhi = 1;
+	for (int b = 0; b < 16; b++)
+	{
+		if ((cnt[b] + 3) / 4 > nlo) nlo = (cnt[b] + 3) / 4;
+		if ((cnt[31 - b] + 3) / 4 > nhi) nhi = (cnt[31 - b] + 3) / 4;
+	}
+	if (nlo > ED_Q15_NLO_MAX || nhi > ED_Q15_NHI_MAX)
+	{
+		if (err) snprintf(err, err_cap, "variant C: mel bands need %d+%d taps per lane, the kernel's budget is %d+%d", nlo, nhi,
+		                  ED_Q15_NLO_MAX, ED_Q15_NHI_MAX);
+		free(W);
+		return EDISON_E_NO_IMPL;
+	}
+	/* two compiled shapes (see edison_internal.h) */
+	if (nlo <= 6 && nhi <= 18) { nlo = 6; nhi = 18; } else { nlo = ED_Q15_NLO_MAX; nhi = ED_Q15_NHI_MAX; }
+	out->mel_nlo = nlo; out->mel_nhi = nhi;
+	for (int l = 0; l < 64; l++)
+	{
+		const int b = l & 15, rr = l >> 4;
+		for (int part = 0; part < 2; part++)
+		{
+			const int m = part == 0 ? b : 31 - b, N = part == 0 ? nlo : nhi;
+			const int per = (cnt[m] + 3) / 4;
+			const int k0 = first[m] + rr * per;                       /* this lane's run: [k0, k1) */
+			int k1 = k0 + per;
+			if (k1 > first[m] + cnt[m]) k1 = first[m] + cnt[m];
+			int s = k0;
+			if (s > nbins - N) s = nbins - N;                         /* keep every read inside spec[0..512] */
+			if (s < 0) s = 0;
+			if (part == 0) out->mel_lo_bin[l] = s; else out->mel_hi_bin[l] = s;
+			for (int t = 0; t < N; t++)
+			{
+				const int k = s + t;
+				const int mine = k >= k0 && k < k1 && k < nbins;
+				const int c = mine ? (int16_t)(scale * W[(size_t)k * NMEL + m]) : 0;
+				out->mel_tap[(part == 0 ? 0 : nlo) + t][l] = c;
+				if (c != 0 && k == nbins - 1) out->need_nyquist = 1;
+			}
+		}
 	}
 	free(W);
 	out->mel_scale = scale;
-	out->n_mel_coef = pos;
+	out->n_mel_coef = total;
 	return EDISON_OK;
 }

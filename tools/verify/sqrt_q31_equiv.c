@@ -1,0 +1,64 @@
+/*
+ * Exhaustive equivalence proof (by enumeration) for the GPU's formulation of arm_sqrt_q31.
+ *
+ * ref():  the sequence of CMSIS-DSP arm_sqrt_q31 (FastMathFunctions/arm_sqrt_q31.c:50-139) with its 64-bit products.
+ * fast(): what mfcc_q15_kernels.hip executes: every (a*b)>>31 becomes one unsigned high multiply with one operand
+ *         pre-doubled, valid as long as every intermediate stays in [0, 2^31).
+ * The program walks ALL 2^31-1 positive inputs (a superset of re^2+im^2) and compares the full 32-bit results.
+ *   gcc -O2 -fopenmp -o sqrt_q31_equiv sqrt_q31_equiv.c && ./sqrt_q31_equiv [stride]
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+static inline int32_t ref(int32_t in)
+{
+	if (in <= 0) return 0;
+	int sb = __builtin_clz((uint32_t)in) - 1;
+	int sh = (sb & 1) ? sb - 1 : sb;
+	int32_t number = (int32_t)((uint32_t)in << sh), half = number >> 1, keep = number;
+	union { int32_t i; float f; } cv;
+	cv.f = (float)number * 4.6566128731e-010f;
+	cv.i = 0x5f3759df - (cv.i >> 1);
+	int32_t v = (int32_t)(cv.f * 1073741824.0f);
+	for (int it = 0; it < 3; it++)
+	{
+		int32_t vv = (int32_t)(((int64_t)v * v) >> 31);
+		int32_t hv = (int32_t)(((int64_t)vv * (int64_t)half) >> 31);
+		v = (int32_t)((uint32_t)(int32_t)(((int64_t)v * (int64_t)(0x30000000 - hv)) >> 31) << 2);
+	}
+	v = (int32_t)((uint32_t)(int32_t)(((int64_t)keep * v) >> 31) << 1);
+	return v >> (sh / 2);
+}
+
+static inline uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+static inline int32_t fast(int32_t in)
+{
+	if (in <= 0) return 0;
+	const int sh = (__builtin_clz((uint32_t)in) - 1) & ~1;
+	const uint32_t number = (uint32_t)in << sh, number2 = number & ~1u; /* 2 * (number >> 1) */
+	union { int32_t i; float f; } cv;
+	cv.f = (float)(int32_t)number * 4.6566128731e-010f;
+	cv.i = 0x5f3759df - (cv.i >> 1);
+	uint32_t v = (uint32_t)(int32_t)(cv.f * 1073741824.0f);
+	for (int it = 0; it < 3; it++)
+	{
+		const uint32_t vv = mulhi(v << 1, v);
+		const uint32_t hv = mulhi(vv, number2);
+		v = mulhi(v, (0x30000000u - hv) << 1) << 2;
+	}
+	v = mulhi(number << 1, v) << 1;
+	return (int32_t)v >> (sh >> 1);
+}
+
+int main(int argc, char **argv)
+{
+	const int64_t stride = argc > 1 ? atoll(argv[1]) : 1;
+	int64_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+	for (int64_t x = 1; x < ((int64_t)1 << 31); x += stride)
+		if (ref((int32_t)x) != fast((int32_t)x)) bad++;
+	printf("stride %lld: %lld mismatches\n", (long long)stride, (long long)bad);
+	return bad != 0;
+}
