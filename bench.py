@@ -272,6 +272,11 @@ def main():
                                  unit="GB/s", frac=round(qach / HBM_PEAK_GBS, 4), traffic=None, bytes_per_unit=qbytes,
                                  units_per_launch=nf, kernel_ms=round(qev_ms, 4)),
                    checksum=int(out16.to(torch.int64).sum().item()))
+        q15["roofline"]["kernel"] = "ed_mfcc_q15_kernel<false, 6, 18>"
+        qtr = hbm_traffic_from_profiles("ed_mfcc_q15_kernel<false, 6, 18>:short") if nf == 65536 else None
+        if qtr is not None:
+            q15["roofline"]["traffic"] = qtr[0]
+            q15["roofline"]["traffic_source"] = qtr[1]
     del bufs
     # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
     # this command, FETCH_SIZE doubled as the gfx950 guide prescribes); only valid for the default batch size
