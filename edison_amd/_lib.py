@@ -21,6 +21,18 @@ CNN_ACT_BYTES = 10420
 c_void_p, c_int, c_int64, c_size_t, c_float, c_double, c_char_p = (
     ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float, ctypes.c_double, ctypes.c_char_p)
 
+class StreamOpts(ctypes.Structure):
+    """edison_stream_opts"""
+    _fields_ = [("hop", c_int), ("chunk_frames", c_int), ("mfcc_variant", c_int), ("filter", c_int),
+                ("filter_alpha", c_double), ("true_threshold", c_double)]
+
+
+class Fsm(ctypes.Structure):
+    """edison_fsm"""
+    _fields_ = [("state", c_int), ("hot_timeout_ms", ctypes.c_uint32), ("wake_idx", c_int), ("loc_idx", c_int),
+                ("val_idx", c_int), ("last_loc", c_int), ("last_val", c_int), ("commands", ctypes.c_uint32)]
+
+
 # name -> (restype, argtypes): every symbol include/edison_hip.h declares
 SIGNATURES = {
     "edison_init": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
@@ -62,6 +74,12 @@ SIGNATURES = {
     "edison_stream_push_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "edison_stream_push": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "edison_stream_frames_seen": (c_int64, [c_void_p]),
+    "edison_stream_default_opts": (None, [ctypes.POINTER(StreamOpts)]),
+    "edison_stream_create_ex": (c_int, [c_void_p, ctypes.POINTER(StreamOpts), ctypes.POINTER(c_void_p)]),
+    "edison_stream_filtered": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_stream_filtered_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_fsm_init": (None, [ctypes.POINTER(Fsm)]),
+    "edison_fsm_step": (c_int, [ctypes.POINTER(Fsm), c_float, ctypes.c_uint32, ctypes.c_uint32, c_double]),
     # legacy firmware call surface
     "aiInitialize": (c_int, []),
     "aiGetInputShape": (None, [ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint16)]),

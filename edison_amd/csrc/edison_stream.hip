@@ -4,15 +4,17 @@
  *
  *     per new 1024-sample frame:  audioCalcMFCCs -> mfccToNetInputPush (drop the oldest of 31 rows, append the
  *                                 newest, app.c:706-719) -> aiRunInference on the 31 x 13 window
+ *                                 -> moving average over the outputs, arm_max_f32, threshold (app.c:341-356)
  *
  * Here a push delivers `chunk` hops of new samples at once (chunk = 1 for lowest latency, thousands for
  * throughput). Frames may overlap (hop 512 = the 50 % overlap of BASELINE config 5; hop 1024 = the shipped
- * firmware cadence, audio/config.py:27). Device-resident state: the last 1024 - hop samples and the last 30
- * feature rows. The sliding window is never copied per frame: window i of a push is rows i..i+30 of one
- * [30 + chunk][13] int8 buffer, which the CNN kernel reads with a 13-byte "utterance" stride.
+ * firmware cadence, audio/config.py:27). Device-resident state: the last 1024 - hop samples, the last 30
+ * feature rows and the ten filtered outputs. The sliding window is never copied per frame: window i of a push is
+ * rows i..i+30 of one [30 + chunk][13] int8 buffer, which the CNN kernel reads with a 13-byte "utterance" stride.
  *
- * The three device operations of a push (MFCC kernel, CNN kernel, history shift) are captured ONCE into a hipGraph
- * and replayed per push. The net input starts as zeros like the firmware's static netInput buffer.
+ * The device operations of a push (MFCC kernel, CNN kernel, output filter, history shift) are captured ONCE into a
+ * hipGraph and replayed per push. The net input starts as zeros like the firmware's static netInput buffer, the
+ * filter state as zeros like netOutFilt (app.c:299-300).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -23,11 +25,18 @@ struct edison_stream
 {
 	edison_ctx *ctx;
 	int hop, chunk, tail; /* tail = 1024 - hop samples of history */
+	int variant;          /* EDISON_MFCC_B or EDISON_MFCC_C */
+	int filter;
+	double alpha, one_minus_alpha, threshold;
 	int16_t *d_audio;     /* [tail + chunk*hop]                      */
 	int8_t *d_feat;       /* [(30 + chunk) * 13]                     */
 	int8_t *d_soft;       /* [chunk * 10]                            */
 	int8_t *d_logits;     /* [chunk * 10]                            */
 	int32_t *d_argmax;    /* [chunk]                                 */
+	float *d_filt_state;  /* [10]  netOutFilt                        */
+	float *d_filt;        /* [chunk * 10] netOutFilt after each inference of the push */
+	int32_t *d_likely;    /* [chunk] arm_max_f32 index               */
+	int32_t *d_spotted;   /* [chunk] that index if the maximum exceeds the threshold, else -1 */
 	hipStream_t own;      /* the graph always runs on this private stream (the default stream cannot be captured);  */
 	hipEvent_t ev_in, ev_out; /* ordered against the context's current stream with events                      */
 	hipGraph_t graph;
@@ -49,9 +58,52 @@ __global__ void ed_stream_shift_kernel(int16_t *audio, int tail, int new_samples
 	for (int i = 0; i < 2; i++) { const int j = t + i * 256; if (j < 30 * EDISON_NUM_MFCC) feat[j] = f[i]; }
 }
 
+/*
+ * The firmware's post-processing of the network output (app.c:332-356), for the `chunk` inferences of a push:
+ *   netOutFloat[i] = (float)netOutput[i]
+ *   netOutFilt[i]  = (ALPHA*netOutFilt[i] + (1.0-ALPHA)*netOutFloat[i])      double arithmetic (the constants are
+ *                                                                           doubles), rounded to float on the store
+ *   arm_max_f32(netOutFilt, 10, &predMax, &predMaxIdx)                      first maximum
+ *   spotted = predMax > TRUE_THRESHOLD
+ * The recurrence rounds at every step, so it is sequential in time by definition; the ten classes run on ten
+ * lanes, the products (1-ALPHA)*x come from a 256-entry table (x is an int8), and the per-frame maximum is taken in
+ * parallel afterwards. One workgroup.
+ */
+__global__ __launch_bounds__(256) void ed_stream_filter_kernel(const int8_t *soft, int chunk, double alpha, double one_minus_alpha,
+                                                               double threshold, float *state, float *filt, int32_t *likely,
+                                                               int32_t *spotted)
+{
+	__shared__ double bx[256];
+	const int t = threadIdx.x;
+	bx[t] = __dmul_rn(one_minus_alpha, (double)(float)(int8_t)(t - 128));
+	__syncthreads();
+	if (t < EDISON_NET_OUT)
+	{
+		float y = state[t];
+		for (int i = 0; i < chunk; i++)
+		{
+			const int x = soft[(size_t)i * EDISON_NET_OUT + t];
+			y = (float)__dadd_rn(__dmul_rn(alpha, (double)y), bx[x + 128]);
+			filt[(size_t)i * EDISON_NET_OUT + t] = y;
+		}
+		state[t] = y;
+	}
+	__syncthreads();
+	for (int i = t; i < chunk; i += 256)
+	{
+		const float *row = filt + (size_t)i * EDISON_NET_OUT;
+		float best = row[0];
+		int idx = 0;
+		for (int c = 1; c < EDISON_NET_OUT; c++)
+			if (best < row[c]) { best = row[c]; idx = c; }
+		likely[i] = idx;
+		spotted[i] = ((double)best > threshold) ? idx : -1;
+	}
+}
+
 static int enqueue_push_on_ctx_stream(edison_stream *s);
 
-/* enqueue the three device operations of a push on the stream's private hipStream */
+/* enqueue the device operations of a push on the stream's private hipStream */
 static int enqueue_push(edison_stream *s)
 {
 	hipStream_t saved = s->ctx->stream;
@@ -64,13 +116,19 @@ static int enqueue_push(edison_stream *s)
 static int enqueue_push_on_ctx_stream(edison_stream *s)
 {
 	edison_ctx *ctx = s->ctx;
-	/* variant B, 13 coefficients, int8 net input (scale 1): rows 30.. of the feature buffer */
-	int r = ed_ctx_mfcc_launch(ctx, s->d_audio, s->chunk, s->chunk, 0, s->hop, EDISON_MFCC_B, EDISON_NUM_MFCC, NULL,
+	/* 13 coefficients, int8 net input (scale 1): rows 30.. of the feature buffer */
+	int r = ed_ctx_mfcc_launch(ctx, s->d_audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
 	                           s->d_feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
 	if (r != EDISON_OK) return r;
 	int e = ed_launch_cnn_mfma(ctx->d_model_mfma, s->d_feat, s->chunk, EDISON_NUM_MFCC, s->d_logits, s->d_soft, s->d_argmax,
 	                           ctx->n_cu, ctx->stream);
 	if (e != 0) return ed_set_err(ctx, EDISON_E_RUNTIME, "stream: CNN launch failed");
+	if (s->filter)
+	{
+		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, ctx->stream, s->d_soft, s->chunk, s->alpha,
+		                   s->one_minus_alpha, s->threshold, s->d_filt_state, s->d_filt, s->d_likely, s->d_spotted);
+		if (hipGetLastError() != hipSuccess) return ed_set_err(ctx, EDISON_E_RUNTIME, "stream: filter launch failed");
+	}
 	hipLaunchKernelGGL(ed_stream_shift_kernel, dim3(1), dim3(256), 0, ctx->stream, s->d_audio, s->tail, s->chunk * s->hop,
 	                   s->d_feat, s->chunk);
 	return hipGetLastError() == hipSuccess ? EDISON_OK : ed_set_err(ctx, EDISON_E_RUNTIME, "stream: shift launch failed");
@@ -87,6 +145,10 @@ extern "C" void edison_stream_destroy(edison_stream *s)
 	if (s->d_soft) (void)hipFree(s->d_soft);
 	if (s->d_logits) (void)hipFree(s->d_logits);
 	if (s->d_argmax) (void)hipFree(s->d_argmax);
+	if (s->d_filt_state) (void)hipFree(s->d_filt_state);
+	if (s->d_filt) (void)hipFree(s->d_filt);
+	if (s->d_likely) (void)hipFree(s->d_likely);
+	if (s->d_spotted) (void)hipFree(s->d_spotted);
 	if (s->ev_in) (void)hipEventDestroy(s->ev_in);
 	if (s->ev_out) (void)hipEventDestroy(s->ev_out);
 	if (s->own) (void)hipStreamDestroy(s->own);
@@ -99,21 +161,44 @@ extern "C" int edison_stream_reset(edison_stream *s)
 	edison_ctx *ctx = s->ctx;
 	ED_HIP(ctx, hipMemsetAsync(s->d_audio, 0, sizeof(int16_t) * (size_t)(s->tail + s->chunk * s->hop), s->own));
 	ED_HIP(ctx, hipMemsetAsync(s->d_feat, 0, (size_t)(30 + s->chunk) * EDISON_NUM_MFCC, s->own));
+	if (s->filter) ED_HIP(ctx, hipMemsetAsync(s->d_filt_state, 0, sizeof(float) * EDISON_NET_OUT, s->own));
 	ED_HIP(ctx, hipStreamSynchronize(s->own));
 	s->frames_seen = 0;
 	return EDISON_OK;
 }
 
-extern "C" int edison_stream_create(edison_ctx *ctx, int hop, int chunk_frames, edison_stream **out)
+extern "C" void edison_stream_default_opts(edison_stream_opts *o)
 {
-	if (!ctx || !out) return EDISON_E_ARGUMENT;
+	if (!o) return;
+	memset(o, 0, sizeof(*o));
+	o->hop = EDISON_FRAME_LEN;
+	o->chunk_frames = 1;
+	o->mfcc_variant = EDISON_MFCC_B;
+	o->filter = 0;
+	o->filter_alpha = 0.9;   /* NET_OUT_MOVING_AVG_ALPHA for NET_TYPE_NNOM, app.c:38 */
+	o->true_threshold = 0.5; /* TRUE_THRESHOLD, app.c:34 */
+}
+
+extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts *o, edison_stream **out)
+{
+	if (!ctx || !out || !o) return EDISON_E_ARGUMENT;
 	*out = NULL;
+	const int hop = o->hop, chunk_frames = o->chunk_frames;
 	if (!ctx->have_model) return ed_set_err(ctx, EDISON_E_NO_MODEL, "no CNN model loaded (edison_model_load)");
 	if (hop < 2 || hop > EDISON_FRAME_LEN || (hop & 1) || chunk_frames < 1 || chunk_frames > (1 << 22))
 		return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: hop must be even and 2..1024, chunk 1..4M frames");
+	if (o->mfcc_variant != EDISON_MFCC_B && o->mfcc_variant != EDISON_MFCC_C)
+		return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: MFCC variant must be EDISON_MFCC_B or EDISON_MFCC_C");
+	if (o->filter && !(o->filter_alpha >= 0.0 && o->filter_alpha <= 1.0))
+		return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: filter_alpha must be within [0, 1]");
 	edison_stream *s = (edison_stream *)calloc(1, sizeof(edison_stream));
 	if (!s) return ed_set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed");
 	s->ctx = ctx; s->hop = hop; s->chunk = chunk_frames; s->tail = EDISON_FRAME_LEN - hop;
+	s->variant = o->mfcc_variant;
+	s->filter = o->filter ? 1 : 0;
+	s->alpha = o->filter_alpha;
+	s->one_minus_alpha = 1.0 - o->filter_alpha; /* the firmware's (1.0-NET_OUT_MOVING_AVG_ALPHA), folded in double */
+	s->threshold = o->true_threshold;
 	hipError_t e = hipSetDevice(ctx->device);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
@@ -123,6 +208,13 @@ extern "C" int edison_stream_create(edison_ctx *ctx, int hop, int chunk_frames, 
 	if (e == hipSuccess) e = hipMalloc((void **)&s->d_soft, (size_t)s->chunk * EDISON_NET_OUT + 16);
 	if (e == hipSuccess) e = hipMalloc((void **)&s->d_logits, (size_t)s->chunk * EDISON_NET_OUT + 16);
 	if (e == hipSuccess) e = hipMalloc((void **)&s->d_argmax, sizeof(int32_t) * (size_t)s->chunk);
+	if (s->filter)
+	{
+		if (e == hipSuccess) e = hipMalloc((void **)&s->d_filt_state, sizeof(float) * EDISON_NET_OUT);
+		if (e == hipSuccess) e = hipMalloc((void **)&s->d_filt, sizeof(float) * (size_t)s->chunk * EDISON_NET_OUT);
+		if (e == hipSuccess) e = hipMalloc((void **)&s->d_likely, sizeof(int32_t) * (size_t)s->chunk);
+		if (e == hipSuccess) e = hipMalloc((void **)&s->d_spotted, sizeof(int32_t) * (size_t)s->chunk);
+	}
 	if (e != hipSuccess)
 	{
 		edison_stream_destroy(s);
@@ -151,6 +243,15 @@ extern "C" int edison_stream_create(edison_ctx *ctx, int hop, int chunk_frames, 
 	if (r != EDISON_OK) { edison_stream_destroy(s); return r; }
 	*out = s;
 	return EDISON_OK;
+}
+
+extern "C" int edison_stream_create(edison_ctx *ctx, int hop, int chunk_frames, edison_stream **out)
+{
+	edison_stream_opts o;
+	edison_stream_default_opts(&o);
+	o.hop = hop;
+	o.chunk_frames = chunk_frames;
+	return edison_stream_create_ex(ctx, &o, out);
 }
 
 /* samples: chunk*hop NEW int16 samples in device memory. Outputs (device, each may be NULL): softmax / logits
@@ -190,6 +291,36 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 	ED_HIP(ctx, hipStreamSynchronize(s->own));
 	s->frames_seen += s->chunk;
 	return EDISON_OK;
+}
+
+/* Filtered outputs of the LAST push (filter enabled in the options): filt [chunk][10] fp32, likely / spotted [chunk].
+ * host = 1: host pointers, synchronous; host = 0: device pointers, ordered on the context's stream like a push. */
+static int stream_filter_out(edison_stream *s, float *filt, int32_t *likely, int32_t *spotted, int host)
+{
+	if (!s) return EDISON_E_ARGUMENT;
+	edison_ctx *ctx = s->ctx;
+	if (!s->filter) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: created without the output filter");
+	const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+	if (filt) ED_HIP(ctx, hipMemcpyAsync(filt, s->d_filt, sizeof(float) * (size_t)s->chunk * EDISON_NET_OUT, kind, s->own));
+	if (likely) ED_HIP(ctx, hipMemcpyAsync(likely, s->d_likely, sizeof(int32_t) * (size_t)s->chunk, kind, s->own));
+	if (spotted) ED_HIP(ctx, hipMemcpyAsync(spotted, s->d_spotted, sizeof(int32_t) * (size_t)s->chunk, kind, s->own));
+	if (host) ED_HIP(ctx, hipStreamSynchronize(s->own));
+	else
+	{
+		ED_HIP(ctx, hipEventRecord(s->ev_out, s->own));
+		ED_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_out, 0));
+	}
+	return EDISON_OK;
+}
+
+extern "C" int edison_stream_filtered(edison_stream *s, float *filt, int32_t *likely, int32_t *spotted)
+{
+	return stream_filter_out(s, filt, likely, spotted, 1);
+}
+
+extern "C" int edison_stream_filtered_dev(edison_stream *s, float *filt, int32_t *likely, int32_t *spotted)
+{
+	return stream_filter_out(s, filt, likely, spotted, 0);
 }
 
 extern "C" int64_t edison_stream_frames_seen(const edison_stream *s) { return s ? s->frames_seen : -1; }

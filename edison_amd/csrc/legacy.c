@@ -174,3 +174,67 @@ int edison_mfcc_frame(const int16_t *frame1024, int variant, float *out32)
 	}
 	return edison_mfcc_batch(g_ctx, frame1024, 1, EDISON_FRAME_LEN, variant, EDISON_NUM_MEL, out32, NULL, 1.0f);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * edisonFSM (firmware/src/app.c:727-928) without the LED strip: the keyword roles are the firmware's tables
+ * (ediLocations / ediValues, app.c:135-147; EDI_WAKEWORD, app.c:50), resolved by name against the keyword list
+ * exactly like the EDI_RESET state does (app.c:770-784).
+ */
+#define EDI_LOC_TIMEOUT_MS 5000u /* app.c:48 */
+static const char *const g_fsm_locations[] = {"cinema", "bedroom", "office", "livingroom", "kitchen", NULL};
+static const char *const g_fsm_values[] = {"off", "on", NULL};
+static const char *const g_fsm_wakeword = "edison";
+
+static int fsm_role(const char *const *names, uint32_t keyword_idx)
+{
+	if (keyword_idx >= EDISON_NET_OUT) return 0;
+	for (int i = 0; names[i]; i++)
+		if (strcmp(names[i], g_keywords[keyword_idx]) == 0) return 1;
+	return 0;
+}
+
+void edison_fsm_init(edison_fsm *f)
+{
+	if (!f) return;
+	memset(f, 0, sizeof(*f));
+	f->state = EDISON_FSM_RESET;
+	f->wake_idx = f->loc_idx = f->val_idx = f->last_loc = f->last_val = -1;
+}
+
+int edison_fsm_step(edison_fsm *f, float pred_max, uint32_t pred_idx, uint32_t dt_us, double true_threshold)
+{
+	if (!f) return EDISON_E_ARGUMENT;
+	int next = f->state;
+	const int hit = (double)pred_max > true_threshold;
+	switch (f->state)
+	{
+	case EDISON_FSM_RESET: /* app.c:766-791 */
+		for (int i = 0; i < EDISON_NET_OUT; i++)
+			if (strcmp(g_keywords[i], g_fsm_wakeword) == 0) f->wake_idx = i;
+		next = EDISON_FSM_IDLE;
+		break;
+	case EDISON_FSM_IDLE: /* app.c:793-800 */
+		if (hit && (int)pred_idx == f->wake_idx) { f->hot_timeout_ms = 0; next = EDISON_FSM_HOT; }
+		break;
+	case EDISON_FSM_HOT: /* app.c:801-824 */
+		f->hot_timeout_ms += dt_us / 1000u;
+		if (hit && fsm_role(g_fsm_locations, pred_idx)) { f->loc_idx = (int)pred_idx; f->hot_timeout_ms = 0; next = EDISON_FSM_LOC; }
+		if (f->hot_timeout_ms > EDI_LOC_TIMEOUT_MS) next = EDISON_FSM_IDLE;
+		break;
+	case EDISON_FSM_LOC: /* app.c:826-848: a value found at the very call that times out is dropped */
+		f->hot_timeout_ms += dt_us / 1000u;
+		if (hit && fsm_role(g_fsm_values, pred_idx)) { f->val_idx = (int)pred_idx; next = EDISON_FSM_SET; }
+		if (f->hot_timeout_ms > EDI_LOC_TIMEOUT_MS) next = EDISON_FSM_IDLE;
+		break;
+	case EDISON_FSM_SET: /* app.c:850-872: "set location to required value", then idle */
+		f->last_loc = f->loc_idx;
+		f->last_val = f->val_idx;
+		f->commands++;
+		next = EDISON_FSM_IDLE;
+		break;
+	default:
+		return EDISON_E_ARGUMENT;
+	}
+	f->state = next;
+	return next;
+}

@@ -5,6 +5,11 @@ Counterpart of the firmware's continuous mode (firmware/src/app.c:288-371, 635-7
 31 MFCC rows. Note the reference's host mirror *prepends* new rows (kws_on_mcu.py:558-567) while the firmware
 *appends* them (app.c:706-719); this stream follows the firmware (oldest row first), which is also the order the
 network was trained on.
+
+``q15=True`` computes the features with the firmware's own Q15 arithmetic (MFCC variant C) instead of the host
+float model; ``output_filter=True`` adds the firmware's post-processing of the network output (moving average,
+maximum, threshold: app.c:332-356). ``Fsm`` is the firmware's wake-word / location / value state machine
+(app.c:727-928) without the LEDs.
 """
 import ctypes
 
@@ -16,14 +21,20 @@ from .context import KEYWORDS, default_context
 
 
 class Stream:
-    def __init__(self, ctx=None, hop=FRAME_LEN, chunk_frames=1):
+    def __init__(self, ctx=None, hop=FRAME_LEN, chunk_frames=1, q15=False, output_filter=False, alpha=0.9,
+                 threshold=0.5):
         self.ctx = ctx or default_context()
         self._L = _lib.lib()
+        o = _lib.StreamOpts()
+        self._L.edison_stream_default_opts(ctypes.byref(o))
+        o.hop, o.chunk_frames = int(hop), int(chunk_frames)
+        o.mfcc_variant = _lib.MFCC_C if q15 else _lib.MFCC_B
+        o.filter = 1 if output_filter else 0
+        o.filter_alpha, o.true_threshold = float(alpha), float(threshold)
         h = ctypes.c_void_p()
-        r = self._L.edison_stream_create(self.ctx._h, int(hop), int(chunk_frames), ctypes.byref(h))
-        self.ctx._check(r)
+        self.ctx._check(self._L.edison_stream_create_ex(self.ctx._h, ctypes.byref(o), ctypes.byref(h)))
         self._h = h
-        self.hop, self.chunk = int(hop), int(chunk_frames)
+        self.hop, self.chunk, self.output_filter = int(hop), int(chunk_frames), bool(output_filter)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -44,7 +55,8 @@ class Stream:
         return int(self._L.edison_stream_frames_seen(self._h))
 
     def push(self, samples):
-        """samples: chunk_frames*hop new int16 samples (host). Returns dict(logits, softmax, argmax, keywords)."""
+        """samples: chunk_frames*hop new int16 samples (host). Returns dict(logits, softmax, argmax, keywords) plus,
+        with the output filter, filtered [chunk,10] fp32, likely [chunk], spotted [chunk] (-1 = below threshold)."""
         x = np.ascontiguousarray(samples, dtype=np.int16).ravel()
         if x.shape[0] != self.chunk * self.hop:
             raise ValueError("push needs exactly chunk_frames*hop = %d samples" % (self.chunk * self.hop))
@@ -53,11 +65,51 @@ class Stream:
         am = np.zeros(self.chunk, np.int32)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         self.ctx._check(self._L.edison_stream_push(self._h, p(x), p(logits), p(soft), p(am)))
-        return dict(logits=logits, softmax=soft, argmax=am, keywords=[KEYWORDS[i] for i in am])
+        out = dict(logits=logits, softmax=soft, argmax=am, keywords=[KEYWORDS[i] for i in am])
+        if self.output_filter:
+            filt = np.zeros((self.chunk, NET_OUT), np.float32)
+            likely, spotted = np.zeros(self.chunk, np.int32), np.zeros(self.chunk, np.int32)
+            self.ctx._check(self._L.edison_stream_filtered(self._h, p(filt), p(likely), p(spotted)))
+            out.update(filtered=filt, likely=likely, spotted=spotted)
+        return out
 
-    def push_t(self, samples, logits=None, softmax=None, argmax=None):
-        """Device tensors (torch, int16 / int8 / int32 on the context's GPU); asynchronous on the context's stream."""
+    def push_t(self, samples, logits=None, softmax=None, argmax=None, filtered=None, likely=None, spotted=None):
+        """Device tensors (torch, int16 / int8 / int32 / fp32 on the context's GPU); asynchronous on the context's stream."""
         if samples.numel() != self.chunk * self.hop:
             raise ValueError("push needs exactly chunk_frames*hop = %d samples" % (self.chunk * self.hop))
         q = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         self.ctx._check(self._L.edison_stream_push_dev(self._h, q(samples), q(logits), q(softmax), q(argmax)))
+        if filtered is not None or likely is not None or spotted is not None:
+            self.ctx._check(self._L.edison_stream_filtered_dev(self._h, q(filtered), q(likely), q(spotted)))
+
+
+class Fsm:
+    """edisonFSM (app.c:727-928): RESET -> IDLE -> HOT (wake word) -> LOC (location) -> SET (value) -> IDLE."""
+    STATES = ("RESET", "IDLE", "HOT", "LOC", "SET")
+
+    def __init__(self, threshold=0.5):
+        self._L = _lib.lib()
+        self._f = _lib.Fsm()
+        self._L.edison_fsm_init(ctypes.byref(self._f))
+        self.threshold = float(threshold)
+
+    def step(self, pred_max, pred_idx, dt_us):
+        r = self._L.edison_fsm_step(ctypes.byref(self._f), float(pred_max), int(pred_idx), int(dt_us), self.threshold)
+        if r < 0:
+            raise EdisonError(r, "edison_fsm_step")
+        return self.STATES[r]
+
+    @property
+    def state(self):
+        return self.STATES[self._f.state]
+
+    @property
+    def last_command(self):
+        """(location, value) keyword strings of the last executed command, or None."""
+        if self._f.last_loc < 0:
+            return None
+        return KEYWORDS[self._f.last_loc], KEYWORDS[self._f.last_val]
+
+    @property
+    def commands(self):
+        return int(self._f.commands)

@@ -195,6 +195,49 @@ int edison_stream_push(edison_stream *s, const int16_t *samples /* host */, int8
                        int32_t *argmax);
 int64_t edison_stream_frames_seen(const edison_stream *s);
 
+/* Stream options beyond hop / chunk. mfcc_variant: EDISON_MFCC_B (host float model, default) or EDISON_MFCC_C (the
+ * firmware's own Q15 features). filter = 1 adds the firmware's output post-processing to every inference of a push
+ * (app.c:332-356): netOutFilt[c] = (float)(alpha*netOutFilt[c] + (1.0-alpha)*(float)netOutput[c]) in double
+ * arithmetic, arm_max_f32 (first maximum) over the ten filtered outputs, "spotted" if that maximum exceeds
+ * true_threshold. Defaults (edison_stream_default_opts): alpha 0.9 = NET_OUT_MOVING_AVG_ALPHA for NNoM (app.c:38),
+ * threshold 0.5 = TRUE_THRESHOLD (app.c:34); the filter state starts at zero (app.c:299-300) and survives pushes. */
+typedef struct edison_stream_opts
+{
+	int hop, chunk_frames;
+	int mfcc_variant;
+	int filter;
+	double filter_alpha;
+	double true_threshold;
+} edison_stream_opts;
+void edison_stream_default_opts(edison_stream_opts *o);
+int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts *o, edison_stream **out);
+/* Filtered outputs of the LAST push: filt [chunk][10] fp32 (netOutFilt after each inference), likely [chunk] int32
+ * (predMaxIdx), spotted [chunk] int32 (predMaxIdx where predMax > threshold, else -1). Each may be NULL. */
+int edison_stream_filtered(edison_stream *s, float *filt /* host */, int32_t *likely, int32_t *spotted);
+int edison_stream_filtered_dev(edison_stream *s, float *filt /* device */, int32_t *likely, int32_t *spotted);
+
+/* ---- the firmware's home-automation state machine (edisonFSM, app.c:727-928), host side, without the LEDs -------
+ * RESET -> IDLE -(wake word "edison" spotted)-> HOT -(a location spotted)-> LOC -(a value spotted)-> SET -> IDLE;
+ * HOT and LOC fall back to IDLE after EDI_LOC_TIMEOUT = 5000 ms (app.c:48). Time advances by dt_us per call exactly
+ * like the firmware's `hotTimeout += dt/1000` (integer milliseconds per call). One step per inference. */
+#define EDISON_FSM_RESET 0
+#define EDISON_FSM_IDLE 1
+#define EDISON_FSM_HOT 2
+#define EDISON_FSM_LOC 3
+#define EDISON_FSM_SET 4
+typedef struct edison_fsm
+{
+	int state;
+	uint32_t hot_timeout_ms;
+	int wake_idx;
+	int loc_idx, val_idx;       /* keyword indices of the pending location / value */
+	int last_loc, last_val;     /* the last executed command (keyword indices), -1 before the first */
+	uint32_t commands;          /* how many "location value" commands were executed */
+} edison_fsm;
+void edison_fsm_init(edison_fsm *f);
+/* pred_max / pred_idx: arm_max_f32 of the filtered outputs; returns the new state. */
+int edison_fsm_step(edison_fsm *f, float pred_max, uint32_t pred_idx, uint32_t dt_us, double true_threshold);
+
 /* ---- legacy call surface of the reference firmware (batch = 1, process-global context) --------------- */
 /* firmware/src/ai/ai.h:74-80. aiInitialize() creates the global context on device $EDISON_DEVICE (default 0)
  * and loads $EDISON_MODEL (default: kws_nnom.ednn next to the library). in_data: 403 int8, out_data: 10 int8. */

@@ -93,6 +93,11 @@ int oracle_cnn_run(const oracle_layer_t *layers, int n_layers, int in_h, int in_
                    const int8_t *in, int64_t n, int8_t *acts, int64_t acts_stride,
                    int8_t *logits, int8_t *softmax, int32_t *argmax, int n_threads);
 
+/* app.c:332-356 for n consecutive inferences: state[10] (netOutFilt) is read and updated; filt [n][10], likely [n],
+ * spotted [n] may be NULL. */
+void oracle_output_filter(const int8_t *soft, int64_t n, double alpha, double threshold, float *state, float *filt,
+                          int32_t *likely, int32_t *spotted);
+
 int oracle_num_threads(void);
 
 #ifdef __cplusplus

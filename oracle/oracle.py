@@ -35,7 +35,7 @@ def build(force=False):
     """Compile the restatement (always possible: gcc only) and, when the reference is mounted, the reference."""
     if force or not os.path.exists(PORT_SO) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(PORT_SO)
-            for f in ("mfcc_ref.c", "mfcc_q15_ref.c", "kws_cnn_ref.c", "oracle.h")):
+            for f in ("mfcc_ref.c", "mfcc_q15_ref.c", "kws_cnn_ref.c", "postproc_ref.c", "oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "-B", "port"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/firmware") and (force or not os.path.exists(REF_SO)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -84,6 +84,9 @@ def port():
         L.oracle_mfcc_q15.restype = ctypes.c_int
         L.oracle_mfcc_q15.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.oracle_output_filter.restype = None
+        L.oracle_output_filter.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.oracle_net_input_q15.restype = None
         L.oracle_net_input_q15.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -227,6 +230,17 @@ def net_input_q15(mfcc_rows, n_coef=NUM_MFCC, scale=1, clip_lo=-128, clip_hi=127
     out = np.zeros((n, n_coef), np.int8)
     port().oracle_net_input_q15(_p(m), n, stride, n_coef, scale, clip_lo, clip_hi, _p(out))
     return out
+
+
+def output_filter(softmax, state=None, alpha=0.9, threshold=0.5):
+    """app.c:332-356 over consecutive int8 softmax rows; returns (filt [n,10] f32, likely [n], spotted [n], state [10])."""
+    s = np.ascontiguousarray(softmax, dtype=np.int8).reshape(-1, 10)
+    n = s.shape[0]
+    st = np.zeros(10, np.float32) if state is None else np.array(state, dtype=np.float32)
+    filt = np.zeros((n, 10), np.float32)
+    likely, spotted = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    port().oracle_output_filter(_p(s), n, float(alpha), float(threshold), _p(st), _p(filt), _p(likely), _p(spotted))
+    return filt, likely, spotted, st
 
 
 # -------------------------------------------------------------------------------------------- CNN

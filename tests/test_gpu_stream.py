@@ -43,6 +43,41 @@ def test_stream_matches_batch_windows(ctx, oracle_mod, oracle_model, hop, chunk)
     st.close()
 
 
+@pytest.mark.parametrize("hop,chunk", [(1024, 1), (512, 6)])
+def test_stream_q15_and_output_filter(ctx, oracle_mod, oracle_model, hop, chunk):
+    """Continuous mode as the firmware runs it: variant C features (audioCalcMFCCs), sliding window, inference, then the
+    output post-processing of app.c:332-356 (moving average in double arithmetic, first maximum, threshold) -- the
+    filtered floats must equal the oracle's bit for bit, with the filter state carried across pushes."""
+    from edison_amd.stream import Stream
+    rng = np.random.default_rng(7 * hop + chunk)
+    n_push = 12
+    n_frames = n_push * chunk
+    audio = np.clip(rng.normal(0, 2500, n_frames * hop), -32768, 32767).astype(np.int16)
+    st = Stream(ctx, hop=hop, chunk_frames=chunk, q15=True, output_filter=True)
+    outs = [st.push(audio[i * chunk * hop:(i + 1) * chunk * hop]) for i in range(n_push)]
+    soft = np.concatenate([o["softmax"] for o in outs])
+    full = np.concatenate([np.zeros(1024 - hop, np.int16), audio])
+    feat = oracle_mod.net_input_q15(oracle_mod.mfcc_q15(full, n_frames=n_frames, frame_step=hop, n_threads=4))
+    o = oracle_mod.cnn(oracle_model, _windows_from_features(feat), n_threads=4)
+    assert np.array_equal(soft, o["softmax"])
+    filt, likely, spotted, _ = oracle_mod.output_filter(soft)
+    assert np.array_equal(np.concatenate([x["filtered"] for x in outs]).view(np.uint32), filt.view(np.uint32))
+    assert np.array_equal(np.concatenate([x["likely"] for x in outs]), likely)
+    assert np.array_equal(np.concatenate([x["spotted"] for x in outs]), spotted)
+    # reset clears netOutFilt as the firmware does when the mode starts (app.c:299-300)
+    st.reset()
+    again = st.push(audio[:chunk * hop])
+    assert np.array_equal(again["filtered"], outs[0]["filtered"])
+    st.close()
+    # a different alpha / threshold
+    st = Stream(ctx, hop=hop, chunk_frames=chunk, output_filter=True, alpha=0.5, threshold=40.0)
+    outs = [st.push(audio[i * chunk * hop:(i + 1) * chunk * hop]) for i in range(4)]
+    filt, likely, spotted, _ = oracle_mod.output_filter(np.concatenate([x["softmax"] for x in outs]), alpha=0.5, threshold=40.0)
+    assert np.array_equal(np.concatenate([x["filtered"] for x in outs]), filt)
+    assert np.array_equal(np.concatenate([x["spotted"] for x in outs]), spotted)
+    st.close()
+
+
 def test_stream_utterance_equals_kws(ctx, kws_golden):
     """Feeding the 31 frames of the reference wav (hop 1024) ends on the same decision as the batch KWS call."""
     from edison_amd.stream import Stream

@@ -122,6 +122,90 @@ def test_legacy_glue_host_side(built_lib):
     assert (np.frombuffer(buf, dtype=np.int8).reshape(31, 13)[4] == 77).all()
 
 
+def _py_fsm(events, thr=0.5):
+    """Independent restatement of edisonFSM's transitions (app.c:756-872) for the scenario test below.
+    events: (pred_max, pred_idx, dt_us); returns the state after each call and the executed commands."""
+    LOC, VAL, WAKE, TIMEOUT = {1, 2, 3, 4, 5}, {6, 7}, 0, 5000
+    state, timeout, loc, val, states, cmds = "RESET", 0, None, None, [], []
+    for mx, idx, dt in events:
+        hit = mx > thr
+        nxt = state
+        if state == "RESET":
+            nxt = "IDLE"
+        elif state == "IDLE":
+            if hit and idx == WAKE:
+                timeout, nxt = 0, "HOT"
+        elif state == "HOT":
+            timeout += dt // 1000
+            if hit and idx in LOC:
+                loc, timeout, nxt = idx, 0, "LOC"
+            if timeout > TIMEOUT:
+                nxt = "IDLE"
+        elif state == "LOC":
+            timeout += dt // 1000
+            if hit and idx in VAL:
+                val, nxt = idx, "SET"
+            if timeout > TIMEOUT:
+                nxt = "IDLE"
+        elif state == "SET":
+            cmds.append((loc, val))
+            nxt = "IDLE"
+        state = nxt
+        states.append(state)
+    return states, cmds
+
+
+def test_fsm_scenarios(built_lib):
+    """edisonFSM without the LEDs (host C, no GPU): wake word -> location -> value, the 5 s timeouts, the truncating
+    `hotTimeout += dt/1000`, a value that arrives on the very call that times out, non-keywords ignored."""
+    from edison_amd.stream import Fsm
+    from edison_amd.context import KEYWORDS
+    frame = 64000                                                 # one 1024-sample hop at 16 kHz, in us
+    happy = [(0.0, 9, frame), (90.0, 0, frame), (3.0, 8, frame), (80.0, 5, frame), (0.2, 9, frame), (70.0, 6, frame),
+             (0.0, 9, frame), (0.0, 9, frame)]
+    wrong_order = [(0, 0, frame), (90.0, 6, frame), (90.0, 0, frame), (90.0, 7, frame), (90.0, 2, frame), (90.0, 0, frame),
+                   (90.0, 7, frame), (1.0, 0, frame)]
+    timeouts = [(0, 0, frame), (90.0, 0, frame)] + [(0.1, 9, frame)] * 80 + [(90.0, 3, frame)]
+    late_value = [(0, 0, frame), (90.0, 0, frame), (90.0, 1, frame)] + [(0.1, 9, 999)] * 5 + [(0.1, 9, 2500000), (0.1, 9, 2500000),
+                                                                                              (90.0, 6, 1000)]
+    rng = np.random.default_rng(5)
+    fuzz = [(float(rng.choice([0.0, 0.4, 0.6, 100.0])), int(rng.integers(0, 10)), int(rng.choice([999, 64000, 1700000])))
+            for _ in range(3000)]
+    for ev in (happy, wrong_order, timeouts, late_value, fuzz):
+        f = Fsm()
+        got = [f.step(*e) for e in ev]
+        want, cmds = _py_fsm(ev)
+        assert got == want
+        assert f.commands == len(cmds)
+        if cmds:
+            assert f.last_command == (KEYWORDS[cmds[-1][0]], KEYWORDS[cmds[-1][1]])
+    f = Fsm()
+    assert [f.step(*e) for e in happy] == ["IDLE", "HOT", "HOT", "LOC", "LOC", "SET", "IDLE", "IDLE"]
+    assert f.last_command == ("kitchen", "on")
+    f = Fsm()
+    assert [f.step(*e) for e in late_value][-1] == "IDLE" and f.commands == 0   # the value came with the timeout: dropped
+
+
+def test_oracle_output_filter(oracle_mod):
+    """The filter oracle against numpy float64 -> float32 arithmetic written out step by step."""
+    rng = np.random.default_rng(6)
+    soft = rng.integers(0, 128, (200, 10)).astype(np.int8)
+    soft[50:60] = 0
+    soft[60:70, 3] = 127
+    filt, likely, spotted, state = oracle_mod.output_filter(soft)
+    y = np.zeros(10, np.float32)
+    for i in range(200):
+        y = (np.float64(0.9) * y.astype(np.float64) + (np.float64(1.0) - np.float64(0.9)) * soft[i].astype(np.float32).astype(np.float64)).astype(np.float32)
+        assert np.array_equal(filt[i], y)
+        assert likely[i] == int(np.argmax(y))                     # np.argmax = first maximum, like arm_max_f32
+        assert spotted[i] == (likely[i] if y.max() > 0.5 else -1)
+    assert np.array_equal(state, y)
+    # state carried over: two calls == one call
+    f1, _, _, s1 = oracle_mod.output_filter(soft[:77])
+    f2, _, _, _ = oracle_mod.output_filter(soft[77:], state=s1)
+    assert np.array_equal(np.concatenate([f1, f2]), filt)
+
+
 def test_weights_importer_roundtrip(tmp_path, oracle_mod):
     """tools/import_weights_h.py: parse a synthetic weights.h, check graph, shifts and the dense de-interleave."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
