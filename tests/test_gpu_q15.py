@@ -72,6 +72,27 @@ def test_q15_vs_oracle_seeded(ctx, oracle_mod, mfcc_golden):
         assert np.array_equal(ctx.mfcc_q15(n, n_coef=nc), full[:, :nc])
 
 
+def test_q15_fuzz_16384_frames(ctx, oracle_mod):
+    """Wide sweep for the saturating / wrapping corners of the integer pipeline: amplitudes from 1 LSB to hard
+    clipping, DC offsets, square waves at fs/2, fs/4 and fs/8, sparse impulses, full-scale sign patterns."""
+    rng = np.random.default_rng(34)
+    n = 16384
+    amp = 10.0 ** rng.uniform(0.0, 5.0, (n, 1))
+    x = rng.normal(0.0, 1.0, (n, 1024)) * amp + rng.choice([0.0, 0.0, 1000.0, -20000.0, 32767.0], (n, 1))
+    t = np.arange(1024)
+    for k, period in enumerate((2, 4, 8)):
+        rows = slice(100 * k, 100 * k + 100)
+        x[rows] = np.where((t // (period // 2)) % 2 == 0, 32767.0, -32768.0)[None, :] * rng.choice([1.0, -1.0, 0.5], (100, 1))
+    x[300:400] = 0.0
+    x[300:400, rng.integers(0, 1024, 100)] = rng.choice([32767.0, -32768.0], 100)
+    x[400:500] = rng.choice([32767.0, -32768.0], (100, 1024))
+    x = np.clip(np.rint(x), -32768, 32767).astype(np.int16).reshape(-1)
+    got = ctx.mfcc_q15(x)
+    ref = oracle_mod.mfcc_q15(x, n_threads=8)
+    bad = np.argwhere((got != ref).any(axis=1)).ravel()
+    assert bad.size == 0, "frames differing: %s" % bad[:8].tolist()
+
+
 def test_q15_through_the_float_interface(ctx, oracle_mod, mfcc_golden):
     """EDISON_MFCC_C through edison_mfcc_batch: the int16 values as floats, feat = the firmware's clip."""
     from edison_amd import _lib
