@@ -93,6 +93,11 @@ def main():
         assert np.array_equal(arr[ours], ref_arr), ours
         out["tbl_" + ours] = ref_arr
     print("compact mel tables equal mel_constants.h (%d coefficients)" % arr["mel_coef"].size)
+    # fingerprint of the whole generated header (a hash, not the text): the product's generator
+    # (edison_amd/mfcc/mfcc_on_mcu.py, mirror of the reference's calcCConstants) must reproduce the file byte for byte
+    import hashlib
+    out["mel_constants_sha256"] = np.array(hashlib.sha256(text.encode()).hexdigest())
+    out["mel_constants_bytes"] = np.array(len(text.encode()))
     for k in ("tw1024", "tw16", "rfa", "rfb"):
         out["tbl_" + k] = arr[k]
 
