@@ -61,7 +61,7 @@ __device__ __forceinline__ u32 eq_asr1(u32 a) { return eq_u(eq_s(a) >> (s16x2)(1
 __device__ __forceinline__ u32 eq_asr2(u32 a) { return eq_u(eq_s(a) >> (s16x2)(2)); }
 /* floor((a+b)/2) = (a&b) + ((a^b)>>1); floor((a-b)/2) = ((a^b)>>1) - (~a&b): no 17th bit needed */
 __device__ __forceinline__ u32 eq_hadd(u32 a, u32 b) { return eq_u(eq_s(a & b) + (eq_s(a ^ b) >> (s16x2)(1))); }
-__device__ __forceinline__ u32 eq_hsub(u32 a, u32 b) { return eq_u((eq_s(a ^ b) >> (s16x2)(1)) - eq_s(~a & b)); }
+__device__ __forceinline__ u32 eq_hsub(u32 a, u32 b) { return eq_u((eq_s(a ^ b) >> (s16x2)(1)) - eq_s((a ^ b) & b)); } /* (a^b)&b == ~a&b */
 __device__ __forceinline__ u32 eq_swap(u32 a) { return __builtin_amdgcn_alignbit(a, a, 16); }
 __device__ __forceinline__ u32 eq_lohi(u32 lo_from, u32 hi_from) { return (lo_from & 0xffffu) | (hi_from & 0xffff0000u); }
 
@@ -137,25 +137,36 @@ __device__ __forceinline__ void eq_bf_last(u32 &a, u32 &b, u32 &c, u32 &d)
 	a = eq_hadd(r, tt); b = eq_hsub(r, tt); c = minus; d = plus;
 }
 
+__device__ __forceinline__ u32 eq_mulhi(u32 a, u32 b)
+{
+	u32 r;
+	asm("v_mul_hi_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+
 /* arm_sqrt_q31: float seed from the exponent trick, three Newton steps on 1/sqrt, one multiply back. Every
  * intermediate stays in [0, 2^31), so (a*b)>>31 == mulhi(2a, b) (tools/verify/sqrt_q31_equiv.c enumerates it). */
-__device__ __forceinline__ int eq_sqrt_q31(int in)
+__device__ __forceinline__ int eq_sqrt_q31(int in_raw)
 {
-	if (in <= 0) return 0;
+	/* branch-free (the eight square roots of a lane are independent chains the scheduler can interleave):
+	 * non-positive inputs run the sequence on 1 and select 0 at the end */
+	const int in = in_raw > 0 ? in_raw : 1;
 	const int sh = (__builtin_clz((u32)in) - 1) & ~1;
 	const u32 number = (u32)in << sh, number2 = number & ~1u;
 	const float seed = (float)(int)number * 4.6566128731e-010f;
 	const float guess = __int_as_float(0x5f3759df - (__float_as_int(seed) >> 1)) * 1073741824.0f;
 	u32 v = (u32)(int)guess;
+	/* the multiplies are opaque to the optimiser on purpose: left alone it rewrites "mulhi << 2" into a 64-bit
+	 * multiply plus funnel shifts and masks, twice the instructions */
 #pragma unroll
 	for (int it = 0; it < 3; it++)
 	{
-		const u32 vv = __umulhi(v << 1, v);
-		const u32 hv = __umulhi(vv, number2);
-		v = __umulhi(v, (0x30000000u - hv) << 1) << 2;
+		const u32 vv = eq_mulhi(v + v, v);
+		const u32 hv = eq_mulhi(vv, number2);
+		v = eq_mulhi(v, 0x60000000u - (hv + hv)) << 2; /* (0x30000000 - hv) << 1 */
 	}
-	v = __umulhi(number << 1, v) << 1;
-	return (int)v >> (sh >> 1);
+	v = eq_mulhi(number + number, v) << 1;
+	return in_raw > 0 ? (int)v >> (sh >> 1) : 0;
 }
 
 __device__ __forceinline__ int eq_re(u32 x) { return (int)(short)(x & 0xffffu); }
@@ -270,8 +281,14 @@ __device__ __forceinline__ void eq_dct_batch(const ed_mfcc_q15_args_t &a, int *m
 	}
 }
 
+#ifdef EQ_WAVES_PER_EU /* tuning knob: ask the register allocator for this occupancy */
+#define EQ_OCCUPANCY __attribute__((amdgpu_waves_per_eu(EQ_WAVES_PER_EU, EQ_WAVES_PER_EU)))
+#else
+#define EQ_OCCUPANCY
+#endif
+
 template <bool STAGES, int NLO, int NHI>
-__global__ __launch_bounds__(64 * EQ_WPB) void ed_mfcc_q15_kernel(ed_mfcc_q15_args_t a, const ed_q15_tables_t *__restrict__ T)
+__global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(ed_mfcc_q15_args_t a, const ed_q15_tables_t *__restrict__ T)
 {
 	__shared__ u32 s_buf[EQ_WPB][EQ_BUF];
 	__shared__ int s_tap[NLO + NHI][64];
@@ -366,8 +383,8 @@ __global__ __launch_bounds__(64 * EQ_WPB) void ed_mfcc_q15_kernel(ed_mfcc_q15_ar
 		{
 			const int m = ((kk & 1) << 3) | ((kk & 2) << 1) | ((kk & 4) >> 1); /* bitrev4(kk), kk < 8 */
 			const int re = eq_re(e[m]), im = eq_im(e[m]);
-			const int mag = (EQ_ABLATE & 1) ? (re ^ im) & 0x7fff
-			                                : (int)(short)(eq_sqrt_q31((int)((u32)(re * re) + (u32)(im * im))) >> 16);
+			/* re^2 + im^2 (32-bit wrap-around, like the firmware's q31 sum) is one dot2 of the value with itself */
+			const int mag = (EQ_ABLATE & 1) ? (re ^ im) & 0x7fff : eq_sqrt_q31(eq_dot2<false>(e[m], e[m])) >> 16;
 			spec[64 * kk + rev6] = mag;
 			if (STAGES)
 			{
@@ -379,7 +396,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) void ed_mfcc_q15_kernel(ed_mfcc_q15_ar
 		if (need_nyquist && lane == 0)
 		{
 			const int re = eq_re(e[1]), im = eq_im(e[1]); /* X[512] */
-			const int mag = (int)(short)(eq_sqrt_q31((int)((u32)(re * re) + (u32)(im * im))) >> 16);
+			const int mag = eq_sqrt_q31(eq_dot2<false>(e[1], e[1])) >> 16;
 			spec[512] = mag;
 			if (STAGES && a.fft) { a.fft[((int64_t)f * 513 + 512) * 2] = (int16_t)re; a.fft[((int64_t)f * 513 + 512) * 2 + 1] = (int16_t)im; }
 			if (STAGES && a.spec) a.spec[(int64_t)f * 513 + 512] = (int16_t)mag;
@@ -392,9 +409,9 @@ __global__ __launch_bounds__(64 * EQ_WPB) void ed_mfcc_q15_kernel(ed_mfcc_q15_ar
 		else
 		{
 #pragma unroll
-			for (int t = 0; t < NLO; t++) acc_lo += (u32)(spec[mel_lo_bin + t] * s_tap[t][lane]);
+			for (int t = 0; t < NLO; t++) acc_lo += (u32)__mul24(spec[mel_lo_bin + t], s_tap[t][lane]); /* both fit 16 bits */
 #pragma unroll
-			for (int t = 0; t < NHI; t++) acc_hi += (u32)(spec[mel_hi_bin + t] * s_tap[NLO + t][lane]);
+			for (int t = 0; t < NHI; t++) acc_hi += (u32)__mul24(spec[mel_hi_bin + t], s_tap[NLO + t][lane]);
 		}
 		acc_lo = eq_sum_rows(acc_lo);
 		acc_hi = eq_sum_rows(acc_hi);
