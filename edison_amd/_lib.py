@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libedison_hip.so")
+LIB_PATH = os.environ.get("EDISON_LIB") or os.path.join(_HERE, "csrc", "libedison_hip.so")  # EDISON_LIB: another build
 DEFAULT_MODEL = os.path.join(_HERE, "data", "kws_nnom.ednn")
 
 OK = 0
