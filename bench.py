@@ -255,6 +255,14 @@ def main():
                     units_per_launch=nf, kernel_ms=round(ev_ms, 4))
     checksum = float(out.double().sum().item())
 
+    # ------------------------------------------------------------------ variant A (log-mel, mfcc_utils.mfcc), same batch
+    def mfcc_a_step(i):
+        ctx.mfcc_t(bufs[i % len(bufs)], nf, 1024, _lib.MFCC_A, 13, out=out)
+    a_ms, aev_ms = timed_region(mfcc_a_step, args.steps, args.warmup, world)
+    variant_a = dict(metric="MFCC frames/sec, variant A (ln + DCT, mfcc_utils.mfcc)", unit="frames/s",
+                     value=round(world * nf / (a_ms * 1e-3), 1), ms_per_step=round(a_ms, 4), kernel_ms=round(aev_ms, 4),
+                     roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (aev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+
     # ------------------------------------------------------------------ variant C: the firmware's Q15 MFCC, same batch
     q15 = None
     if not args.skip_q15:
@@ -336,6 +344,7 @@ def main():
                     config=dict(workload="mfcc_batch_%dx1024_int16_per_gpu_variantB_13coef" % nf, global_batch=world * nf,
                                 frame_len=1024, parallelism="dp%d" % world, rotate_buffers=args.rotate),
                     roofline=roofline, device=info["name"], checksum=checksum)
+        line["mfcc_variant_a"] = variant_a
         if q15 is not None:
             line["mfcc_q15"] = q15
             if cpu is not None and "q15" in cpu:

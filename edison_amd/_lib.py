@@ -95,6 +95,13 @@ SIGNATURES = {
     "mfccToNetInputPush": (None, [c_void_p, ctypes.c_uint16, ctypes.c_uint16]),
     "audioInit": (None, []),
     "audioCalcMFCCs": (None, [c_void_p, ctypes.POINTER(c_void_p)]),
+    "mfcc_create": (c_void_p, [c_int, c_int, c_int, c_int, c_float]),
+    "mfcc_delete": (None, [c_void_p]),
+    "mfcc_compute": (None, [c_void_p, c_void_p, c_void_p]),
+    "edison_mfcc_f32_create": (c_void_p, [c_void_p, c_int, c_int, c_int, c_int, c_float]),
+    "edison_mfcc_f32_n_out": (c_int, [c_void_p]),
+    "edison_mfcc_f32_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "edison_mfcc_f32_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "edison_mfcc_frame": (c_int, [c_void_p, c_int, c_void_p]),
     "edison_global_ctx": (c_void_p, []),
 }

@@ -99,6 +99,32 @@ typedef struct {
 	int16_t *mel;  /* [n][32]     */
 } ed_mfcc_q15_args_t;
 
+/* ------------------------------------------------------------------ MFCC variant D (firmware float32 extractor) */
+#define ED_F32_NUM_FBANK 26   /* NUM_FBANK_BINS, firmware/src/audio/mfcc.h:30 */
+#define ED_F32_MAX_FRAME 1024 /* padded frame length supported on this path (the firmware uses 512, app.c:497) */
+#define ED_F32_MAX_W 1100     /* mel weights of all bands back to back (bands overlap: < 2 * bins)               */
+
+typedef struct {
+	int32_t n_features, offset, frame_len, padded, log2p, dec_bits;
+	float preempha, scale;                 /* scale = 2^dec_bits */
+	float window[ED_F32_MAX_FRAME];        /* Hann, float (mfcc.c:66-68) */
+	float tw[ED_F32_MAX_FRAME / 2][2];     /* exp(-2 pi i k / padded) */
+	int32_t mel_first[ED_F32_NUM_FBANK], mel_last[ED_F32_NUM_FBANK], mel_off[ED_F32_NUM_FBANK];
+	float mel_w[ED_F32_MAX_W];
+	float dct[ED_F32_NUM_FBANK * ED_F32_NUM_FBANK]; /* [feature][band], rows < n_features used */
+} ed_f32_tables_t;
+
+int ed_build_f32_tables(int num_mfcc_features, int feature_offset, int frame_len, int mfcc_dec_bits, float preempha,
+                        ed_f32_tables_t *out, char *err, size_t err_cap);
+
+typedef struct {
+	const int16_t *audio;
+	int64_t n_frames, frame_step;
+	int8_t *out;    /* [n][n_features - offset] q7 */
+	float *out_f32; /* same shape, before round / saturate, or NULL */
+	float *logmel;  /* [n][26] or NULL */
+} ed_mfcc_f32_args_t;
+
 /* ------------------------------------------------------------------ int8 CNN model (kws_conv topology)   */
 /* Geometry of the one network this path accelerates (weights.h:138-161).                    */
 #define ED_IN_H 31

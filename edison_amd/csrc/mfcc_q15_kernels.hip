@@ -330,16 +330,27 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	const uint32_t n_frames = (uint32_t)a.n_frames, fstride = gridDim.x * EQ_WPB;
 	const uint32_t f_first = blockIdx.x * EQ_WPB + (uint32_t)w;
 	int slot = 0;
+	/* software prefetch: the samples of frame f + fstride are requested while frame f is being transformed */
+	unsigned short raw[16];
+	if (f_first < n_frames)
+	{
+		const int16_t *src = eq_frame_ptr(a, f_first);
+#pragma unroll
+		for (int i = 0; i < 16; i++) raw[i] = (unsigned short)src[lane + 64 * (i >> 2) + 256 * (i & 3)];
+	}
 	for (uint32_t f = f_first; f < n_frames; f += fstride)
 	{
-		const int16_t *src = eq_frame_ptr(a, f);
 		u32 e[16];
 
 		/* ---- stage 1: real samples become (re, 0) */
 #pragma unroll
-		for (int u = 0; u < 4; u++)
+		for (int i = 0; i < 16; i++) e[i] = (u32)raw[i];
+		if (f + fstride < n_frames && f + fstride > f)
+		{
+			const int16_t *src = eq_frame_ptr(a, f + fstride);
 #pragma unroll
-			for (int q = 0; q < 4; q++) e[4 * u + q] = (u32)(unsigned short)src[lane + 64 * u + 256 * q];
+			for (int i = 0; i < 16; i++) raw[i] = (unsigned short)src[lane + 64 * (i >> 2) + 256 * (i & 3)];
+		}
 #pragma unroll
 		for (int u = 0; u < 4; u++)
 		{

@@ -260,6 +260,27 @@ void mfccToNetInputPush(int16_t *mfcc, uint16_t in_x, uint16_t in_y);
  * int16 (valid until the next call): MFCC variant C, the firmware's own Q15 arithmetic. */
 void audioInit(void);
 void audioCalcMFCCs(int16_t *inp, int16_t **oup);
+/* firmware/src/audio/mfcc.h:64-67 -- MFCC variant D, the float32 ML-KWS extractor of the firmware's NNoM example
+ * (app.c:540,583: mfcc_create(13, 1, 512, 8, 0.97f), hop 256): pre-emphasis, Hann window, FFT of the frame padded to a
+ * power of two, 26 mel bands 20..4000 Hz, logf, DCT rows feature_offset..num_mfcc_features-1, * 2^mfcc_dec_bits,
+ * round, saturate to q7. The handle is opaque (the firmware's struct fields are private scratch); `mfcc_out` receives
+ * num_mfcc_features - feature_offset int8. mfcc_create returns NULL on failure (bad arguments, padded length outside
+ * 128..1024, no GPU). Same struct tag as the firmware's header, so both headers can be included together. */
+#ifndef __KWS_MFCC_H__
+typedef struct _mfcc_t mfcc_t;
+#endif
+mfcc_t *mfcc_create(int num_mfcc_features, int feature_offset, int frame_len, int mfcc_dec_bits, float preemph);
+void mfcc_delete(mfcc_t *mfcc);
+void mfcc_compute(mfcc_t *mfcc, const int16_t *audio_data, int8_t *mfcc_out);
+/* the same on an explicit context, and batched: frame i starts at audio + i*frame_step; out [n][n_out] q7,
+ * out_f32 [n][n_out] (the scaled sums before round/saturate) and logmel [n][26] may be NULL */
+mfcc_t *edison_mfcc_f32_create(edison_ctx *ctx, int num_mfcc_features, int feature_offset, int frame_len,
+                               int mfcc_dec_bits, float preemph);
+int edison_mfcc_f32_n_out(const mfcc_t *mfcc);
+int edison_mfcc_f32_batch_dev(mfcc_t *mfcc, const int16_t *audio, int64_t n_frames, int64_t frame_step, int8_t *out,
+                              float *out_f32, float *logmel);
+int edison_mfcc_f32_batch(mfcc_t *mfcc, const int16_t *audio, int64_t n_frames, int64_t frame_step, int8_t *out,
+                          float *out_f32, float *logmel);
 /* One 1024-sample frame through the GPU MFCC, any variant; out32 fp32. */
 int edison_mfcc_frame(const int16_t *frame1024, int variant, float *out32);
 edison_ctx *edison_global_ctx(void);

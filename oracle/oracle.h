@@ -67,6 +67,19 @@ int oracle_mfcc_q15(const oracle_q15_tables_t *t, const int16_t *x, int64_t n_fr
 void oracle_net_input_q15(const int16_t *mfcc, int64_t n_rows, int stride, int n_coef, int scale, int clip_lo,
                           int clip_hi, int8_t *out);
 
+/* ---- MFCC variant D: the firmware's float32 ML-KWS extractor (mfcc_f32_ref.c; parity unpinned, see its header) ---- */
+
+typedef struct oracle_f32_mfcc oracle_f32_mfcc_t;
+/* mfcc_create (firmware/src/audio/mfcc.c:47-84); NULL on bad arguments */
+oracle_f32_mfcc_t *oracle_f32_mfcc_new(int num_mfcc_features, int feature_offset, int frame_len, int mfcc_dec_bits,
+                                       float preempha);
+void oracle_f32_mfcc_free(oracle_f32_mfcc_t *m);
+int oracle_f32_mfcc_n_out(const oracle_f32_mfcc_t *m);
+/* mfcc_compute on n_frames frames starting every frame_step samples: out int8 [n][n_out]; out_f32 (may be NULL) the
+ * scaled sums before round/saturate; logmel (may be NULL) [n][26] */
+int oracle_f32_mfcc_run(const oracle_f32_mfcc_t *m, const int16_t *x, int64_t n_frames, int64_t frame_step, int8_t *out,
+                        float *out_f32, float *logmel, int n_threads);
+
 /* ---- int8 CNN (NNoM/CMSIS-NN arithmetic) -------------------------------------------------------- */
 
 #define ORACLE_L_CONV 1

@@ -35,7 +35,7 @@ def build(force=False):
     """Compile the restatement (always possible: gcc only) and, when the reference is mounted, the reference."""
     if force or not os.path.exists(PORT_SO) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(PORT_SO)
-            for f in ("mfcc_ref.c", "mfcc_q15_ref.c", "kws_cnn_ref.c", "postproc_ref.c", "oracle.h")):
+            for f in ("mfcc_ref.c", "mfcc_q15_ref.c", "mfcc_f32_ref.c", "kws_cnn_ref.c", "postproc_ref.c", "oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "-B", "port"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/firmware") and (force or not os.path.exists(REF_SO)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -84,6 +84,14 @@ def port():
         L.oracle_mfcc_q15.restype = ctypes.c_int
         L.oracle_mfcc_q15.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.oracle_f32_mfcc_new.restype = ctypes.c_void_p
+        L.oracle_f32_mfcc_new.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float]
+        L.oracle_f32_mfcc_free.restype = None
+        L.oracle_f32_mfcc_free.argtypes = [ctypes.c_void_p]
+        L.oracle_f32_mfcc_n_out.argtypes = [ctypes.c_void_p]
+        L.oracle_f32_mfcc_run.restype = ctypes.c_int
+        L.oracle_f32_mfcc_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.oracle_output_filter.restype = None
         L.oracle_output_filter.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -230,6 +238,36 @@ def net_input_q15(mfcc_rows, n_coef=NUM_MFCC, scale=1, clip_lo=-128, clip_hi=127
     out = np.zeros((n, n_coef), np.int8)
     port().oracle_net_input_q15(_p(m), n, stride, n_coef, scale, clip_lo, clip_hi, _p(out))
     return out
+
+
+class MfccF32:
+    """Variant D: mfcc_create / mfcc_compute of firmware/src/audio/mfcc.c (defaults = app.c:540)."""
+
+    def __init__(self, num_mfcc_features=13, feature_offset=1, frame_len=512, mfcc_dec_bits=8, preempha=0.97):
+        self.h = port().oracle_f32_mfcc_new(num_mfcc_features, feature_offset, frame_len, mfcc_dec_bits, preempha)
+        if not self.h:
+            raise ValueError("bad mfcc_create arguments")
+        self.frame_len, self.n_out = frame_len, port().oracle_f32_mfcc_n_out(self.h)
+
+    def __call__(self, x, n_frames=None, frame_step=None, n_threads=1):
+        """-> (int8 [n, n_out], float32 [n, n_out] before round/saturate, float32 log-mel [n, 26])"""
+        x = np.ascontiguousarray(x, dtype=np.int16).ravel()
+        step = self.frame_len if frame_step is None else frame_step
+        if n_frames is None:
+            n_frames = 1 + (x.shape[0] - self.frame_len) // step if x.shape[0] >= self.frame_len else 0
+        n = max(n_frames, 0)
+        out = np.zeros((n, self.n_out), np.int8)
+        f32 = np.zeros((n, self.n_out), np.float32)
+        lm = np.zeros((n, 26), np.float32)
+        if n:
+            assert (n - 1) * step + self.frame_len <= x.shape[0]
+            port().oracle_f32_mfcc_run(self.h, _p(x), n, step, _p(out), _p(f32), _p(lm), int(n_threads))
+        return out, f32, lm
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            port().oracle_f32_mfcc_free(self.h)
+            self.h = None
 
 
 def output_filter(softmax, state=None, alpha=0.9, threshold=0.5):
