@@ -66,18 +66,76 @@ def file_inference(path, pad_mode="zero", ctx=None, verbose=True):
     return res
 
 
+def rmse(a, b):
+    return np.sqrt(np.mean((a - b) ** 2))
+
+
+def compare(data_a, data_b, name, out=sys.stdout):
+    """The comparison block of kws_on_mcu.compare (:159-168), same wording and number formats."""
+    dev = 100.0 * (1.0 - (data_b.ravel() + 1e-9) / (data_a.ravel() + 1e-9))
+    print('_________________________________________________________________', file=out)
+    print('Comparing: %s' % (name), file=out)
+    print("Deviation: max %.3f%% min %.3f%% avg %.3f%% \nrmse %.3f" % (
+        dev.max(), dev.min(), np.mean(dev), rmse(data_b.ravel(), data_a.ravel())), file=out)
+    print('scale %.3f=1/%.3f' % (data_b.max() / data_a.max(), data_a.max() / data_b.max()), file=out)
+    print('correlation coeff %.3f' % (np.corrcoef(data_a.ravel(), data_b.ravel())[0, 1]), file=out)
+    print('_________________________________________________________________', file=out)
+
+
+def frame_inference(path, ctx=None, out=sys.stdout):
+    """`kws mcu file <wav>` = kws_on_mcu.frameInference (:310-401): the wav (edge-padded to 2 s) through the host
+    leg (MFCC variant B) and through the board's leg -- here the GPU's variant C, i.e. the firmware's own Q15
+    arithmetic -- each followed by the int8 network, then the two comparison blocks the reference prints
+    (README.md:121-139 shows them for data/edison_16k_16b.wav)."""
+    from .. import _lib
+    ctx = ctx or default_context()
+    data = pad_or_cut(read_wav(path), mode="edge")
+    np.set_printoptions(precision=3, suppress=True)
+    host = ctx.kws(data, n_utt=1, utt_stride=data.shape[0])
+    mcu = ctx.kws(data, n_utt=1, utt_stride=data.shape[0], q15=True)
+    host_pred = host["softmax"][0].astype(np.float32) / 127.0
+    mcu_pred = mcu["softmax"][0].astype(np.float32) / 127.0
+    print('keywords:', list(KEYWORDS), file=out)
+    print('host prediction:', host_pred, KEYWORDS[int(host["argmax"][0])], file=out)
+    print('mcu prediction: ', mcu_pred, KEYWORDS[int(mcu["argmax"][0])], file=out)
+    print('rmse:', rmse(host_pred, mcu_pred), file=out)
+    compare(host_pred, mcu_pred, 'predictions', out)
+    # the MFCC block compares the unclipped coefficients, float32 like the reference's arrays (:346, app.c:212)
+    host_mfcc = ctx.mfcc(data, variant=_lib.MFCC_B, n_coef=cfg.num_mfcc).astype(np.float32)
+    mcu_mfcc = ctx.mfcc_q15(data, n_coef=cfg.num_mfcc).astype(np.float32)
+    compare(host_mfcc, mcu_mfcc, 'MFCC=net input', out)
+    return dict(host=host, mcu=mcu, host_mfcc=host_mfcc, mcu_mfcc=mcu_mfcc)
+
+
+def single_inference(repeat=1, ctx=None, out=sys.stdout):
+    """`kws mcu single [n]` = kws_on_mcu.singleInference (:236-270), nnom branch: the all-zero int8 net input."""
+    ctx = ctx or default_context()
+    res = None
+    for _ in range(max(1, int(repeat))):
+        res = ctx.cnn(np.zeros((1, cfg.n_frames * cfg.num_mfcc), np.int8))
+        report(res, 0, out)
+    return res
+
+
 def main(argv):
-    """``kws mcu <mode> [file]`` of the reference's CLI (main.py:146-165); modes that only make sense with the
-    STM32 board attached (single/mic/hil) report that the board transport is out of scope."""
+    """``kws mcu <mode> [file]`` of the reference's CLI (main.py:146-165, kws_on_mcu.py:650-690). The modes that record
+    from a microphone (mic, host, hostcont, hostsingle, miccont) are not part of this port."""
     if len(argv) < 2:
-        print('usage: kws mcu <file|fileinf|frame> <wav>')
+        print('usage: kws mcu <single [n] | fileinf <wav> | file <wav> | frame <wav>>')
         return 1
     mode = argv[1]
+    print('Running mode', mode, 'with args', argv[2:])
+    if mode == "single":
+        single_inference(int(argv[2]) if len(argv) > 2 else 1)
+        return 0
     if mode in ("file", "fileinf", "frame", "host"):
         if len(argv) < 3:
             print('need a wav file')
             return 1
-        file_inference(argv[2], pad_mode="edge" if mode == "frame" else "zero")
+        if mode == "file":
+            frame_inference(argv[2])
+        else:
+            file_inference(argv[2], pad_mode="edge" if mode == "frame" else "zero")
         return 0
-    print('mode %r needs the STM32 board (UART host interface), which this port replaces by the GPU' % mode)
+    print('mode %r records from a microphone, which this port does not drive' % mode)
     return 1

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """``./main.py <module> <command>`` -- the reference's CLI (audio/main.py:12-39) for the modules that sit on the
-keyword-spotting hot path: ``mfcc host`` (main.py:80-99,199) and ``kws mcu <mode> [file]`` / ``kws live ...``
-(main.py:146-165,231-238). Same dispatch pattern; the other modules (mic, acquire, train, deploy, mcu) drive the
-STM32 board or Keras training and are out of scope here.
+keyword-spotting hot path: ``mfcc host`` / ``mfcc mcu <mode>`` (main.py:80-99,199-205) and ``kws mcu <mode> [file]`` /
+``kws live ...`` (main.py:146-165,231-238). Same dispatch pattern. Where the reference talks to the STM32 board over
+the UART, the board's leg is computed by the GPU's bit-exact variant C. The other modules (mic, acquire, train,
+deploy, mcu) drive the board or Keras training and are out of scope here.
 """
 import argparse
 import sys
@@ -35,11 +36,14 @@ The modules:
 
 Commands
     host    Run MFCC on host (MI355X)
+    mcu     The board comparisons with the GPU's Q15 MFCC as the board: mcu calc [file] | single [wav] | file <wav>
 ''')
     parser.add_argument('command', help='Command to run')
     args = parser.parse_args(self.argv[2:3])
     if args.command == 'host':
       self.mfcc_host()
+    elif args.command == 'mcu':
+      self.mfcc_mcu()
     else:
       print('Unrecognized command')
       parser.print_help()
@@ -69,6 +73,10 @@ Commands
   def mfcc_host(self):
     from edison_amd.mfcc import mfcc as mfcc_script
     self.rc = mfcc_script.main(self.argv[3:])
+
+  def mfcc_mcu(self):
+    from edison_amd.mfcc import mfcc_on_mcu
+    self.rc = mfcc_on_mcu.main(self.argv[2:])
 
   def kws_live(self):
     print('kws live needs a microphone stream; see edison_amd.stream for the batched streaming path')

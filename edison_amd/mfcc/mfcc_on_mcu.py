@@ -98,3 +98,96 @@ def calcCConstants(fname=None, sample_size=_cfg.frame_length, num_mel_bins=_cfg.
         with open(fname, "w") as f:
             f.write(text)
     return text
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The hardware-in-the-loop comparisons of the reference script, with the board's leg (audioCalcMFCCs over the UART,
+# audioDumpToHost: audioprocessing.c:221-231) computed by the GPU's variant C -- the same integers, no board.
+
+def _two_tone():
+    """The synthetic frame of mfcc_on_mcu.py:312-315."""
+    t = np.linspace(0, _cfg.frame_length / _cfg.fs, _cfg.frame_length)
+    return np.array(1000 * np.cos(2 * np.pi * (_cfg.fs / 16) * t) + 500 * np.cos(2 * np.pi * (_cfg.fs / 128) * t), dtype="int16")
+
+
+def _read_int16(path):
+    import scipy.io.wavfile as wavfile
+    fs, data = wavfile.read(path)
+    data = np.asarray(data)
+    if data.dtype == np.float32:
+        data = np.array((2 ** 15 - 1) * data, dtype="int16")   # mfcc_on_mcu.py:424-425
+    return fs, np.asarray(data, dtype=np.int16)
+
+
+def compare_stages(y, out=None):
+    """Variant B on the host model vs variant C ("mcu") for the frames of y; prints the four scale lines of
+    mfcc_on_mcu.py:382-392 and returns both sets of stage arrays."""
+    import sys
+    from ..context import default_context
+    from .. import _lib
+    out = out or sys.stdout
+    ctx = default_context()
+    host = ctx.mfcc_stages(y, variant=_lib.MFCC_B)
+    mcu = ctx.mfcc_q15_stages(y)
+    host_fft = host["fft"] / float(_cfg.frame_length)                       # mfcc_mcu keeps fft / 1024 (mfcc_utils.py:297)
+    print("host/mcu fft scale %f" % (np.real(host_fft).max() / mcu["fft"][..., 0].max()), file=out)
+    print("host/mcu spectrum scale %f" % (host["spectrogram"].max() / mcu["spectrogram"].max()), file=out)
+    print("host/mcu mel spectrum scale %f" % (host["mel_spectrogram"].max() / mcu["mel_spectrogram"].max()), file=out)
+    print("host/mcu dct scale %f" % (host["mfcc"].max() / mcu["mfcc"].max()), file=out)
+    return host, mcu
+
+
+def modeSingle(wav=None):
+    """`mfcc mcu single`: one 1024-sample frame. With a wav: its first samples padded with 6 like the reference does
+    with data/hey_short_16k.wav (mfcc_on_mcu.py:320-323); without: the synthetic two-tone."""
+    if wav:
+        _, d = _read_int16(wav)
+        d = d[:_cfg.frame_length]
+        y = np.pad(d, (0, _cfg.frame_length - d.shape[0]), "constant", constant_values=(4, 6)).astype(np.int16)
+    else:
+        y = _two_tone()
+    return compare_stages(y)
+
+
+def modeCalc(fname="mel_constants.h"):
+    """`mfcc mcu calc`: write the firmware's constant header."""
+    calcCConstants(fname)
+    print("wrote %s" % fname)
+
+
+def modeFile(fname):
+    """`mfcc mcu file <wav>`: every 1024-sample frame of the file through both variants (mfcc_on_mcu.py:407-470)."""
+    fs, y = _read_int16(fname)
+    print("Working with %s" % fname)
+    print("Frame length in seconds = %.3fs" % (_cfg.frame_length / fs))
+    print("Number of input samples = %d" % len(y))
+    host, mcu = compare_stages(y)
+    # the coefficients the network sees; beyond index 16 the firmware's RFFT-based "DCT" mirrors its own output
+    # (out[32-k] = out[k], audioprocessing.c:330-436) and is not comparable with a DCT-II any more
+    nc = _cfg.num_mfcc
+    a, b = host["mfcc"][:, :nc].ravel(), mcu["mfcc"][:, :nc].astype(np.float64).ravel()
+    print("MFCC[:%d] host vs mcu over %d frames: rmse %.3f, correlation coeff %.3f" % (
+        nc, host["mfcc"].shape[0], np.sqrt(np.mean((a - b) ** 2)), np.corrcoef(a, b)[0, 1]))
+    return host, mcu
+
+
+def main(argv):
+    """``mfcc mcu <mode>`` of the reference's CLI (mfcc_on_mcu.py:526-548)."""
+    if len(argv) < 2:
+        print("Usage:\n  mfcc mcu <mode>\n    calc [file]   Calculate C constants header file\n"
+              "    single [wav]  Run MFCC on single frame\n    file <wav>    Run MFCC on wav file of any length")
+        return 1
+    mode = argv[1]
+    if mode == "single":
+        modeSingle(argv[2] if len(argv) > 2 else None)
+    elif mode == "calc":
+        modeCalc(argv[2] if len(argv) > 2 else "mel_constants.h")
+    elif mode == "file":
+        if len(argv) < 3:
+            print("Specify input file")
+            return 1
+        modeFile(argv[2])
+    else:
+        print("Unrecognized mode")
+        return 1
+    return 0

@@ -317,10 +317,26 @@ def test_cli_entry_points(ctx, kws_golden, mfcc_golden, tmp_path, capsys):
     assert cli.main(["main.py", "mfcc", "host", wav]) == 0
     out = capsys.readouterr().out
     assert "Number of input samples = 11243" in out and "(2, 10, 13)" in out
-    assert cli.main(["main.py", "kws", "mcu", "file", wav]) == 0
+    assert cli.main(["main.py", "kws", "mcu", "fileinf", wav]) == 0
     out = capsys.readouterr().out
     assert "edison" in out.splitlines()[-2]
     assert cli.main(["main.py", "kws", "mcu", "frame", wav]) == 0
+    capsys.readouterr()
+    # `kws mcu file` = frameInference: host leg (variant B) vs the board's leg (variant C on the GPU). The reference
+    # prints this block for the same wav in README.md:121-139; rmse / scale / correlation of the MFCC block must agree
+    # (the deviation extremes depend on the last bits of the float32 host values and are pinned in test_gpu_q15.py).
+    assert cli.main(["main.py", "kws", "mcu", "file", wav]) == 0
+    out = capsys.readouterr().out
+    assert out.count("edison") >= 3 and "Comparing: predictions" in out
+    blk = out.split("Comparing: MFCC=net input")[1]
+    assert "rmse 2.036" in blk and "scale 0.959=1/1.043" in blk and "correlation coeff 0.997" in blk
+    assert cli.main(["main.py", "kws", "mcu", "single"]) == 0
+    assert "_noise" in capsys.readouterr().out               # all-zero input: class 9 (SURVEY 8c known answer)
+    assert cli.main(["main.py", "mfcc", "mcu", "single"]) == 0
+    out = capsys.readouterr().out
+    assert all(k in out for k in ("host/mcu fft scale", "host/mcu spectrum scale", "host/mcu mel spectrum scale", "host/mcu dct scale"))
+    assert cli.main(["main.py", "mfcc", "mcu", "file", wav]) == 0
+    assert "correlation coeff 0.99" in capsys.readouterr().out
 
 
 def test_c_program_links_against_the_abi(built_lib, ctx, kws_golden, tmp_path):

@@ -272,6 +272,12 @@ def test_pad_or_cut_and_cli_dispatch(tmp_path, capsys):
     assert cli.main(["main.py", "kws", "bogus"]) == 1
     assert cli.main(["main.py", "kws", "live", "host"]) == 0   # reference quirk (exit 1 after running) not kept
     assert cli.main(["main.py", "mfcc", "host", str(tmp_path / "missing.wav")]) == 1
+    assert cli.main(["main.py", "mfcc", "mcu"]) == 1
+    assert cli.main(["main.py", "mfcc", "mcu", "nosuch"]) == 1
+    assert cli.main(["main.py", "kws", "mcu", "mic"]) == 1
+    hdr = tmp_path / "mel_constants.h"
+    assert cli.main(["main.py", "mfcc", "mcu", "calc", str(hdr)]) == 0     # host-only: no GPU needed
+    assert hdr.read_text().startswith("#define MEL_SAMPLE_SIZE          1024\n") and hdr.stat().st_size > 200000
 
 
 def test_shard_range():
