@@ -1,0 +1,53 @@
+"""``kws live <host|mcu> <wav>`` -- the firmware's continuous mode (firmware/src/app.c:288-371) replayed on a wav file.
+
+The reference's ``audio/edison/kws/kws_live.py`` listens to a microphone; the signal path behind the microphone is
+what this module runs, frame by frame, on the GPU: 1024-sample frames -> MFCC -> 31-row sliding window -> int8 network
+-> moving average over the outputs -> maximum / threshold -> wake-word state machine. ``host`` uses the host float
+model of the features (variant B), ``mcu`` the firmware's own Q15 arithmetic (variant C). The printed lines follow the
+firmware's UART log (app.c:330-353).
+"""
+import sys
+
+import numpy as np
+
+from .. import config as cfg
+from ..context import KEYWORDS, default_context
+from ..stream import Fsm, Stream
+from .kws_host import read_wav
+
+
+def run(path, q15=False, ctx=None, out=sys.stdout, alpha=0.9, threshold=0.5):
+    ctx = ctx or default_context()
+    data = read_wav(path)
+    hop = cfg.frame_length
+    n = -(-data.shape[0] // hop)
+    data = np.pad(data, (0, n * hop - data.shape[0]))
+    st = Stream(ctx, hop=hop, chunk_frames=n, q15=q15, output_filter=True, alpha=alpha, threshold=threshold)
+    res = st.push(data)
+    st.close()
+    fsm = Fsm(threshold)
+    dt_us = int(round(hop * 1e6 / cfg.fs))                      # one frame of audio between two FSM calls
+    events = []
+    for i in range(n):
+        filt = res["filtered"][i]
+        likely, spotted = int(res["likely"][i]), int(res["spotted"][i])
+        line = "pred: [ " + " ".join("%2.2f" % float(v) for v in res["softmax"][i]) + " ] likely: %s" % KEYWORDS[likely]
+        if spotted >= 0:
+            line += " spotted %s" % KEYWORDS[spotted]
+        before, cmds = fsm.state, fsm.commands
+        after = fsm.step(float(filt[likely]), likely, dt_us)
+        if after != before:
+            line += "   [FSM %s -> %s]" % (before, after)
+        if fsm.commands != cmds:
+            line += "   [%s %s]" % fsm.last_command
+            events.append(fsm.last_command)
+        print(line, file=out)
+    return dict(result=res, commands=events, state=fsm.state)
+
+
+def main(argv):
+    if len(argv) < 3 or argv[1] not in ("host", "mcu"):
+        print("usage: kws live <host|mcu> <wav>   (the microphone front end of the reference is not part of this port)")
+        return 0 if len(argv) >= 2 and argv[1] in ("host", "mcu") else 1
+    run(argv[2], q15=(argv[1] == "mcu"))
+    return 0

@@ -54,7 +54,7 @@ Commands
 
 Commands
     mcu     KWS on a wav file: mcu file <wav> | mcu frame <wav>
-    live    (needs a microphone / the board: not part of this port)
+    live    The firmware's continuous mode replayed on a wav: live host <wav> | live mcu <wav>
 ''')
     parser.add_argument('command', help='Command to run')
     args = parser.parse_args(self.argv[2:3])
@@ -79,8 +79,8 @@ Commands
     self.rc = mfcc_on_mcu.main(self.argv[2:])
 
   def kws_live(self):
-    print('kws live needs a microphone stream; see edison_amd.stream for the batched streaming path')
-    self.rc = 0
+    from edison_amd.kws import kws_live
+    self.rc = kws_live.main(self.argv[2:])
 
   def kws_mcu(self):
     from edison_amd.kws import kws_host

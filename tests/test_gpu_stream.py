@@ -78,6 +78,29 @@ def test_stream_q15_and_output_filter(ctx, oracle_mod, oracle_model, hop, chunk)
     st.close()
 
 
+def test_kws_live_replay(ctx, kws_golden, oracle_mod, oracle_model, tmp_path, capsys):
+    """`kws live mcu <wav>`: the firmware's continuous loop on a file -- features (variant C), sliding window, network,
+    output filter, FSM. The reference wav says "edison": the filtered wake-word output crosses the threshold, the FSM
+    goes IDLE -> HOT, and every printed stage equals the oracle chain."""
+    import scipy.io.wavfile as wavfile
+    from edison_amd import main as cli
+    from edison_amd.kws import kws_live
+    a = kws_golden["kws_zero_audio"][:31 * 1024]
+    wav = str(tmp_path / "e.wav")
+    wavfile.write(wav, 16000, a)
+    r = kws_live.run(wav, q15=True, ctx=ctx)
+    out = capsys.readouterr().out
+    assert len(out.splitlines()) == 31 and "[FSM IDLE -> HOT]" in out and "spotted edison" in out
+    feat = oracle_mod.net_input_q15(oracle_mod.mfcc_q15(a))
+    o = oracle_mod.cnn(oracle_model, _windows_from_features(feat), n_threads=4)
+    assert np.array_equal(r["result"]["softmax"], o["softmax"])
+    filt, likely, spotted, _ = oracle_mod.output_filter(o["softmax"])
+    assert np.array_equal(r["result"]["filtered"], filt) and np.array_equal(r["result"]["spotted"], spotted)
+    assert r["state"] == "HOT" and r["commands"] == []
+    assert cli.main(["main.py", "kws", "live", "host", wav]) == 0
+    assert "likely:" in capsys.readouterr().out
+
+
 def test_stream_utterance_equals_kws(ctx, kws_golden):
     """Feeding the 31 frames of the reference wav (hop 1024) ends on the same decision as the batch KWS call."""
     from edison_amd.stream import Stream
