@@ -24,9 +24,6 @@ extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_t
 
 struct edison_ctx
 {
-	ed_q15_tables_t *d_q15; /* variant C (firmware Q15); NULL when the configured filterbank does not fit it */
-	int q15_nlo, q15_nhi;   /* host copy of the table shape: selects the kernel instance */
-	char q15_err[160];
 	int device;
 	int n_cu;
 	size_t hbm_bytes;
@@ -35,6 +32,9 @@ struct edison_ctx
 	hipStream_t stream;
 	ed_mfcc_tables_t *d_tab[2]; /* variant A, B */
 	int mel_NLO[2], mel_NHI[2];
+	ed_q15_tables_t *d_q15; /* variant C (firmware Q15); NULL when the configured filterbank does not fit it */
+	int q15_nlo, q15_nhi;   /* host copy of the table shape: selects the kernel instance */
+	char q15_err[160];      /* why variant C is unavailable, when it is */
 	ed_cnn_model_t *d_model;           /* layer-by-layer diagnostic kernel (edison_cnn_layers) */
 	ed_cnn_mfma_model_t *d_model_mfma; /* MFMA fast path                                       */
 	int have_model;
@@ -69,8 +69,5 @@ int ed_ctx_mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, 
 int ed_ctx_mfcc_q15_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
                            int64_t frame_step, int n_coef, int16_t *mfcc_i16, float *mfcc_f32, int8_t *feat, int stages,
                            int16_t *fft, int16_t *spec, int16_t *mel);
-int ed_ctx_ensure_scratch(edison_ctx *ctx, size_t bytes);
-int ed_ctx_cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *logits, int8_t *softmax,
-                      int32_t *argmax);
 
 #endif

@@ -356,12 +356,6 @@ extern "C" int edison_cnn_layers_dev(edison_ctx *ctx, const int8_t *feat, int64_
 	return cnn_launch(ctx, feat, n_utt, NULL, NULL, NULL, acts);
 }
 
-int ed_ctx_ensure_scratch(edison_ctx *ctx, size_t bytes) { return ensure_scratch(ctx, bytes); }
-int ed_ctx_cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *logits, int8_t *softmax, int32_t *argmax)
-{
-	return cnn_launch(ctx, feat, n_utt, logits, softmax, argmax, NULL);
-}
-
 static int kws_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_utt, int64_t utt_stride, int variant, int8_t *feat,
                    int8_t *logits, int8_t *softmax, int32_t *argmax)
 {
