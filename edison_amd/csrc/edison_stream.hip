@@ -41,8 +41,18 @@ struct edison_stream
 	hipEvent_t ev_in, ev_out; /* ordered against the context's current stream with events                      */
 	hipGraph_t graph;
 	hipGraphExec_t exec;
+	/* host-pointer pushes of small chunks: pinned staging buffers and a second graph that also holds the upload and the
+	 * downloads, so that a push is one memcpy in, ONE graph launch, one wait, one memcpy out (microphone latency path) */
+	int16_t *h_in;
+	unsigned char *h_out;
+	size_t off_soft, off_argmax, off_filt, off_likely, off_spotted, h_out_bytes;
+	hipGraph_t graph_h;
+	hipGraphExec_t exec_h;
+	int last_push_staged;
 	int64_t frames_seen;
 };
+
+#define ED_STREAM_STAGED_MAX_BYTES (1u << 20) /* chunks above 1 MB of samples go through plain async copies */
 
 __global__ void ed_stream_shift_kernel(int16_t *audio, int tail, int new_samples, int8_t *feat, int chunk)
 {
@@ -140,6 +150,10 @@ extern "C" void edison_stream_destroy(edison_stream *s)
 	if (s->own) (void)hipStreamSynchronize(s->own);
 	if (s->exec) (void)hipGraphExecDestroy(s->exec);
 	if (s->graph) (void)hipGraphDestroy(s->graph);
+	if (s->exec_h) (void)hipGraphExecDestroy(s->exec_h);
+	if (s->graph_h) (void)hipGraphDestroy(s->graph_h);
+	if (s->h_in) (void)hipHostFree(s->h_in);
+	if (s->h_out) (void)hipHostFree(s->h_out);
 	if (s->d_audio) (void)hipFree(s->d_audio);
 	if (s->d_feat) (void)hipFree(s->d_feat);
 	if (s->d_soft) (void)hipFree(s->d_soft);
@@ -240,6 +254,42 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 		else
 			r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: cannot begin graph capture on this stream");
 	}
+	const size_t in_bytes = sizeof(int16_t) * (size_t)s->chunk * s->hop;
+	if (r == EDISON_OK && in_bytes <= ED_STREAM_STAGED_MAX_BYTES)
+	{
+		/* the staged variant: upload + push + downloads in one graph, against pinned host buffers */
+		const size_t c = (size_t)s->chunk;
+		size_t off = c * EDISON_NET_OUT;                                /* logits at 0 */
+		s->off_soft = off; off += c * EDISON_NET_OUT;
+		off = (off + 15) & ~(size_t)15; s->off_argmax = off; off += c * sizeof(int32_t);
+		off = (off + 15) & ~(size_t)15; s->off_filt = off; off += s->filter ? c * EDISON_NET_OUT * sizeof(float) : 0;
+		s->off_likely = off; off += s->filter ? c * sizeof(int32_t) : 0;
+		s->off_spotted = off; off += s->filter ? c * sizeof(int32_t) : 0;
+		s->h_out_bytes = off;
+		e = hipHostMalloc((void **)&s->h_in, in_bytes, hipHostMallocDefault);
+		if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, s->h_out_bytes, hipHostMallocDefault);
+		if (e == hipSuccess) e = hipStreamBeginCapture(s->own, hipStreamCaptureModeThreadLocal);
+		if (e == hipSuccess)
+		{
+			hipError_t c1 = hipMemcpyAsync(s->d_audio + s->tail, s->h_in, in_bytes, hipMemcpyHostToDevice, s->own);
+			r = enqueue_push(s);
+			if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out, s->d_logits, c * EDISON_NET_OUT, hipMemcpyDeviceToHost, s->own);
+			if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out + s->off_soft, s->d_soft, c * EDISON_NET_OUT, hipMemcpyDeviceToHost, s->own);
+			if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out + s->off_argmax, s->d_argmax, c * sizeof(int32_t), hipMemcpyDeviceToHost, s->own);
+			if (s->filter)
+			{
+				if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out + s->off_filt, s->d_filt, c * EDISON_NET_OUT * sizeof(float), hipMemcpyDeviceToHost, s->own);
+				if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out + s->off_likely, s->d_likely, c * sizeof(int32_t), hipMemcpyDeviceToHost, s->own);
+				if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out + s->off_spotted, s->d_spotted, c * sizeof(int32_t), hipMemcpyDeviceToHost, s->own);
+			}
+			hipError_t e2 = hipStreamEndCapture(s->own, &s->graph_h);
+			if (r == EDISON_OK && (c1 != hipSuccess || e2 != hipSuccess)) r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: staged graph capture failed");
+			if (r == EDISON_OK && hipGraphInstantiate(&s->exec_h, s->graph_h, NULL, NULL, 0) != hipSuccess)
+				r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: staged graph instantiation failed");
+		}
+		else
+			r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: pinned staging buffers / capture unavailable");
+	}
 	if (r != EDISON_OK) { edison_stream_destroy(s); return r; }
 	*out = s;
 	return EDISON_OK;
@@ -267,6 +317,7 @@ extern "C" int edison_stream_push_dev(edison_stream *s, const int16_t *samples, 
 	ED_HIP(ctx, hipStreamWaitEvent(s->own, s->ev_in, 0));
 	ED_HIP(ctx, hipMemcpyAsync(s->d_audio + s->tail, samples, nnew * sizeof(int16_t), hipMemcpyDeviceToDevice, s->own));
 	ED_HIP(ctx, hipGraphLaunch(s->exec, s->own));
+	s->last_push_staged = 0;
 	if (logits) ED_HIP(ctx, hipMemcpyAsync(logits, s->d_logits, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToDevice, s->own));
 	if (softmax) ED_HIP(ctx, hipMemcpyAsync(softmax, s->d_soft, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToDevice, s->own));
 	if (argmax) ED_HIP(ctx, hipMemcpyAsync(argmax, s->d_argmax, (size_t)s->chunk * sizeof(int32_t), hipMemcpyDeviceToDevice, s->own));
@@ -283,6 +334,20 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 	if (!s || !samples) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
 	const size_t nnew = (size_t)s->chunk * s->hop;
+	if (s->exec_h)
+	{
+		const size_t c = (size_t)s->chunk;
+		memcpy(s->h_in, samples, nnew * sizeof(int16_t));
+		ED_HIP(ctx, hipGraphLaunch(s->exec_h, s->own));
+		ED_HIP(ctx, hipStreamSynchronize(s->own));
+		if (logits) memcpy(logits, s->h_out, c * EDISON_NET_OUT);
+		if (softmax) memcpy(softmax, s->h_out + s->off_soft, c * EDISON_NET_OUT);
+		if (argmax) memcpy(argmax, s->h_out + s->off_argmax, c * sizeof(int32_t));
+		s->last_push_staged = 1;
+		s->frames_seen += s->chunk;
+		return EDISON_OK;
+	}
+	s->last_push_staged = 0;
 	ED_HIP(ctx, hipMemcpyAsync(s->d_audio + s->tail, samples, nnew * sizeof(int16_t), hipMemcpyHostToDevice, s->own));
 	ED_HIP(ctx, hipGraphLaunch(s->exec, s->own));
 	if (logits) ED_HIP(ctx, hipMemcpyAsync(logits, s->d_logits, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToHost, s->own));
@@ -300,6 +365,15 @@ static int stream_filter_out(edison_stream *s, float *filt, int32_t *likely, int
 	if (!s) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
 	if (!s->filter) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: created without the output filter");
+	if (host && s->last_push_staged)
+	{
+		/* the staged push already brought them to the host */
+		const size_t c = (size_t)s->chunk;
+		if (filt) memcpy(filt, s->h_out + s->off_filt, c * EDISON_NET_OUT * sizeof(float));
+		if (likely) memcpy(likely, s->h_out + s->off_likely, c * sizeof(int32_t));
+		if (spotted) memcpy(spotted, s->h_out + s->off_spotted, c * sizeof(int32_t));
+		return EDISON_OK;
+	}
 	const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
 	if (filt) ED_HIP(ctx, hipMemcpyAsync(filt, s->d_filt, sizeof(float) * (size_t)s->chunk * EDISON_NET_OUT, kind, s->own));
 	if (likely) ED_HIP(ctx, hipMemcpyAsync(likely, s->d_likely, sizeof(int32_t) * (size_t)s->chunk, kind, s->own));
