@@ -43,6 +43,7 @@ struct edison_stream
 	hipGraphExec_t exec;
 	/* host-pointer pushes of small chunks: pinned staging buffers and a second graph that also holds the upload and the
 	 * downloads, so that a push is one memcpy in, ONE graph launch, one wait, one memcpy out (microphone latency path) */
+	unsigned char *d_out; /* one block: logits | softmax | argmax | filt | likely | spotted at the offsets below */
 	int16_t *h_in;
 	unsigned char *h_out;
 	size_t off_soft, off_argmax, off_filt, off_likely, off_spotted, h_out_bytes;
@@ -156,13 +157,8 @@ extern "C" void edison_stream_destroy(edison_stream *s)
 	if (s->h_out) (void)hipHostFree(s->h_out);
 	if (s->d_audio) (void)hipFree(s->d_audio);
 	if (s->d_feat) (void)hipFree(s->d_feat);
-	if (s->d_soft) (void)hipFree(s->d_soft);
-	if (s->d_logits) (void)hipFree(s->d_logits);
-	if (s->d_argmax) (void)hipFree(s->d_argmax);
+	if (s->d_out) (void)hipFree(s->d_out); /* logits, softmax, argmax and the filter outputs live in this one block */
 	if (s->d_filt_state) (void)hipFree(s->d_filt_state);
-	if (s->d_filt) (void)hipFree(s->d_filt);
-	if (s->d_likely) (void)hipFree(s->d_likely);
-	if (s->d_spotted) (void)hipFree(s->d_spotted);
 	if (s->ev_in) (void)hipEventDestroy(s->ev_in);
 	if (s->ev_out) (void)hipEventDestroy(s->ev_out);
 	if (s->own) (void)hipStreamDestroy(s->own);
@@ -219,15 +215,30 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipMalloc((void **)&s->d_audio, sizeof(int16_t) * (size_t)(s->tail + s->chunk * s->hop) + 16);
 	if (e == hipSuccess) e = hipMalloc((void **)&s->d_feat, (size_t)(30 + s->chunk) * EDISON_NUM_MFCC + 16);
-	if (e == hipSuccess) e = hipMalloc((void **)&s->d_soft, (size_t)s->chunk * EDISON_NET_OUT + 16);
-	if (e == hipSuccess) e = hipMalloc((void **)&s->d_logits, (size_t)s->chunk * EDISON_NET_OUT + 16);
-	if (e == hipSuccess) e = hipMalloc((void **)&s->d_argmax, sizeof(int32_t) * (size_t)s->chunk);
+	{
+		/* every output of a push in one device block, so that the host path fetches them with a single copy */
+		const size_t c = (size_t)s->chunk;
+		size_t off = c * EDISON_NET_OUT;                                /* logits at 0 */
+		s->off_soft = off; off += c * EDISON_NET_OUT;
+		off = (off + 15) & ~(size_t)15; s->off_argmax = off; off += c * sizeof(int32_t);
+		off = (off + 15) & ~(size_t)15; s->off_filt = off; off += s->filter ? c * EDISON_NET_OUT * sizeof(float) : 0;
+		s->off_likely = off; off += s->filter ? c * sizeof(int32_t) : 0;
+		s->off_spotted = off; off += s->filter ? c * sizeof(int32_t) : 0;
+		s->h_out_bytes = off;
+		if (e == hipSuccess) e = hipMalloc((void **)&s->d_out, s->h_out_bytes + 16);
+		if (e == hipSuccess)
+		{
+			s->d_logits = (int8_t *)s->d_out;
+			s->d_soft = (int8_t *)(s->d_out + s->off_soft);
+			s->d_argmax = (int32_t *)(s->d_out + s->off_argmax);
+			s->d_filt = (float *)(s->d_out + s->off_filt);
+			s->d_likely = (int32_t *)(s->d_out + s->off_likely);
+			s->d_spotted = (int32_t *)(s->d_out + s->off_spotted);
+		}
+	}
 	if (s->filter)
 	{
 		if (e == hipSuccess) e = hipMalloc((void **)&s->d_filt_state, sizeof(float) * EDISON_NET_OUT);
-		if (e == hipSuccess) e = hipMalloc((void **)&s->d_filt, sizeof(float) * (size_t)s->chunk * EDISON_NET_OUT);
-		if (e == hipSuccess) e = hipMalloc((void **)&s->d_likely, sizeof(int32_t) * (size_t)s->chunk);
-		if (e == hipSuccess) e = hipMalloc((void **)&s->d_spotted, sizeof(int32_t) * (size_t)s->chunk);
 	}
 	if (e != hipSuccess)
 	{
@@ -258,14 +269,6 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 	if (r == EDISON_OK && in_bytes <= ED_STREAM_STAGED_MAX_BYTES)
 	{
 		/* the staged variant: upload + push + downloads in one graph, against pinned host buffers */
-		const size_t c = (size_t)s->chunk;
-		size_t off = c * EDISON_NET_OUT;                                /* logits at 0 */
-		s->off_soft = off; off += c * EDISON_NET_OUT;
-		off = (off + 15) & ~(size_t)15; s->off_argmax = off; off += c * sizeof(int32_t);
-		off = (off + 15) & ~(size_t)15; s->off_filt = off; off += s->filter ? c * EDISON_NET_OUT * sizeof(float) : 0;
-		s->off_likely = off; off += s->filter ? c * sizeof(int32_t) : 0;
-		s->off_spotted = off; off += s->filter ? c * sizeof(int32_t) : 0;
-		s->h_out_bytes = off;
 		e = hipHostMalloc((void **)&s->h_in, in_bytes, hipHostMallocDefault);
 		if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, s->h_out_bytes, hipHostMallocDefault);
 		if (e == hipSuccess) e = hipStreamBeginCapture(s->own, hipStreamCaptureModeThreadLocal);
@@ -273,15 +276,7 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 		{
 			hipError_t c1 = hipMemcpyAsync(s->d_audio + s->tail, s->h_in, in_bytes, hipMemcpyHostToDevice, s->own);
 			r = enqueue_push(s);
-			if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out, s->d_logits, c * EDISON_NET_OUT, hipMemcpyDeviceToHost, s->own);
-			if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out + s->off_soft, s->d_soft, c * EDISON_NET_OUT, hipMemcpyDeviceToHost, s->own);
-			if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out + s->off_argmax, s->d_argmax, c * sizeof(int32_t), hipMemcpyDeviceToHost, s->own);
-			if (s->filter)
-			{
-				if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out + s->off_filt, s->d_filt, c * EDISON_NET_OUT * sizeof(float), hipMemcpyDeviceToHost, s->own);
-				if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out + s->off_likely, s->d_likely, c * sizeof(int32_t), hipMemcpyDeviceToHost, s->own);
-				if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out + s->off_spotted, s->d_spotted, c * sizeof(int32_t), hipMemcpyDeviceToHost, s->own);
-			}
+			if (c1 == hipSuccess) c1 = hipMemcpyAsync(s->h_out, s->d_out, s->h_out_bytes, hipMemcpyDeviceToHost, s->own);
 			hipError_t e2 = hipStreamEndCapture(s->own, &s->graph_h);
 			if (r == EDISON_OK && (c1 != hipSuccess || e2 != hipSuccess)) r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: staged graph capture failed");
 			if (r == EDISON_OK && hipGraphInstantiate(&s->exec_h, s->graph_h, NULL, NULL, 0) != hipSuccess)
