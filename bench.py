@@ -320,6 +320,17 @@ def main():
                                  peak=HBM_PEAK_GBS, unit="GB/s", frac=round(kach / HBM_PEAK_GBS, 4), traffic=None,
                                  bytes_per_unit=KWS_BYTES_PER_UTT, units_per_launch=nu, kernel_ms=round(kev_ms, 4)),
                    class_histogram=hist)
+        if not args.skip_q15:
+            # the same utterances with the firmware's own features (variant C): what the board would answer, at GPU speed
+            def kws_q15_step(i):
+                ctx.kws_t(audio, nu, 31 * 1024, feat=feat, logits=logits, softmax=soft, argmax=am, q15=True)
+                if gather is not None:
+                    gather(logits)
+            qsteps = max(5, args.steps // 5)
+            kq_ms, _ = timed_region(kws_q15_step, qsteps, min(args.warmup, 3), world)
+            kws["q15_features"] = dict(value=round(world * nu / (kq_ms * 1e-3), 1), unit="inferences/s", steps=qsteps,
+                                       ms_per_step=round(kq_ms, 4),
+                                       class_histogram=torch.bincount(am.to(torch.int64), minlength=10).tolist())
         del audio
 
     # ------------------------------------------------------------------ streaming (configs[4]): rank 0, N = 1 only
