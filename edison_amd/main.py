@@ -1,95 +1,67 @@
 #!/usr/bin/env python
-"""``./main.py <module> <command>`` -- the reference's CLI (audio/main.py:12-39) for the modules that sit on the
-keyword-spotting hot path: ``mfcc host`` / ``mfcc mcu <mode>`` (main.py:80-99,199-205) and ``kws mcu <mode> [file]`` /
-``kws live ...`` (main.py:146-165,231-238). Same dispatch pattern. Where the reference talks to the STM32 board over
-the UART, the board's leg is computed by the GPU's bit-exact variant C. The other modules (mic, acquire, train,
-deploy, mcu) drive the board or Keras training and are out of scope here.
+"""``./main.py <module> <command> [args]`` -- the command line of the reference (audio/main.py) for the modules that sit
+on the keyword-spotting hot path:
+
+    mfcc host [wav]                      audio/main.py:80-99,199     -> edison_amd.mfcc.mfcc
+    mfcc mcu calc|single|file ...        mfcc_on_mcu.py:526-548      -> edison_amd.mfcc.mfcc_on_mcu
+    kws  mcu single|fileinf|file|frame   kws_on_mcu.py:650-690       -> edison_amd.kws.kws_host
+    kws  live host|mcu <wav>             audio/main.py:231-233       -> edison_amd.kws.kws_live
+
+Where the reference talks to the STM32 board over the UART, the board's leg is computed by the GPU's bit-exact
+variant C. The remaining reference modules (mic, acquire, train, deploy, mcu) drive the board or Keras training and are
+out of scope. One deliberate difference: the reference's ``kws`` dispatcher runs ``live`` and then falls into the
+"Unrecognized command" branch of the next ``if`` (main.py:158-165, exit status 1); here ``kws live`` returns 0.
 """
-import argparse
+import importlib
 import sys
+
+# module -> command -> (python module under edison_amd, how many leading argv entries that module's main() skips)
+COMMANDS = {
+    "mfcc": {
+        "host": ("edison_amd.mfcc.mfcc", 3),
+        "mcu": ("edison_amd.mfcc.mfcc_on_mcu", 2),
+    },
+    "kws": {
+        "mcu": ("edison_amd.kws.kws_host", 2),
+        "live": ("edison_amd.kws.kws_live", 2),
+    },
+}
+
+USAGE = """usage: edison <module> <command> [<args>]
+
+  mfcc host [wav]                        MFCC variants A / B of a wav on the GPU
+  mfcc mcu calc [file]                   write the firmware's mel_constants.h
+  mfcc mcu single [wav] | file <wav>     host model (variant B) against the firmware's arithmetic (variant C)
+  kws  mcu single [n] | fileinf <wav> | file <wav> | frame <wav>
+  kws  live host|mcu <wav>               the firmware's continuous mode replayed on a wav
+"""
 
 
 class Edison(object):
+    """Same shape as the reference's dispatcher class: construct with argv, read ``rc``."""
 
-  def __init__(self, argv=None):
-    self.argv = list(sys.argv if argv is None else argv)
-    self.rc = 0
-    parser = argparse.ArgumentParser(
-      description='Edison Keyword Spotting tools (MI355X hot path)',
-      usage='''edison <module> <command> [<args>]
+    def __init__(self, argv=None):
+        self.argv = list(sys.argv if argv is None else argv)
+        self.rc = self._run()
 
-The modules:
-    mfcc      Mel frequency cepstral coefficient tools
-    kws       Experiment with the keyword spotting algorithm
-''')
-    parser.add_argument('module', help='Which module to select')
-    args = parser.parse_args(self.argv[1:2])
-    if args.module.startswith('_') or not hasattr(self, args.module) or args.module in ('argv', 'rc'):
-      print('Unrecognized module')
-      parser.print_help()
-      self.rc = 1
-      return
-    getattr(self, args.module)()
-
-  def mfcc(self):
-    parser = argparse.ArgumentParser(usage='''edison mfcc <command> [<args>]
-
-Commands
-    host    Run MFCC on host (MI355X)
-    mcu     The board comparisons with the GPU's Q15 MFCC as the board: mcu calc [file] | single [wav] | file <wav>
-''')
-    parser.add_argument('command', help='Command to run')
-    args = parser.parse_args(self.argv[2:3])
-    if args.command == 'host':
-      self.mfcc_host()
-    elif args.command == 'mcu':
-      self.mfcc_mcu()
-    else:
-      print('Unrecognized command')
-      parser.print_help()
-      self.rc = 1
-
-  def kws(self):
-    parser = argparse.ArgumentParser(usage='''edison kws <command> [<args>]
-
-Commands
-    mcu     KWS on a wav file: mcu file <wav> | mcu frame <wav>
-    live    The firmware's continuous mode replayed on a wav: live host <wav> | live mcu <wav>
-''')
-    parser.add_argument('command', help='Command to run')
-    args = parser.parse_args(self.argv[2:3])
-    if args.command == 'live':
-      self.kws_live()
-    elif args.command == 'mcu':   # the reference falls through to "Unrecognized command" after `live` (main.py:158-165)
-      self.kws_mcu()
-    else:
-      print('Unrecognized command')
-      parser.print_help()
-      self.rc = 1
-
-  ######################################################
-  # Final commands to run
-
-  def mfcc_host(self):
-    from edison_amd.mfcc import mfcc as mfcc_script
-    self.rc = mfcc_script.main(self.argv[3:])
-
-  def mfcc_mcu(self):
-    from edison_amd.mfcc import mfcc_on_mcu
-    self.rc = mfcc_on_mcu.main(self.argv[2:])
-
-  def kws_live(self):
-    from edison_amd.kws import kws_live
-    self.rc = kws_live.main(self.argv[2:])
-
-  def kws_mcu(self):
-    from edison_amd.kws import kws_host
-    self.rc = kws_host.main(self.argv[2:])
+    def _run(self):
+        module = self.argv[1] if len(self.argv) > 1 else None
+        if module not in COMMANDS:
+            print("Unrecognized module")
+            print(USAGE)
+            return 1
+        command = self.argv[2] if len(self.argv) > 2 else None
+        if command not in COMMANDS[module]:
+            print("Unrecognized command")
+            print(USAGE)
+            return 1
+        target, skip = COMMANDS[module][command]
+        return importlib.import_module(target).main(self.argv[skip:])
 
 
 def main(argv=None):
-  return Edison(argv).rc
+    return Edison(argv).rc
 
 
-if __name__ == '__main__':
-  sys.exit(main())
+if __name__ == "__main__":
+    sys.exit(main())
