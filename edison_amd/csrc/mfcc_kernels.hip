@@ -458,7 +458,293 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 	}
 }
 
+/* ================================================================================================================
+ * Two frames per wavefront, packed fp32.
+ *
+ * Measured on gfx950 (tools/ubench/fft_pk.hip): a radix-8 pass with its twiddles costs ~3.7 cycles per VALU
+ * instruction per wavefront at every occupancy from 1 to 8 waves/SIMD -- and exactly the same when every instruction
+ * is the packed form (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) working on two independent values per lane. The
+ * kernel is bound by instruction issue, not by ALU width, so the fast path carries TWO frames per wavefront: frame A in
+ * the .x halves and frame B in the .y halves of 64-bit register pairs. All arithmetic (the three radix-8 passes, the
+ * twiddles, the real-FFT split, the mel and DCT dot products) then costs one instruction for both frames; only the
+ * data movement that works on 32-bit registers (int16 -> fp32, DPP / permlane exchanges, ds_bpermute, sqrt, log) is
+ * issued once per frame. Same algorithm, same operation order per frame as ed_mfcc_kernel above, which stays as the
+ * stage-dump kernel and as the checker of this one (tests compare the two paths bit for bit).
+ * LDS per wave: 526 transpose slots of 16 B (re A, re B, im A, im B: register pairs stay pairs), the two spectra interleaved as float2[516]
+ * behind them (aliased like above), the DCT inputs of both frames.
+ */
+typedef float ed_f2 __attribute__((ext_vector_type(2)));
+#ifndef ED2_WPB
+#define ED2_WPB 4
+#endif
+#define ED2_S_OFF 1088    /* float offset of the interleaved spectra: their zero padding lies beyond the 2104 transpose floats */
+#define ED2_L_OFF 2128
+#define ED2_XBUF_FLOATS 2208
+
+/* NOT (ed_f2)(a, b): in C++ that is a cast of the comma expression, i.e. a splat of b */
+__device__ __forceinline__ ed_f2 ed_mk2(float a, float b) { ed_f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ ed_f2 ed_splat(float x) { return ed_mk2(x, x); }
+__device__ __forceinline__ ed_f2 ed_fma2(ed_f2 a, ed_f2 b, ed_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ void ed_dft4_2(ed_f2 y0r, ed_f2 y0i, ed_f2 y1r, ed_f2 y1i, ed_f2 y2r, ed_f2 y2i, ed_f2 y3r, ed_f2 y3i,
+                                          ed_f2 &o0r, ed_f2 &o0i, ed_f2 &o1r, ed_f2 &o1i, ed_f2 &o2r, ed_f2 &o2i, ed_f2 &o3r, ed_f2 &o3i)
+{
+	ed_f2 a0r = y0r + y2r, a0i = y0i + y2i;
+	ed_f2 a1r = y0r - y2r, a1i = y0i - y2i;
+	ed_f2 a2r = y1r + y3r, a2i = y1i + y3i;
+	ed_f2 a3r = y1i - y3i, a3i = y3r - y1r;
+	o0r = a0r + a2r; o0i = a0i + a2i;
+	o2r = a0r - a2r; o2i = a0i - a2i;
+	o1r = a1r + a3r; o1i = a1i + a3i;
+	o3r = a1r - a3r; o3i = a1i - a3i;
+}
+
+/* ed_radix8 on two frames at once */
+__device__ __forceinline__ void ed_radix8_2(ed_f2 (&r)[8], ed_f2 (&i)[8])
+{
+	const ed_f2 h = ed_splat(0.70710678118654752440f), nh = ed_splat(-0.70710678118654752440f);
+	ed_f2 ur[4], ui[4], vr[4], vi[4];
+#pragma unroll
+	for (int a = 0; a < 4; a++)
+	{
+		ur[a] = r[a] + r[a + 4]; ui[a] = i[a] + i[a + 4];
+		vr[a] = r[a] - r[a + 4]; vi[a] = i[a] - i[a + 4];
+	}
+	ed_dft4_2(ur[0], ui[0], ur[1], ui[1], ur[2], ui[2], ur[3], ui[3], r[0], i[0], r[2], i[2], r[4], i[4], r[6], i[6]);
+	const ed_f2 t1r = vr[1] + vi[1], t1i = vi[1] - vr[1];
+	const ed_f2 t3r = vi[3] - vr[3], t3i = -(vi[3] + vr[3]);
+	const ed_f2 a0r = vr[0] + vi[2], a0i = vi[0] - vr[2];
+	const ed_f2 a1r = vr[0] - vi[2], a1i = vi[0] + vr[2];
+	const ed_f2 u_r = t1r + t3r, u_i = t1i + t3i;
+	const ed_f2 w_r = t1i - t3i, w_i = t3r - t1r;
+	r[1] = ed_fma2(h, u_r, a0r);  i[1] = ed_fma2(h, u_i, a0i);
+	r[5] = ed_fma2(nh, u_r, a0r); i[5] = ed_fma2(nh, u_i, a0i);
+	r[3] = ed_fma2(h, w_r, a1r);  i[3] = ed_fma2(h, w_i, a1i);
+	r[7] = ed_fma2(nh, w_r, a1r); i[7] = ed_fma2(nh, w_i, a1i);
+}
+
+/* the VALU transpose works on 32-bit registers: once per frame */
+template <int LB0, int LB1, int LB2>
+__device__ __forceinline__ void ed_transpose8_2(ed_f2 (&x)[8], int lane)
+{
+	float a[8], b[8];
+#pragma unroll
+	for (int i = 0; i < 8; i++) { a[i] = x[i].x; b[i] = x[i].y; }
+	ed_transpose8<LB0, LB1, LB2>(a, lane);
+	ed_transpose8<LB0, LB1, LB2>(b, lane);
+#pragma unroll
+	for (int i = 0; i < 8; i++) x[i] = ed_mk2(a[i], b[i]);
+}
+
+__device__ __forceinline__ ed_f2 ed_sum_halves2(ed_f2 x) { return ed_mk2(ed_sum_halves(x.x), ed_sum_halves(x.y)); }
+__device__ __forceinline__ ed_f2 ed_sum_rows2(ed_f2 x) { return ed_mk2(ed_sum_rows(x.x), ed_sum_rows(x.y)); }
+
+template <bool ALIGNED, int NLO, int NHI>
+__global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
+{
+	extern __shared__ __attribute__((aligned(16))) float smem[];
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const float4 *dctl = reinterpret_cast<const float4 *>(smem);                     /* [2][64] x 4 coefficients */
+	const float2 *tpl = reinterpret_cast<const float2 *>(smem + 512);                /* [4][64] split twiddles   */
+	const float4 *melw4 = reinterpret_cast<const float4 *>(smem + ED_FIXTAB_FLOATS); /* [NLO+NHI][64] quads      */
+	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + wave * ED2_XBUF_FLOATS; /* wave-private          */
+
+	/* frame pair p of this wave: frames 2p (A) and 2p+1 (B; the last pair of an odd batch repeats A and drops B) */
+	const uint32_t n_frames = (uint32_t)args.n_frames;
+	const uint32_t n_pairs = (n_frames + 1) >> 1;
+	const uint32_t stride = gridDim.x * ED2_WPB;
+	uint32_t p = blockIdx.x * ED2_WPB + wave;
+	uint32_t rawA[8], rawB[8];
+	if (p < n_pairs)
+	{
+		const uint32_t fb = 2 * p + 1 < n_frames ? 2 * p + 1 : 2 * p;
+		ed_load_frame<ALIGNED>(ed_frame_ptr(args, 2 * p), lane, rawA);
+		ed_load_frame<ALIGNED>(ed_frame_ptr(args, fb), lane, rawB);
+	}
+	{
+		const float4 *src = reinterpret_cast<const float4 *>(&tab->dct4[0][0][0]);
+		float4 *dst = reinterpret_cast<float4 *>(smem);
+		for (int t = threadIdx.x; t < (ED_FIXTAB_FLOATS + (NLO + NHI) * 256) / 4; t += blockDim.x) dst[t] = src[t];
+	}
+	float t1r[8], t1i[8], t2r[8], t2i[8];
+#pragma unroll
+	for (int q = 1; q < 8; q++)
+	{
+		const float2 a = *reinterpret_cast<const float2 *>(&tab->tw1[q][lane][0]);
+		const float2 b = *reinterpret_cast<const float2 *>(&tab->tw2[q][lane][0]);
+		t1r[q] = a.x; t1i[q] = a.y; t2r[q] = b.x; t2i[q] = b.y;
+	}
+	__syncthreads();
+	const int mel_slo4 = tab->mel_slo4[lane], mel_shi4 = tab->mel_shi4[lane];
+	const float log_offset = tab->log_offset;
+	const bool do_log = tab->always_log || args.use_log;
+	const int k0 = ED_K0(lane);
+	const int k0p = (64 - k0) & 63;
+	const int pull = (ED_T2_LDS ? k0p : (((k0p & 7) << 3) | (k0p >> 3))) << 2;
+	const int hi3 = lane >> 3, lo3 = lane & 7;
+	float4 *xc4 = reinterpret_cast<float4 *>(xbuf);
+	ed_f2 *S2 = reinterpret_cast<ed_f2 *>(xbuf + ED2_S_OFF);
+	if (lane < 3) S2[513 + lane] = ed_splat(0.0f);
+
+	for (; p < n_pairs; p += stride)
+	{
+		const uint32_t fA = 2 * p;
+		const bool haveB = fA + 1 < n_frames;
+		/* ---- 1. unpack both frames, put the next pair's loads in flight */
+		ed_f2 re[8], im[8];
+#pragma unroll
+		for (int a = 0; a < 8; a++)
+		{
+			re[a] = ed_mk2((float)(int16_t)(rawA[a] & 0xffffu), (float)(int16_t)(rawB[a] & 0xffffu));
+			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
+		}
+		if (p + stride < n_pairs)
+		{
+			const uint32_t na = 2 * (p + stride), nb = na + 1 < n_frames ? na + 1 : na;
+			ed_load_frame<ALIGNED>(ed_frame_ptr(args, na), lane, rawA);
+			ed_load_frame<ALIGNED>(ed_frame_ptr(args, nb), lane, rawB);
+		}
+
+		/* ---- 2a. pass 1 + twiddle W512^(lane*p) */
+		ed_radix8_2(re, im);
+#pragma unroll
+		for (int q = 1; q < 8; q++)
+		{
+			const ed_f2 wr = ed_splat(t1r[q]), wi = ed_splat(t1i[q]);
+			const ed_f2 xr = re[q], xi = im[q];
+			re[q] = xr * wr - xi * wi;
+			im[q] = xr * wi + xi * wr;
+		}
+		ed_transpose8_2<3, 4, 5>(re, lane);
+		ed_transpose8_2<3, 4, 5>(im, lane);
+
+		/* ---- 2b. pass 2 + twiddle W64^(c*q) */
+		ed_radix8_2(re, im);
+#pragma unroll
+		for (int q = 1; q < 8; q++)
+		{
+			const ed_f2 wr = ed_splat(t2r[q]), wi = ed_splat(t2i[q]);
+			const ed_f2 xr = re[q], xi = im[q];
+			re[q] = xr * wr - xi * wi;
+			im[q] = xr * wi + xi * wr;
+		}
+		/* transpose 2 through LDS, both frames in one 16-byte slot: (lane 8p+c, reg q) -> (lane p+8q, reg c); slot
+		 * 66c + p + 8q keeps the ds_write_b128 (8-lane groups, stride 66 slots = 8 banks mod 64) and the ds_read_b128
+		 * (consecutive slots) free of bank conflicts */
+#pragma unroll
+		for (int q = 0; q < 8; q++) xc4[66 * lo3 + hi3 + 8 * q] = make_float4(re[q].x, re[q].y, im[q].x, im[q].y); /* pairs stay pairs */
+		ed_wave_sync();
+#pragma unroll
+		for (int c = 0; c < 8; c++)
+		{
+			const float4 v = xc4[66 * c + lane];
+			re[c] = ed_mk2(v.x, v.y); im[c] = ed_mk2(v.z, v.w);
+		}
+		ed_wave_sync();
+
+		/* ---- 2c. pass 3: reg r holds Z[k0 + 64r] of both frames */
+		ed_radix8_2(re, im);
+
+		/* ---- 3. real-FFT split (see ed_mfcc_kernel); the partner values come per frame through ds_bpermute */
+		ed_f2 slo[4], shi[4];
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+		{
+			ed_f2 pzr, pzi;
+			pzr.x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].x)));
+			pzr.y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].y)));
+			pzi.x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].x)));
+			pzi.y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].y)));
+			if (lane == 0) { pzr = re[(8 - m) & 7]; pzi = im[(8 - m) & 7]; }
+			const float2 tw = tpl[64 * m + lane];
+			const ed_f2 twx = ed_splat(tw.x), twy = ed_splat(tw.y);
+			const ed_f2 ar = re[m] + pzr, ai = im[m] - pzi;
+			const ed_f2 br = re[m] - pzr, bi = im[m] + pzi;
+			const ed_f2 tr = twx * bi + twy * br;
+			const ed_f2 ti = twy * bi - twx * br;
+			const ed_f2 xr = ar + tr, xi = ai + ti;
+			const ed_f2 yr = ar - tr, yi = ai - ti;
+			const ed_f2 e0 = xr * xr + xi * xi, e1 = yr * yr + yi * yi;
+			slo[m] = ed_mk2(__builtin_amdgcn_sqrtf(e0.x), __builtin_amdgcn_sqrtf(e0.y));
+			shi[m] = ed_mk2(__builtin_amdgcn_sqrtf(e1.x), __builtin_amdgcn_sqrtf(e1.y));
+		}
+		const ed_f2 e256 = re[4] * re[4] + im[4] * im[4];
+		const ed_f2 s256 = ed_mk2(2.0f * __builtin_amdgcn_sqrtf(e256.x), 2.0f * __builtin_amdgcn_sqrtf(e256.y));
+
+		/* ---- 4. both spectra to LDS, interleaved: S2[k] = (|2X_A[k]|, |2X_B[k]|) */
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+		{
+			S2[k0 + 64 * m] = slo[m];
+			S2[512 - k0 - 64 * m] = shi[m];
+		}
+		if (lane == 0) S2[256] = s256;
+		ed_wave_sync();
+
+		/* ---- 5. mel filterbank, balanced as above; a spectrum quad of both frames is two 16-byte reads */
+		const float4 *S4 = reinterpret_cast<const float4 *>(S2);
+		ed_f2 alo0 = ed_splat(0.0f), alo1 = alo0, ahi0 = alo0, ahi1 = alo0;
+#pragma unroll
+		for (int t = 0; t < NLO; t++)
+		{
+			const float4 sa = S4[2 * (mel_slo4 + t)], sb = S4[2 * (mel_slo4 + t) + 1], w = melw4[t * 64 + lane];
+			alo0 = ed_fma2(ed_mk2(sa.x, sa.y), ed_splat(w.x), alo0); alo1 = ed_fma2(ed_mk2(sa.z, sa.w), ed_splat(w.y), alo1);
+			alo0 = ed_fma2(ed_mk2(sb.x, sb.y), ed_splat(w.z), alo0); alo1 = ed_fma2(ed_mk2(sb.z, sb.w), ed_splat(w.w), alo1);
+		}
+#pragma unroll
+		for (int t = 0; t < NHI; t++)
+		{
+			if (t % 2 == 0) __builtin_amdgcn_sched_barrier(0); /* bounds the registers this stage holds in flight */
+			const float4 sa = S4[2 * (mel_shi4 + t)], sb = S4[2 * (mel_shi4 + t) + 1], w = melw4[(NLO + t) * 64 + lane];
+			ahi0 = ed_fma2(ed_mk2(sa.x, sa.y), ed_splat(w.x), ahi0); ahi1 = ed_fma2(ed_mk2(sa.z, sa.w), ed_splat(w.y), ahi1);
+			ahi0 = ed_fma2(ed_mk2(sb.x, sb.y), ed_splat(w.z), ahi0); ahi1 = ed_fma2(ed_mk2(sb.z, sb.w), ed_splat(w.w), ahi1);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		const ed_f2 elo = ed_sum_rows2(alo0 + alo1), ehi = ed_sum_rows2(ahi0 + ahi1);
+		ed_f2 llo = elo, lhi = ehi;
+		if (do_log)
+		{
+			llo = ed_mk2(__logf(elo.x + log_offset), __logf(elo.y + log_offset));
+			lhi = ed_mk2(__logf(ehi.x + log_offset), __logf(ehi.y + log_offset));
+		}
+
+		/* ---- 6. DCT-II through cos symmetry, both frames */
+		ed_f2 *Lb2 = reinterpret_cast<ed_f2 *>(xbuf + ED2_L_OFF); /* u[16] | v[16] as float2 */
+		if (lane < 16) { Lb2[lane] = llo + lhi; Lb2[16 + lane] = llo - lhi; }
+		ed_wave_sync();
+		const float4 *L4 = reinterpret_cast<const float4 *>(Lb2 + 16 * (lane & 1) + 8 * (lane >> 5));
+		const float4 v0 = L4[0], v1 = L4[1], v2 = L4[2], v3 = L4[3];
+		const float4 w0 = dctl[lane], w1 = dctl[64 + lane];
+		ed_f2 d = ed_mk2(v0.x, v0.y) * ed_splat(w0.x), d1 = ed_mk2(v2.x, v2.y) * ed_splat(w1.x);
+		d = ed_fma2(ed_mk2(v0.z, v0.w), ed_splat(w0.y), d); d1 = ed_fma2(ed_mk2(v2.z, v2.w), ed_splat(w1.y), d1);
+		d = ed_fma2(ed_mk2(v1.x, v1.y), ed_splat(w0.z), d); d1 = ed_fma2(ed_mk2(v3.x, v3.y), ed_splat(w1.z), d1);
+		d = ed_fma2(ed_mk2(v1.z, v1.w), ed_splat(w0.w), d); d1 = ed_fma2(ed_mk2(v3.z, v3.w), ed_splat(w1.w), d1);
+		d = ed_sum_halves2(d + d1);
+		ed_wave_sync(); /* Lb2 / S2 are rewritten by the next pair */
+
+		/* ---- 7. store */
+		if (lane < args.n_coef)
+		{
+			const int64_t at = (int64_t)fA * args.n_coef + lane;
+			if (args.mfcc)
+			{
+				args.mfcc[at] = d.x;
+				if (haveB) args.mfcc[at + args.n_coef] = d.y;
+			}
+			if (args.feat)
+			{
+				ed_f2 q = d * ed_splat(args.feat_scale);
+				const float qa = fminf(fmaxf(q.x, -128.0f), 127.0f), qb = fminf(fmaxf(q.y, -128.0f), 127.0f);
+				args.feat[at] = (int8_t)__float2int_rn(qa);
+				if (haveB) args.feat[at + args.n_coef] = (int8_t)__float2int_rn(qb);
+			}
+		}
+	}
+}
+
 static int g_mfcc_blocks_per_cu[2] = {-1, -1};
+static int g_mfcc2_blocks_per_cu[2] = {-1, -1};
 
 template <int NLO, int NHI>
 static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
@@ -481,6 +767,29 @@ static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables
 	/* 4-byte loads need every frame start 4-byte aligned */
 	const bool aligned = ((reinterpret_cast<uintptr_t>(args->audio) & 3) == 0) && (args->frame_step % 2 == 0) &&
 	                     (args->group_stride % 2 == 0);
+	static const int one_frame = getenv("ED_MFCC_ONE_FRAME") ? atoi(getenv("ED_MFCC_ONE_FRAME")) : 0; /* A/B knob */
+	if (!stages && !one_frame)
+	{
+		/* the fast path: two frames per wavefront in packed fp32 */
+		const size_t lds2 = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_WPB * ED2_XBUF_FLOATS);
+		int *bpc2 = &g_mfcc2_blocks_per_cu[NLO == 2 ? 0 : 1];
+		if (*bpc2 < 0)
+		{
+			int nb = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ed_mfcc2_kernel<true, NLO, NHI>, 64 * ED2_WPB, lds2) != hipSuccess || nb < 1)
+				nb = 1;
+			const char *env = getenv("ED_MFCC_BLOCKS_PER_CU");
+			if (env && atoi(env) > 0 && atoi(env) < nb) nb = atoi(env);
+			*bpc2 = nb;
+		}
+		const int64_t n_pairs = (args->n_frames + 1) / 2;
+		int64_t blocks2 = (n_pairs + ED2_WPB - 1) / ED2_WPB;
+		if (blocks2 > (int64_t)n_cu * *bpc2) blocks2 = (int64_t)n_cu * *bpc2;
+		dim3 grid2((unsigned)blocks2), block2(64 * ED2_WPB);
+		if (aligned) hipLaunchKernelGGL((ed_mfcc2_kernel<true, NLO, NHI>), grid2, block2, lds2, stream, *args, dev_tab);
+		else hipLaunchKernelGGL((ed_mfcc2_kernel<false, NLO, NHI>), grid2, block2, lds2, stream, *args, dev_tab);
+		return (int)hipGetLastError();
+	}
 	dim3 grid((unsigned)blocks), block(64 * ED_WPB);
 	if (stages)
 	{
