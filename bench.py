@@ -250,7 +250,7 @@ def main():
     wall_ms, ev_ms = timed_region(mfcc_step, args.steps, args.warmup, world)
     frames_per_s = world * nf / (wall_ms * 1e-3)
     ach = MFCC_BYTES_PER_FRAME * nf / (ev_ms * 1e-3) / 1e9
-    roofline = dict(bound="hbm", kernel="ed_mfcc_kernel<false, true, 2, 5>", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+    roofline = dict(bound="hbm", kernel="ed_mfcc2_kernel<true, 2, 5>", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, bytes_per_unit=MFCC_BYTES_PER_FRAME,
                     units_per_launch=nf, kernel_ms=round(ev_ms, 4))
     checksum = float(out.double().sum().item())
@@ -288,7 +288,7 @@ def main():
     del bufs
     # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
     # this command, FETCH_SIZE doubled as the gfx950 guide prescribes); only valid for the default batch size
-    tr = hbm_traffic_from_profiles("ed_mfcc_kernel<false, true, 2, 5>:short") if nf == 65536 else None
+    tr = hbm_traffic_from_profiles("ed_mfcc2_kernel<true, 2, 5>:short") if nf == 65536 else None
     if tr is not None:
         roofline["traffic"] = tr[0]
         roofline["traffic_source"] = tr[1]
@@ -316,7 +316,7 @@ def main():
                    mfcc_frames_per_s=round(inf_per_s * 31, 1), ms_per_step=round(kw_ms, 4),
                    config=dict(workload="kws_full_%d_utt_per_gpu_x31_frames_mfccB_int8cnn" % nu, global_batch=world * nu,
                                collective="all_gather int8 logits (RCCL)" if world > 1 else "none"),
-                   roofline=dict(bound="hbm", kernel="ed_mfcc_kernel<false, true, 2, 5> + ed_cnn_mfma_kernel", achieved=round(kach, 1),
+                   roofline=dict(bound="hbm", kernel="ed_mfcc2_kernel<true, 2, 5> + ed_cnn_mfma_kernel", achieved=round(kach, 1),
                                  peak=HBM_PEAK_GBS, unit="GB/s", frac=round(kach / HBM_PEAK_GBS, 4), traffic=None,
                                  bytes_per_unit=KWS_BYTES_PER_UTT, units_per_launch=nu, kernel_ms=round(kev_ms, 4)),
                    class_histogram=hist)
