@@ -28,6 +28,11 @@
  * Waves never share LDS data, so there is no workgroup barrier inside the frame loop. The constant tables
  * (mel taps, DCT, split twiddles) are staged once per workgroup in LDS; only the pass-1/2 twiddles live in
  * registers.
+ *
+ * Two kernels implement this pipeline. ed_mfcc_kernel (one frame per wavefront) is the reference implementation of
+ * the design and the one that dumps the intermediate stages; ed_mfcc2_kernel further down carries TWO frames per
+ * wavefront in packed fp32 and is what every batched call without stage dumps runs (ED_MFCC_ONE_FRAME=1 selects the
+ * former for A/B measurements).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -56,6 +56,21 @@ def test_mfcc_stages_golden(ctx, mfcc_golden, variant):
             assert np.abs(st["log_mel_spectrogram"] - lm).max() <= 1e-4
 
 
+def test_two_frame_kernel_agrees_with_one_frame_kernel(ctx, mfcc_golden):
+    """The batched path runs ed_mfcc2_kernel (two frames per wavefront, packed fp32), the stage-dump path the one-frame
+    ed_mfcc_kernel: same algorithm and operation order, different instruction selection (FMA contraction), so they
+    agree to a few ulp -- and a frame's result must not depend on whether it rides in the .x or the .y half."""
+    x = np.concatenate([mfcc_golden["in_noise"], mfcc_golden["in_edison"]])
+    for variant in ("A", "B"):
+        two = ctx.mfcc(x, variant=_variant(variant), n_coef=32)
+        one = ctx.mfcc_stages(x, variant=_variant(variant))["mfcc"]
+        assert np.abs(two - one).max() <= 2e-6 * np.abs(one).max()
+        shifted = ctx.mfcc(x[1024:], variant=_variant(variant), n_coef=32)      # every frame changes its half
+        assert np.array_equal(shifted, two[1:])
+        odd = ctx.mfcc(x[:5 * 1024], variant=_variant(variant), n_coef=32)      # odd batch: the last pair repeats A
+        assert np.array_equal(odd, two[:5])
+
+
 def test_mfcc_vs_oracle_seeded(ctx, oracle_mod):
     rng = np.random.default_rng(20)
     t = np.arange(1024) / 16000.0
