@@ -78,6 +78,9 @@ typedef struct {
 	int32_t mel_scale, n_mel_coef;
 	int32_t need_nyquist; /* some band reads spectrum bin 512 */
 	int32_t pad_;
+	/* bit c (c < 32768): arm_sqrt_q31(2 c^2) >> 16 is c - 1 instead of c (the kernel's magnitude shortcut,
+	 * tools/verify/sqrt_q31_floor.c) */
+	uint32_t sqbit[1024];
 } ed_q15_tables_t;
 
 int ed_build_q15_tables(double sample_rate, double lower_edge_hertz, double upper_edge_hertz, double mel_mtx_scale,

@@ -169,6 +169,29 @@ __device__ __forceinline__ int eq_sqrt_q31(int in_raw)
 	return in_raw > 0 ? (int)v >> (sh >> 1) : 0;
 }
 
+/* The firmware keeps mag = arm_sqrt_q31(x) >> 16 of x = re^2 + im^2. The routine approximates sqrt(x * 2^31), so
+ * mag is c = floor(sqrt(x / 2)) unless its few-LSB error crosses a multiple of 2^16. tools/verify/sqrt_q31_floor.c
+ * walks all 2^31 inputs: with d = x - 2 c^2 and t = c >> 11, t < d < 4c + 2 - t implies mag == c. The test also
+ * certifies c itself (0 <= d < 4c + 2), so the 1-ulp v_sqrt_f32 only has to be right almost always: whatever fails
+ * the test goes to eq_mag_fix. Returns true when c is proven. */
+__device__ __forceinline__ bool eq_mag_fast(u32 x, int &c)
+{
+	c = (int)__builtin_amdgcn_sqrtf((float)x * 0.5f);
+	const int d = (int)x + __mul24(c, __mul24(c, -2));
+	const u32 t = (u32)c >> 11;
+	return (u32)d + ~t < 4u * (u32)c + 1u - 2u * t; /* t + 1 <= d <= 4c + 1 - t in one unsigned compare */
+}
+
+/* The rest: x == 2 c^2 (mag is c or c - 1: one bit per c from tables_q15.c) and the rare near-boundary inputs, the
+ * wrapped sum 0x80000000 and a mis-rounded c, which run the routine itself. */
+__device__ __forceinline__ int eq_mag_fix(u32 x, int c, const u32 *sqbit)
+{
+	if (x == 2u * (u32)__mul24(c, c) && c < 32768) return c - (int)((sqbit[c >> 5] >> (c & 31)) & 1u);
+	return eq_sqrt_q31((int)x) >> 16;
+}
+
+#define EQ_BR4(kk) ((((kk) & 1) << 3) | (((kk) & 2) << 1) | (((kk) & 4) >> 1)) /* bitrev4(kk), kk < 8 */
+
 __device__ __forceinline__ int eq_re(u32 x) { return (int)(short)(x & 0xffffu); }
 __device__ __forceinline__ int eq_im(u32 x) { return (int)x >> 16; }
 __device__ __forceinline__ int eq_bitrev(int v, int bits) { return (int)(__builtin_bitreverse32((u32)v) >> (32 - bits)); }
@@ -294,6 +317,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	__shared__ int s_tap[NLO + NHI][64];
 	__shared__ int s_melb[EQ_WPB][EQ_NB * 32];
 	__shared__ u32 s_zb[EQ_WPB][EQ_NB * 16];
+	__shared__ u32 s_sqbit[1024];
 	const int lane = threadIdx.x & 63;
 	const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	u32 *buf = s_buf[w];
@@ -301,6 +325,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	u32 *zb = s_zb[w];
 
 	for (int i = threadIdx.x; i < (NLO + NHI) * 64; i += 64 * EQ_WPB) (&s_tap[0][0])[i] = (&T->mel_tap[0][0])[i];
+	for (int i = threadIdx.x; i < 1024; i += 64 * EQ_WPB) s_sqbit[i] = T->sqbit[i];
 	__syncthreads();
 
 	/* per-lane constants of the whole run */
@@ -389,28 +414,52 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 
 		/* ---- magnitudes: register m = X[64 bitrev4(m) + bitrev6(lane)]; bins 0..511 are the even registers */
 		int *spec = (int *)buf;
+		int mag[8];
+		if (EQ_ABLATE & 1)
+		{
+#pragma unroll
+			for (int kk = 0; kk < 8; kk++) mag[kk] = (int)((e[EQ_BR4(kk)] ^ (e[EQ_BR4(kk)] >> 16)) & 0x7fff);
+		}
+		else
+		{
+			/* re^2 + im^2 (32-bit wrap-around, like the firmware's q31 sum) is one dot2 of the value with itself */
+			u32 pw[8];
+			bool ok[8], all_ok = true;
+#pragma unroll
+			for (int kk = 0; kk < 8; kk++)
+			{
+				pw[kk] = (u32)eq_dot2<false>(e[EQ_BR4(kk)], e[EQ_BR4(kk)]);
+				ok[kk] = eq_mag_fast(pw[kk], mag[kk]);
+				all_ok &= ok[kk];
+			}
+			if (__builtin_amdgcn_ballot_w64(!all_ok) != 0)
+			{
+#pragma unroll
+				for (int kk = 0; kk < 8; kk++)
+					if (!ok[kk]) mag[kk] = eq_mag_fix(pw[kk], mag[kk], s_sqbit);
+			}
+		}
 #pragma unroll
 		for (int kk = 0; kk < 8; kk++)
 		{
-			const int m = ((kk & 1) << 3) | ((kk & 2) << 1) | ((kk & 4) >> 1); /* bitrev4(kk), kk < 8 */
-			const int re = eq_re(e[m]), im = eq_im(e[m]);
-			/* re^2 + im^2 (32-bit wrap-around, like the firmware's q31 sum) is one dot2 of the value with itself */
-			const int mag = (EQ_ABLATE & 1) ? (re ^ im) & 0x7fff : eq_sqrt_q31(eq_dot2<false>(e[m], e[m])) >> 16;
-			spec[64 * kk + rev6] = mag;
+			spec[64 * kk + rev6] = mag[kk];
 			if (STAGES)
 			{
 				const int64_t k = 64 * kk + rev6;
-				if (a.fft) { a.fft[((int64_t)f * 513 + k) * 2] = (int16_t)re; a.fft[((int64_t)f * 513 + k) * 2 + 1] = (int16_t)im; }
-				if (a.spec) a.spec[(int64_t)f * 513 + k] = (int16_t)mag;
+				const u32 v = e[EQ_BR4(kk)];
+				if (a.fft) { a.fft[((int64_t)f * 513 + k) * 2] = (int16_t)eq_re(v); a.fft[((int64_t)f * 513 + k) * 2 + 1] = (int16_t)eq_im(v); }
+				if (a.spec) a.spec[(int64_t)f * 513 + k] = (int16_t)mag[kk];
 			}
 		}
 		if (need_nyquist && lane == 0)
 		{
 			const int re = eq_re(e[1]), im = eq_im(e[1]); /* X[512] */
-			const int mag = eq_sqrt_q31(eq_dot2<false>(e[1], e[1])) >> 16;
-			spec[512] = mag;
+			const u32 pw512 = (u32)eq_dot2<false>(e[1], e[1]);
+			int mag512;
+			if (!eq_mag_fast(pw512, mag512)) mag512 = eq_mag_fix(pw512, mag512, s_sqbit);
+			spec[512] = mag512;
 			if (STAGES && a.fft) { a.fft[((int64_t)f * 513 + 512) * 2] = (int16_t)re; a.fft[((int64_t)f * 513 + 512) * 2 + 1] = (int16_t)im; }
-			if (STAGES && a.spec) a.spec[(int64_t)f * 513 + 512] = (int16_t)mag;
+			if (STAGES && a.spec) a.spec[(int64_t)f * 513 + 512] = (int16_t)mag512;
 		}
 		eq_wave_sync();
 

@@ -43,6 +43,26 @@ static int q15_round(double x)
 
 static uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
 
+static uint32_t mul_q31(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 31); }
+
+/* arm_sqrt_q31 (CMSIS-DSP FastMathFunctions/arm_sqrt_q31.c:50-139) for in > 0, table construction only: the
+ * exponent-trick seed of 1/sqrt, three Newton steps, one multiply back, the normalisation shift undone. */
+static uint32_t sqrt_q31_host(uint32_t in)
+{
+	const int sh = (__builtin_clz(in) - 1) & ~1;
+	const uint32_t number = in << sh;
+	union { int32_t i; float f; } cv;
+	cv.f = (float)(int32_t)number * 4.6566128731e-010f;
+	cv.i = 0x5f3759df - (cv.i >> 1);
+	uint32_t v = (uint32_t)(int32_t)(cv.f * 1073741824.0f);
+	for (int it = 0; it < 3; it++)
+	{
+		const uint32_t hv = mul_q31(mul_q31(v, v), number >> 1);
+		v = mul_q31(v, 0x30000000u - hv) << 2;
+	}
+	return (mul_q31(number, v) << 1) >> (sh >> 1);
+}
+
 int ed_build_q15_tables(double sample_rate, double lower_edge_hertz, double upper_edge_hertz, double mel_mtx_scale,
                         ed_q15_tables_t *out, char *err, size_t err_cap)
 {
@@ -66,6 +86,18 @@ int ed_build_q15_tables(double sample_rate, double lower_edge_hertz, double uppe
 		const int bre = q15_round(0.5 * (1.0 + sin(a))), bim = q15_round(0.5 * cos(a));
 		out->rfa[i] = pack16(are, -aim); /* outR = p.re*A.re - p.im*A.im + q.re*B.re + q.im*B.im */
 		out->rfb[i] = pack16(bre, bim);
+	}
+	/* magnitudes: the kernel takes floor(sqrt(x/2)) where that provably equals arm_sqrt_q31(x) >> 16; for x = 2 c^2
+	 * the routine lands on c or one below, recorded here */
+	for (uint32_t c = 1; c < 32768; c++)
+	{
+		const uint32_t mag = sqrt_q31_host(2u * c * c) >> 16;
+		if (mag == c - 1) out->sqbit[c >> 5] |= 1u << (c & 31);
+		else if (mag != c)
+		{
+			if (err) snprintf(err, err_cap, "variant C: arm_sqrt_q31(2*%u^2) >> 16 = %u, expected %u or %u", c, mag, c - 1, c);
+			return EDISON_E_RUNTIME;
+		}
 	}
 
 	const int nbins = EDISON_FRAME_LEN / 2 + 1, NMEL = EDISON_NUM_MEL;

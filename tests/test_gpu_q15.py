@@ -93,6 +93,32 @@ def test_q15_fuzz_16384_frames(ctx, oracle_mod):
     assert bad.size == 0, "frames differing: %s" % bad[:8].tolist()
 
 
+def test_q15_magnitude_classes(ctx, oracle_mod):
+    """The kernel takes floor(sqrt(x/2)) where that provably equals arm_sqrt_q31(x) >> 16
+    (tools/verify/sqrt_q31_floor.c), a bitmap for x = 2c^2 and the routine itself near the 2^16 boundaries. Quiet
+    frames put most bins in the bitmap class, bin-centred full-scale tones reach the large magnitudes where the
+    boundary class lives, all-zero and all -32768 frames give x = 0 and the wrapped 0x80000000."""
+    rng = np.random.default_rng(35)
+    t = np.arange(1024)
+    frames = [np.zeros(1024), np.full(1024, -32768.0), np.full(1024, 32767.0)]
+    for i in range(700):
+        frames.append(rng.normal(0.0, 10.0 ** rng.uniform(0.0, 2.0), 1024))               # 1..100 LSB rms
+    for i in range(700):
+        k = rng.integers(1, 512)
+        frames.append(rng.uniform(0.3, 1.0) * 32767.0 * np.cos(2 * np.pi * k * t / 1024 + rng.uniform(0, 6.28))
+                      + rng.normal(0.0, rng.uniform(0.0, 30.0), 1024))
+    for i in range(300):
+        frames.append(np.where((t // rng.integers(1, 64)) % 2 == 0, 1.0, -1.0) * rng.uniform(0.5, 1.0) * 32767.0)
+    x = np.clip(np.rint(np.concatenate(frames)), -32768, 32767).astype(np.int16)
+    ref, rst = oracle_mod.mfcc_q15(x, stages=True, n_threads=8)
+    st = ctx.mfcc_q15_stages(x)
+    assert np.array_equal(st["fft"], rst["fft"][:, :513])
+    spec = rst["spectrogram"]
+    assert np.array_equal(st["spectrogram"], spec)
+    assert spec.max() >= 8192 and (spec[3:703] < 64).mean() > 0.5                         # both ends were exercised
+    assert np.array_equal(ctx.mfcc_q15(x), ref)
+
+
 def test_q15_through_the_float_interface(ctx, oracle_mod, mfcc_golden):
     """EDISON_MFCC_C through edison_mfcc_batch: the int16 values as floats, feat = the firmware's clip."""
     from edison_amd import _lib
