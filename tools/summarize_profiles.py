@@ -16,8 +16,21 @@ def one(d, pat):
 
 def main():
     rnd, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
-    sq_dirs = sys.argv[5:]
+    sq_dirs = [a for a in sys.argv[5:] if not a.startswith("steady=")]
+    steady = [a[7:] for a in sys.argv[5:] if a.startswith("steady=")]
     out = {"round": rnd, "kernels": {}, "hbm": {}, "sq_per_launch": {}}
+    # steady=DIR: kernel trace of the default bench command (thousands of launches): mean duration of every 100
+    # consecutive dispatches in launch order -- shows the power-management transient and the settled value
+    for d in steady:
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(one(d, "*kernel_trace.csv"))):
+            if "ed_mfcc" in r["Kernel_Name"] or "ed_cnn" in r["Kernel_Name"]:
+                per[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        out["steady_blocks_of_100_ns"] = {}
+        for k, v in per.items():
+            v.sort()
+            dur = [x[1] for x in v]
+            out["steady_blocks_of_100_ns"][k] = [round(sum(dur[i:i + 100]) / len(dur[i:i + 100]), 1) for i in range(0, len(dur), 100)]
     for r in csv.DictReader(open(one(stats_dir, "*kernel_stats.csv"))):
         if "ed_mfcc" in r["Name"] or "ed_cnn" in r["Name"]:
             out["kernels"][r["Name"].split("(")[0].replace("void ", "")] = dict(
