@@ -27,6 +27,17 @@ class StreamOpts(ctypes.Structure):
                 ("filter_alpha", c_double), ("true_threshold", c_double)]
 
 
+class NetInfo(ctypes.Structure):
+    """edison_net_info"""
+    _fields_ = [(k, ctypes.c_int32) for k in ("in_h", "in_w", "in_c", "n_out", "n_layers", "acts_bytes", "has_softmax",
+                                              "accelerated")]
+
+
+class NetLayerInfo(ctypes.Structure):
+    """edison_net_layer_info_t"""
+    _fields_ = [(k, ctypes.c_int32) for k in ("type", "out_h", "out_w", "out_c", "acts_offset", "relu")]
+
+
 class Fsm(ctypes.Structure):
     """edison_fsm"""
     _fields_ = [("state", c_int), ("hot_timeout_ms", ctypes.c_uint32), ("wake_idx", c_int), ("loc_idx", c_int),
@@ -46,6 +57,12 @@ SIGNATURES = {
     "edison_gen_mel_weight_matrix": (c_int, [c_int, c_int, c_double, c_double, c_double, c_void_p]),
     "edison_model_load": (c_int, [c_void_p, c_char_p]),
     "edison_model_load_mem": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "edison_net_get_info": (c_int, [c_void_p, ctypes.POINTER(NetInfo)]),
+    "edison_net_layer_info": (c_int, [c_void_p, c_int, ctypes.POINTER(NetLayerInfo)]),
+    "edison_net_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "edison_net_layers_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "edison_net_batch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "edison_net_layers": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "edison_dev_alloc": (c_int, [c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
     "edison_dev_free": (c_int, [c_void_p, c_void_p]),
     "edison_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),

@@ -54,6 +54,13 @@ class Context:
     def load_model(self, path):
         self._check(self._L.edison_model_load(self._h, str(path).encode()))
 
+    def load_weights_h(self, path):
+        """Load an NNoM-generated model header directly (the reference's weights.h, or one of a retrained / other graph)."""
+        from . import nnom_import
+        with open(path, "r") as f:
+            shape, layers = nnom_import.parse_weights_h(f.read())
+        self.load_model_bytes(nnom_import.build_blob(shape, layers))
+
     def load_model_bytes(self, blob):
         buf = ctypes.create_string_buffer(bytes(blob), len(blob))
         self._check(self._L.edison_model_load_mem(self._h, ctypes.cast(buf, ctypes.c_void_p), len(blob)))
@@ -136,6 +143,39 @@ class Context:
             out[k] = acts[:, off:off + sz]
             off += sz
         return out
+
+    # ---- any NNoM graph (edison_net_*): shapes come from the loaded model
+    def net_info(self):
+        """dict of edison_net_info plus `layers`: one dict per compute layer (type, out_h, out_w, out_c, acts_offset, relu)."""
+        info = _lib.NetInfo()
+        self._check(self._L.edison_net_get_info(self._h, ctypes.byref(info)))
+        d = {k: getattr(info, k) for k, _ in _lib.NetInfo._fields_}
+        d["layers"] = []
+        for i in range(info.n_layers):
+            li = _lib.NetLayerInfo()
+            self._check(self._L.edison_net_layer_info(self._h, i, ctypes.byref(li)))
+            d["layers"].append({k: getattr(li, k) for k, _ in _lib.NetLayerInfo._fields_})
+        return d
+
+    def net(self, x):
+        """model_run + first-maximum argmax for n inputs [n][in_h*in_w*in_c] int8 (nnom.c:975-1040, nnom_utils.c:275-284)."""
+        info = self.net_info()
+        f = np.ascontiguousarray(x, dtype=np.int8).reshape(-1, info["in_h"] * info["in_w"] * info["in_c"])
+        n = f.shape[0]
+        logits = np.zeros((n, info["n_out"]), np.int8)
+        soft = np.zeros((n, info["n_out"]), np.int8) if info["has_softmax"] else None
+        am = np.zeros(n, np.int32)
+        self._check(self._L.edison_net_batch(self._h, _np_ptr(f), n, _np_ptr(logits), _np_ptr(soft) if soft is not None else None,
+                                             _np_ptr(am)))
+        return dict(logits=logits, softmax=soft, argmax=am)
+
+    def net_layers(self, x):
+        """Every compute layer's output, back to back per input: what a model_set_callback hook sees (nnom.c:1043)."""
+        info = self.net_info()
+        f = np.ascontiguousarray(x, dtype=np.int8).reshape(-1, info["in_h"] * info["in_w"] * info["in_c"])
+        acts = np.zeros((f.shape[0], info["acts_bytes"]), np.int8)
+        self._check(self._L.edison_net_layers(self._h, _np_ptr(f), f.shape[0], _np_ptr(acts)))
+        return acts
 
     def _frames(self, x, n_frames, frame_step):
         if n_frames is None:

@@ -19,6 +19,10 @@ extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const in
                                   int64_t feat_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu,
                                   hipStream_t stream);
 
+extern "C" int ed_launch_net(const ed_net_plan_t *dev_plan, const int8_t *dev_w, const int32_t *dev_seeds, int lds_bytes,
+                             const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax,
+                             int8_t *acts, int n_cu, hipStream_t stream);
+
 extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int mel_nlo, int mel_nhi,
                                   int stages, int n_cu, hipStream_t stream);
 
@@ -37,7 +41,14 @@ struct edison_ctx
 	char q15_err[160];      /* why variant C is unavailable, when it is */
 	ed_cnn_model_t *d_model;           /* layer-by-layer diagnostic kernel (edison_cnn_layers) */
 	ed_cnn_mfma_model_t *d_model_mfma; /* MFMA fast path                                       */
-	int have_model;
+	int have_model;                    /* a model is loaded (any graph the planner accepts)    */
+	int fast_model;                    /* ... and it is the kws_conv graph the two kernels above are specialised for */
+	int model_epoch;                   /* counts loads: captured graphs (edison_stream) hold device addresses of one load */
+	/* the general layer-by-layer path (cnn_net_kernels.hip): plan (host copy + device copy), weights, seeds */
+	ed_net_plan_t net;
+	ed_net_plan_t *d_net_plan;
+	int8_t *d_net_w;
+	int32_t *d_net_seeds;
 	/* growable device scratch for the host-pointer entry points and the fused KWS path */
 	void *scratch;
 	size_t scratch_bytes;
@@ -60,6 +71,11 @@ static inline int ed_set_err(edison_ctx *ctx, int code, const char *msg)
 	if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
 	return code;
 }
+
+/* The loaded model on 31x13x1 -> 10 features (the geometry of every kws / stream entry point): matrix-core kernel for
+ * the kws_conv graph, the general kernel for any other graph of that shape. feat_stride = bytes between utterances. */
+int ed_ctx_kws_cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int64_t feat_stride, int8_t *logits,
+                          int8_t *softmax, int32_t *argmax);
 
 /* Fill the launch arguments of the MFCC kernel for `variant` and enqueue it on the context's stream. */
 int ed_ctx_mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,

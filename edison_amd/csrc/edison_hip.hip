@@ -121,6 +121,9 @@ extern "C" void edison_shutdown(edison_ctx *ctx)
 	if (ctx->d_q15) (void)hipFree(ctx->d_q15);
 	if (ctx->d_model) (void)hipFree(ctx->d_model);
 	if (ctx->d_model_mfma) (void)hipFree(ctx->d_model_mfma);
+	if (ctx->d_net_plan) (void)hipFree(ctx->d_net_plan);
+	if (ctx->d_net_w) (void)hipFree(ctx->d_net_w);
+	if (ctx->d_net_seeds) (void)hipFree(ctx->d_net_seeds);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	free(ctx);
@@ -179,21 +182,45 @@ extern "C" int edison_gen_mel_weight_matrix(int num_mel_bins, int num_spectrogra
 extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t blob_bytes)
 {
 	if (!ctx || !blob) return EDISON_E_ARGUMENT;
+	/* every graph gets the general plan; the kws_conv graph additionally gets the two specialised weight images */
+	ed_net_plan_t *plan = (ed_net_plan_t *)malloc(sizeof(ed_net_plan_t));
 	ed_cnn_model_t *h = (ed_cnn_model_t *)malloc(sizeof(ed_cnn_model_t));
 	ed_cnn_mfma_model_t *hm = (ed_cnn_mfma_model_t *)malloc(sizeof(ed_cnn_mfma_model_t));
-	if (!h || !hm) { free(h); free(hm); return set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed"); }
-	int r = ed_parse_model(blob, blob_bytes, h, hm, ctx->err, sizeof(ctx->err));
-	if (r != EDISON_OK) { free(h); free(hm); return r; }
-	hipError_t e = hipSetDevice(ctx->device);
-	if (e == hipSuccess && !ctx->d_model) e = hipMalloc((void **)&ctx->d_model, sizeof(ed_cnn_model_t));
-	if (e == hipSuccess && !ctx->d_model_mfma) e = hipMalloc((void **)&ctx->d_model_mfma, sizeof(ed_cnn_mfma_model_t));
-	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-	if (e == hipSuccess) e = hipMemcpy(ctx->d_model, h, sizeof(ed_cnn_model_t), hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipMemcpy(ctx->d_model_mfma, hm, sizeof(ed_cnn_mfma_model_t), hipMemcpyHostToDevice);
-	free(h);
-	free(hm);
+	int8_t *w = NULL;
+	int32_t *seeds = NULL;
+	int r = (plan && h && hm) ? ed_plan_net(blob, blob_bytes, plan, &w, &seeds, ctx->err, sizeof(ctx->err))
+	                          : set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed");
+	hipError_t e = hipSuccess;
+	if (r == EDISON_OK)
+	{
+		char why[256];
+		const int fast = ed_parse_model(blob, blob_bytes, h, hm, why, sizeof(why)) == EDISON_OK;
+		e = hipSetDevice(ctx->device);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		if (e == hipSuccess && fast && !ctx->d_model) e = hipMalloc((void **)&ctx->d_model, sizeof(ed_cnn_model_t));
+		if (e == hipSuccess && fast && !ctx->d_model_mfma) e = hipMalloc((void **)&ctx->d_model_mfma, sizeof(ed_cnn_mfma_model_t));
+		if (e == hipSuccess && fast) e = hipMemcpy(ctx->d_model, h, sizeof(ed_cnn_model_t), hipMemcpyHostToDevice);
+		if (e == hipSuccess && fast) e = hipMemcpy(ctx->d_model_mfma, hm, sizeof(ed_cnn_mfma_model_t), hipMemcpyHostToDevice);
+		ctx->have_model = 0;
+		if (ctx->d_net_w) { (void)hipFree(ctx->d_net_w); ctx->d_net_w = NULL; }
+		if (ctx->d_net_seeds) { (void)hipFree(ctx->d_net_seeds); ctx->d_net_seeds = NULL; }
+		if (e == hipSuccess && !ctx->d_net_plan) e = hipMalloc((void **)&ctx->d_net_plan, sizeof(ed_net_plan_t));
+		if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_net_w, (size_t)plan->weights_bytes + 16);
+		if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_net_seeds, ((size_t)plan->n_seeds + 4) * sizeof(int32_t));
+		if (e == hipSuccess) e = hipMemcpy(ctx->d_net_plan, plan, sizeof(ed_net_plan_t), hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMemcpy(ctx->d_net_w, w, (size_t)plan->weights_bytes, hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMemcpy(ctx->d_net_seeds, seeds, (size_t)plan->n_seeds * sizeof(int32_t), hipMemcpyHostToDevice);
+		if (e == hipSuccess)
+		{
+			ctx->net = *plan;
+			ctx->fast_model = fast;
+			ctx->have_model = 1;
+			ctx->model_epoch++;
+		}
+	}
+	free(plan); free(h); free(hm); free(w); free(seeds);
+	if (r != EDISON_OK) return r;
 	ED_HIP(ctx, e);
-	ctx->have_model = 1;
 	return EDISON_OK;
 }
 
@@ -327,15 +354,40 @@ extern "C" int edison_mfcc_stages_dev(edison_ctx *ctx, const int16_t *audio, int
 	                   mfcc32, NULL, 1.0f, 1, fft, spec, mel, logmel);
 }
 
+static int kws_shaped(const ed_net_plan_t *p)
+{
+	return p->in_h == EDISON_UTT_FRAMES && p->in_w == EDISON_NUM_MFCC && p->in_c == 1 && p->out_n == EDISON_NET_OUT && p->has_softmax;
+}
+
+int ed_ctx_kws_cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int64_t feat_stride, int8_t *logits,
+                          int8_t *softmax, int32_t *argmax)
+{
+	if (!ctx->have_model) return set_err(ctx, EDISON_E_NO_MODEL, "no CNN model loaded (edison_model_load)");
+	if (!ctx->fast_model && !kws_shaped(&ctx->net))
+		return set_err(ctx, EDISON_E_SIZE, "the loaded model is not a 31x13x1 -> 10 softmax classifier; use edison_net_batch");
+	int e = ctx->fast_model
+	            ? ed_launch_cnn_mfma(ctx->d_model_mfma, feat, n_utt, feat_stride, logits, softmax, argmax, ctx->n_cu, ctx->stream)
+	            : ed_launch_net(ctx->d_net_plan, ctx->d_net_w, ctx->d_net_seeds, ctx->net.lds_bytes, feat, n_utt, feat_stride,
+	                            logits, softmax, argmax, NULL, ctx->n_cu, ctx->stream);
+	if (e != 0)
+	{
+		snprintf(ctx->err, sizeof(ctx->err), "CNN kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+		return EDISON_E_RUNTIME;
+	}
+	return EDISON_OK;
+}
+
 static int cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *logits, int8_t *softmax,
                       int32_t *argmax, int8_t *acts)
 {
 	if (!ctx || n_utt < 0 || (!feat && n_utt > 0)) return EDISON_E_ARGUMENT;
 	if (!ctx->have_model) return set_err(ctx, EDISON_E_NO_MODEL, "no CNN model loaded (edison_model_load)");
 	if (n_utt == 0) return EDISON_OK;
-	/* per-layer activations come from the layer-by-layer kernel; everything else runs on the matrix cores */
-	int e = acts ? ed_launch_cnn(ctx->d_model, feat, n_utt, logits, softmax, argmax, acts, ctx->n_cu, ctx->stream)
-	             : ed_launch_cnn_mfma(ctx->d_model_mfma, feat, n_utt, EDISON_NET_IN, logits, softmax, argmax, ctx->n_cu, ctx->stream);
+	if (!acts) return ed_ctx_kws_cnn_launch(ctx, feat, n_utt, EDISON_NET_IN, logits, softmax, argmax);
+	/* per-layer activations in the kws_conv layout come from that graph's layer-by-layer kernel */
+	if (!ctx->fast_model)
+		return set_err(ctx, EDISON_E_SIZE, "edison_cnn_layers dumps the kws_conv layout; use edison_net_layers for this model");
+	int e = ed_launch_cnn(ctx->d_model, feat, n_utt, logits, softmax, argmax, acts, ctx->n_cu, ctx->stream);
 	if (e != 0)
 	{
 		snprintf(ctx->err, sizeof(ctx->err), "CNN kernel launch failed: %s", hipGetErrorString((hipError_t)e));

@@ -180,6 +180,42 @@ typedef struct {
 int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, ed_cnn_mfma_model_t *out_mfma, char *err,
                    size_t err_cap);
 
+/* ------------------------------------------------------------------ any sequential NNoM int8 graph (cnn_net_kernels.hip)
+ * The plan of the layer-by-layer kernel: what model_compile() (nnom.c:758-900) works out for the chain
+ * Input -> {Conv2D [+ReLU] | MaxPool | Dense [+ReLU] | Flatten | Softmax}* -> Output. One workgroup owns an
+ * utterance; activations ping-pong between two LDS buffers; weights stay OHWI int8 in HBM/L2. */
+#define ED_NET_MAX_LAYERS 32
+#define ED_NET_MAX_LDS (64 * 1024 - 256) /* both activation buffers */
+enum { ED_NET_CONV = 1, ED_NET_POOL = 2, ED_NET_DENSE = 3, ED_NET_SOFTMAX = 4 };
+
+typedef struct {
+	int32_t type, relu;
+	int32_t in_h, in_w, in_c, out_h, out_w, out_c;
+	int32_t kh, kw, sh, sw, pad_h, pad_w;
+	int32_t rs;       /* output right shift (conv, dense)                                                     */
+	int32_t w_off;    /* byte offset of the layer's weights in the device weight buffer (16-byte aligned)      */
+	int32_t seed_off; /* index of its first accumulator seed (bias << bias_lshift) + NN_ROUND(out_rshift)      */
+	int32_t in_buf, out_buf; /* LDS byte offsets                                                             */
+	int32_t in_n, out_n;     /* elements                                                                     */
+	int32_t acts_off; /* offset of the layer's output inside one utterance's activation dump                  */
+	int32_t pad_[2];
+} ed_net_layer_t;
+
+typedef struct {
+	int32_t n_layers;
+	int32_t in_h, in_w, in_c, in_n;
+	int32_t out_n;        /* width of logits / softmax                                                        */
+	int32_t logits_layer; /* the layer whose output is reported as logits: the one before a final Softmax      */
+	int32_t has_softmax;
+	int32_t lds_bytes, acts_bytes, weights_bytes, n_seeds;
+	ed_net_layer_t L[ED_NET_MAX_LAYERS];
+} ed_net_plan_t;
+
+/* Builds the plan, the device weight image and the seeds from an .ednn blob; *weights / *seeds are malloc'd.
+ * EDISON_E_SIZE for a malformed graph, EDISON_E_NO_IMPL for one the reference accepts but this path does not run. */
+int ed_plan_net(const void *blob, size_t blob_bytes, ed_net_plan_t *plan, int8_t **weights, int32_t **seeds, char *err,
+                size_t err_cap);
+
 /* ------------------------------------------------------------------ kernel launchers (HIP side)           */
 typedef struct {
 	const int16_t *audio;

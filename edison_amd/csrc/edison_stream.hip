@@ -51,6 +51,7 @@ struct edison_stream
 	hipGraphExec_t exec_h;
 	int last_push_staged;
 	int64_t frames_seen;
+	int model_epoch;      /* the graphs hold the device addresses of the model that was loaded when they were captured */
 };
 
 #define ED_STREAM_STAGED_MAX_BYTES (1u << 20) /* chunks above 1 MB of samples go through plain async copies */
@@ -131,9 +132,9 @@ static int enqueue_push_on_ctx_stream(edison_stream *s)
 	int r = ed_ctx_mfcc_launch(ctx, s->d_audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
 	                           s->d_feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
 	if (r != EDISON_OK) return r;
-	int e = ed_launch_cnn_mfma(ctx->d_model_mfma, s->d_feat, s->chunk, EDISON_NUM_MFCC, s->d_logits, s->d_soft, s->d_argmax,
-	                           ctx->n_cu, ctx->stream);
-	if (e != 0) return ed_set_err(ctx, EDISON_E_RUNTIME, "stream: CNN launch failed");
+	/* window i of the push = rows i..i+30 of the feature buffer: a 13-byte utterance stride, nothing is copied */
+	r = ed_ctx_kws_cnn_launch(ctx, s->d_feat, s->chunk, EDISON_NUM_MFCC, s->d_logits, s->d_soft, s->d_argmax);
+	if (r != EDISON_OK) return r;
 	if (s->filter)
 	{
 		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, ctx->stream, s->d_soft, s->chunk, s->alpha,
@@ -195,6 +196,9 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 	*out = NULL;
 	const int hop = o->hop, chunk_frames = o->chunk_frames;
 	if (!ctx->have_model) return ed_set_err(ctx, EDISON_E_NO_MODEL, "no CNN model loaded (edison_model_load)");
+	if (!ctx->fast_model && !(ctx->net.in_h == EDISON_UTT_FRAMES && ctx->net.in_w == EDISON_NUM_MFCC && ctx->net.in_c == 1 &&
+	                          ctx->net.out_n == EDISON_NET_OUT && ctx->net.has_softmax))
+		return ed_set_err(ctx, EDISON_E_SIZE, "stream: the loaded model is not a 31x13x1 -> 10 softmax classifier");
 	if (hop < 2 || hop > EDISON_FRAME_LEN || (hop & 1) || chunk_frames < 1 || chunk_frames > (1 << 22))
 		return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: hop must be even and 2..1024, chunk 1..4M frames");
 	if (o->mfcc_variant != EDISON_MFCC_B && o->mfcc_variant != EDISON_MFCC_C)
@@ -205,6 +209,7 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 	if (!s) return ed_set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed");
 	s->ctx = ctx; s->hop = hop; s->chunk = chunk_frames; s->tail = EDISON_FRAME_LEN - hop;
 	s->variant = o->mfcc_variant;
+	s->model_epoch = ctx->model_epoch;
 	s->filter = o->filter ? 1 : 0;
 	s->alpha = o->filter_alpha;
 	s->one_minus_alpha = 1.0 - o->filter_alpha; /* the firmware's (1.0-NET_OUT_MOVING_AVG_ALPHA), folded in double */
@@ -306,6 +311,7 @@ extern "C" int edison_stream_push_dev(edison_stream *s, const int16_t *samples, 
 {
 	if (!s || !samples) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
+	if (s->model_epoch != ctx->model_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: the model was reloaded after this stream was created; create a new stream");
 	const size_t nnew = (size_t)s->chunk * s->hop;
 	/* the caller produced `samples` on the context's stream: the private stream waits for that point ... */
 	ED_HIP(ctx, hipEventRecord(s->ev_in, ctx->stream));
@@ -328,6 +334,7 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 {
 	if (!s || !samples) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
+	if (s->model_epoch != ctx->model_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: the model was reloaded after this stream was created; create a new stream");
 	const size_t nnew = (size_t)s->chunk * s->hop;
 	if (s->exec_h)
 	{

@@ -89,9 +89,44 @@ int edison_mfcc_configure(edison_ctx *ctx, double sample_rate, double lower_edge
 int edison_gen_mel_weight_matrix(int num_mel_bins, int num_spectrogram_bins, double sample_rate,
                                  double lower_edge_hertz, double upper_edge_hertz, double *W);
 
-/* Load the int8 CNN (an .ednn blob written by tools/import_weights_h.py from an NNoM weights.h).          */
+/* Load the int8 CNN (an .ednn blob written by tools/import_weights_h.py from an NNoM weights.h): the GPU's
+ * nnom_model_create() + model_compile() (weights.h:138-161, nnom.c:758-900). Accepted: any chain
+ * Input -> {Conv2D valid|same [+ReLU] | MaxPool valid|same | Dense [+ReLU] | Flatten | Softmax (last)}* -> Output whose
+ * activations fit 2 x 32 KB. The shipped kws_conv graph (and any retrained model of that shape) runs on the matrix
+ * cores; every other graph runs on the general layer-by-layer kernel. EDISON_E_SIZE: malformed graph or one the
+ * reference itself would reject; EDISON_E_NO_IMPL: a layer/shape the reference runs but this path does not.  */
 int edison_model_load(edison_ctx *ctx, const char *ednn_path);
 int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t blob_bytes);
+
+/* ---- any NNoM graph: shapes come from the loaded model ---------------------------------------------------
+ * edison_net_batch = model_run() (nnom.c:975-1040) + nnom_predict()'s first-maximum argmax (nnom_utils.c:258-305)
+ * for n inputs; edison_net_layers = the outputs of every layer, as a layer callback installed with
+ * model_set_callback() (nnom.c:1043) would see them.
+ *   in      [n][in_h*in_w*in_c] int8, HWC                  logits  [n][n_out] int8: output of the layer before a final
+ *   softmax [n][n_out] int8 (NULL if the graph has none)            Softmax, or of the last layer if there is none
+ *   argmax  [n] int32 first maximum of the LAST layer's output      acts    [n][acts_bytes]: layer outputs back to back
+ * The fixed-shape entry points below (edison_cnn_*, edison_kws_*, edison_stream_*) accept any loaded model that maps
+ * 31x13x1 features to 10 softmax classes. */
+typedef struct edison_net_info {
+	int32_t in_h, in_w, in_c; /* Input(shape(h, w, c))                                                          */
+	int32_t n_out;            /* elements of the last layer's output                                            */
+	int32_t n_layers;         /* compute layers (Input/Output/Flatten are not counted)                          */
+	int32_t acts_bytes;       /* bytes per input of edison_net_layers                                           */
+	int32_t has_softmax;
+	int32_t accelerated;      /* 1: the kws_conv graph, served by the matrix-core kernel                        */
+} edison_net_info;
+typedef struct edison_net_layer_info_t {
+	int32_t type;             /* 1 Conv2D, 2 MaxPool, 3 Dense, 4 Softmax                                        */
+	int32_t out_h, out_w, out_c;
+	int32_t acts_offset;      /* where this layer's output starts inside one input's acts record                */
+	int32_t relu;
+} edison_net_layer_info_t;
+int edison_net_get_info(edison_ctx *ctx, edison_net_info *out);
+int edison_net_layer_info(edison_ctx *ctx, int layer, edison_net_layer_info_t *out);
+int edison_net_batch_dev(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *logits, int8_t *softmax, int32_t *argmax);
+int edison_net_layers_dev(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *acts);
+int edison_net_batch(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *logits, int8_t *softmax, int32_t *argmax);
+int edison_net_layers(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *acts);
 
 /* ---- device memory helpers (so a C caller needs nothing but this library) ---------------------------- */
 int edison_dev_alloc(edison_ctx *ctx, size_t bytes, void **dptr);

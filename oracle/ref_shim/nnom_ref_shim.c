@@ -150,3 +150,7 @@ int nnom_ref_run_batch(const int8_t *in, int64_t n, int8_t *logits, int8_t *soft
 }
 
 size_t nnom_ref_mem_stat(void) { return nnom_mem_stat(); }
+
+/* sizes of the model header this build was compiled around (403 / 10 for the shipped one; `make alt` builds others) */
+int nnom_ref_in_bytes(void) { return (int)sizeof(nnom_input_data); }
+int nnom_ref_out_bytes(void) { return (int)sizeof(nnom_output_data); }

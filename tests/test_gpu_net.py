@@ -1,0 +1,181 @@
+"""GPU parity tests of the GENERAL network path (edison_net_*, csrc/cnn_net_kernels.hip + model_net.c): any sequential
+NNoM int8 graph, not only the shipped kws_conv one. Integer arithmetic => every comparison is bit for bit.
+
+The expected values in tests/golden/net_golden.npz come from the REFERENCE's own NNoM 0.3.0 + CMSIS-NN compiled around
+four other generated model headers (tests/golden/gen_fixtures_net.py); larger seeded batches are compared with the numpy
+restatement oracle/net_ref.py, which that script checked against the same reference build.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = ["same_stride", "odd_no_softmax", "square", "kws_small"]
+
+
+@pytest.fixture(scope="module")
+def net_golden():
+    return np.load(os.path.join(GOLDEN, "net_golden.npz"))
+
+
+def _header(name):
+    return os.path.join(GOLDEN, "alt_models", name + ".h")
+
+
+def _blob(name):
+    from edison_amd import nnom_import
+    with open(_header(name)) as f:
+        shape, layers = nnom_import.parse_weights_h(f.read())
+    return nnom_import.build_blob(shape, layers)
+
+
+def _context(built_lib, name):
+    from edison_amd.context import Context
+    c = Context(0, model_path=None)
+    c.load_weights_h(_header(name))
+    return c
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_net_matches_reference_nnom(built_lib, net_golden, name):
+    c = _context(built_lib, name)
+    info = c.net_info()
+    x, ref = net_golden["in_" + name], net_golden["acts_" + name]
+    assert info["acts_bytes"] == ref.shape[1] and not info["accelerated"]
+    assert np.array_equal(c.net_layers(x), ref)
+    out = c.net(x)
+    last = info["layers"][-1]
+    n_out = info["n_out"]
+    final = ref[:, last["acts_offset"]:last["acts_offset"] + n_out]
+    if info["has_softmax"]:
+        pre = info["layers"][-2]
+        assert np.array_equal(out["softmax"], final)
+        assert np.array_equal(out["logits"], ref[:, pre["acts_offset"]:pre["acts_offset"] + n_out])
+    else:
+        assert out["softmax"] is None and np.array_equal(out["logits"], final)
+    assert np.array_equal(out["argmax"], np.argmax(final, axis=1))            # first maximum (nnom_utils.c:275-284)
+    c.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_net_vs_numpy_restatement_seeded(built_lib, name):
+    """3000 inputs per graph: full-range noise, quiet inputs, constant extremes; more than one pass of the persistent grid."""
+    from oracle import net_ref
+    c = _context(built_lib, name)
+    info = c.net_info()
+    n_in = info["in_h"] * info["in_w"] * info["in_c"]
+    rng = np.random.default_rng(41)
+    x = rng.integers(-128, 128, (3000, n_in)).astype(np.int8)
+    x[:300] = rng.integers(-12, 13, (300, n_in))
+    x[300], x[301], x[302] = 0, 127, -128
+    ref = net_ref.run(_blob(name), x)
+    assert np.array_equal(c.net_layers(x), np.concatenate(ref["acts"], axis=1))
+    out = c.net(x)
+    assert np.array_equal(out["logits"], ref["logits"]) and np.array_equal(out["argmax"], ref["argmax"])
+    if info["has_softmax"]:
+        assert np.array_equal(out["softmax"], ref["softmax"])
+    c.close()
+
+
+def test_general_kernel_on_the_shipped_graph(ctx, cnn_golden):
+    """The shipped kws_conv model also has a general plan: its layer outputs equal the specialised kernels' and the
+    reference vectors of tests/golden/cnn_golden.npz; edison_net_batch keeps the matrix-core kernel for it."""
+    info = ctx.net_info()
+    assert info["accelerated"] == 1 and (info["in_h"], info["in_w"], info["in_c"], info["n_out"]) == (31, 13, 1, 10)
+    assert [L["type"] for L in info["layers"]] == [1, 2, 1, 2, 1, 1, 3, 4] and info["acts_bytes"] == 10420
+    rng = np.random.default_rng(42)
+    x = rng.integers(-128, 128, (700, 403)).astype(np.int8)
+    x[:100] = rng.integers(-30, 31, (100, 403))
+    general = ctx.net_layers(x)
+    special = ctx.cnn_layers(x)
+    assert np.array_equal(general, np.concatenate([special[k] for k in ("conv1", "pool1", "conv2", "pool2", "conv3", "conv4", "dense", "softmax")], axis=1))
+    a, b = ctx.net(x), ctx.cnn(x)
+    for k in ("logits", "softmax", "argmax"):
+        assert np.array_equal(a[k], b[k])
+    # the reference NNoM build's own layer outputs (tests/golden/gen_fixtures.py)
+    g = ctx.net_layers(cnn_golden["feats"])
+    want = np.concatenate([cnn_golden[k].reshape(g.shape[0], -1) for k in ("conv1", "pool1", "conv2", "pool2", "conv3", "conv4", "dense", "softmax")], axis=1)
+    assert np.array_equal(g, want)
+
+
+def test_other_classifier_through_kws_and_stream(built_lib, net_golden):
+    """A different graph with the keyword-spotting geometry (31x13x1 -> 10) serves edison_kws_batch, edison_cnn_batch
+    and the stream through the general kernel."""
+    from edison_amd import _lib
+    from edison_amd.stream import Stream
+    from oracle import net_ref
+    c = _context(built_lib, "kws_small")
+    blob = _blob("kws_small")
+    rng = np.random.default_rng(43)
+    audio = np.clip(rng.normal(0, 2500, 40 * 32000), -32768, 32767).astype(np.int16)
+    out = c.kws(audio, n_utt=40, utt_stride=32000)
+    ref = net_ref.run(blob, out["feat"].reshape(40, 403))
+    assert np.array_equal(out["logits"], ref["logits"]) and np.array_equal(out["softmax"], ref["softmax"])
+    assert np.array_equal(out["argmax"], ref["argmax"])
+    assert np.array_equal(c.cnn(net_golden["in_kws_small"])["softmax"], net_golden["acts_kws_small"][:, -10:])
+    with pytest.raises(_lib.EdisonError) as e:                                   # the kws_conv dump layout is not this graph's
+        c.cnn_layers(net_golden["in_kws_small"])
+    assert e.value.code == _lib.E_SIZE
+    # stream: window i of a push == the batch call on the same 31 frames
+    st = Stream(c, hop=1024, chunk_frames=4)
+    a = audio[:44 * 1024]
+    soft = np.concatenate([st.push(a[i * 4096:(i + 1) * 4096])["softmax"] for i in range(11)])
+    for i in range(30, 44):
+        w = c.kws(a[(i - 30) * 1024:(i + 1) * 1024], n_utt=1, utt_stride=31 * 1024)
+        assert np.array_equal(soft[i], w["softmax"][0])
+    # a reload invalidates the device addresses the stream's graphs captured
+    c.load_weights_h(_header("kws_small"))
+    with pytest.raises(_lib.EdisonError):
+        st.push(a[:4096])
+    st.close()
+    c.close()
+
+
+def test_planner_refusals(built_lib):
+    """Graphs the reference itself would run differently from the plain formula, or reject, are refused at load time."""
+    from edison_amd import _lib, nnom_import
+    from edison_amd.context import Context
+    T_CONV, T_POOL, T_DENSE, T_SOFTMAX = 1, 2, 3, 4
+    rng = np.random.default_rng(44)
+
+    def conv(oc, kh, kw, sh, sw, cin, same=0):
+        return dict(type=T_CONV, out_ch=oc, kh=kh, kw=kw, sh=sh, sw=sw, w=rng.integers(-9, 9, oc * kh * kw * cin).astype(np.int8),
+                    b=np.zeros(oc, np.int8), out_rshift=7, bias_lshift=0, relu=1, same=same)
+
+    def dense(no, ni):
+        return dict(type=T_DENSE, out=no, w=rng.integers(-9, 9, no * ni).astype(np.int8), b=np.zeros(no, np.int8), out_rshift=7,
+                    bias_lshift=0, relu=0)
+
+    c = Context(0, model_path=None)
+    cases = [
+        # square image, non-square kernel: the reference's square kernels would use kernel.w for both axes
+        ((12, 12, 1), [conv(4, 3, 5, 1, 1, 1)], _lib.E_NO_IMPL),
+        # 1x1, C_in % 4 == 0, C_out % 2 == 0, stride 2: arm_convolve_1x1_HWC_q7_fast_nonsquare returns SIZE_MISMATCH
+        ((10, 6, 4), [conv(2, 1, 1, 2, 2, 4)], _lib.E_SIZE),
+        # Softmax in the middle
+        ((10, 6, 1), [dict(type=T_SOFTMAX), dense(3, 60)], _lib.E_NO_IMPL),
+        # activations beyond the two LDS buffers
+        ((100, 60, 1), [conv(16, 3, 3, 1, 1, 1, same=1)], _lib.E_NO_IMPL),
+        # kernel larger than the image
+        ((4, 6, 1), [conv(2, 5, 3, 1, 1, 1)], _lib.E_SIZE),
+    ]
+    for shape, layers, code in cases:
+        with pytest.raises(_lib.EdisonError) as e:
+            c.load_model_bytes(nnom_import.build_blob(shape, layers))
+        assert e.value.code == code, (shape, str(e.value))
+    with pytest.raises(_lib.EdisonError):
+        c.net_info()                                                              # nothing loaded after the refusals
+    # a model that loads but is not 31x13x1 -> 10 cannot serve the fixed-shape entry points
+    c.load_model_bytes(nnom_import.build_blob((10, 6, 1), [conv(4, 3, 3, 1, 1, 1), dense(3, 8 * 4 * 4)]))
+    assert c.net(np.zeros((2, 60), np.int8))["logits"].shape == (2, 3)
+    with pytest.raises(_lib.EdisonError) as e:
+        c.cnn(np.zeros((1, 403), np.int8))
+    assert e.value.code == _lib.E_SIZE
+    # truncated blob
+    blob = nnom_import.build_blob((10, 6, 1), [conv(4, 3, 3, 1, 1, 1)])
+    with pytest.raises(_lib.EdisonError):
+        c.load_model_bytes(blob[:-20])
+    c.close()

@@ -151,3 +151,31 @@ def test_softmax_saturation_cases(oracle_mod, oracle_model, cnn_golden):
     d = cnn_golden["dense"][i].astype(int)
     assert d.max() - d.min() > 136
     assert cnn_golden["softmax"][i][d.argmin()] == 0
+
+
+@pytest.mark.parametrize("name", ["same_stride", "odd_no_softmax", "square", "kws_small"])
+def test_net_restatement_matches_reference_nnom(name):
+    """oracle/net_ref.py (any sequential NNoM graph) against layer outputs of the reference's own NNoM 0.3.0 + CMSIS-NN
+    compiled around four other generated model headers (tests/golden/gen_fixtures_net.py), through the importer."""
+    import os
+    from edison_amd import nnom_import
+    from oracle import net_ref
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold = np.load(os.path.join(g, "net_golden.npz"))
+    with open(os.path.join(g, "alt_models", name + ".h")) as f:
+        shape, layers = nnom_import.parse_weights_h(f.read())
+    out = net_ref.run(nnom_import.build_blob(shape, layers), gold["in_" + name])
+    assert np.array_equal(np.concatenate(out["acts"], axis=1), gold["acts_" + name])
+
+
+def test_net_restatement_on_the_shipped_graph(cnn_golden):
+    """The same numpy restatement on the committed kws_conv blob reproduces the reference build's layer outputs."""
+    import os
+    from oracle import net_ref
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "edison_amd", "data", "kws_nnom.ednn"), "rb") as f:
+        out = net_ref.run(f.read(), cnn_golden["feats"])
+    n = cnn_golden["feats"].shape[0]
+    for got, key in zip(out["acts"], ("conv1", "pool1", "conv2", "pool2", "conv3", "conv4", "dense", "softmax")):
+        assert np.array_equal(got, cnn_golden[key].reshape(n, -1)), key
+    assert np.array_equal(out["argmax"], cnn_golden["argmax"].ravel())
