@@ -3,9 +3,10 @@
  *
  * Input: an .ednn blob (tools/import_weights_h.py) holding the numbers of an NNoM weights.h -- for the
  * reference that is firmware/src/ai/nnom/kws_nnom/weights.h (arrays :3-45, shifts :50-105, graph :138-161).
- * The GPU kernels are specialised for that graph (kws_conv: conv5x5x16 / pool(2,1) / conv3x3x32 / pool(2,1) /
- * conv3x3x64 / conv3x3x32 / dense10 / softmax on a 31x13x1 input); a blob with any other topology is refused
- * with EDISON_E_SIZE rather than run wrongly. Weight VALUES and all shifts are free (a retrained model loads).
+ * The two fast kernels are specialised for that graph (kws_conv: conv5x5x16 / pool(2,1) / conv3x3x32 / pool(2,1) /
+ * conv3x3x64 / conv3x3x32 / dense10 / softmax on a 31x13x1 input); this parser answers EDISON_E_SIZE for any other
+ * topology, and the caller (edison_model_load_mem) then serves the model with the general plan of model_net.c alone.
+ * Weight VALUES and all shifts are free (a retrained model loads).
  *
  * Output: ed_cnn_model_t -- weights as dwords [K/4][out_channel] (OHWI order inside K), accumulator seeds
  * (bias << bias_lshift) + NN_ROUND(out_rshift) precomputed (arm_convolve_HWC_q7_basic_nonsquare.c:196).
