@@ -35,6 +35,10 @@ typedef struct {
 	 * against mel_w4[t][lane], then mel_shi4[lane] + t, t < mel_NHI, against mel_w4[mel_NLO + t][lane].
 	 * The four quarters of a band are summed across the lane rows (xor 16, xor 32).                          */
 	int32_t mel_slo4[64], mel_shi4[64];
+	/* Which band pair a column serves and which 16-byte half of a quad a lane reads first are free choices; tables.c
+	 * makes them so that the fast kernel's LDS reads spread over the banks. mel_band[lane] = the narrow band b of
+	 * the lane's column (its wide band is 31-b); mel_half[lane] = 0/1.                                           */
+	int32_t mel_band[64], mel_half[64];
 	/* ---- the block below is copied verbatim into LDS by every workgroup ---- */
 	/* DCT-II with the variant's normalisation folded in, using D[31-n][c] = (-1)^c D[n][c]:
 	 * y[c] = sum_{n<16} D[n][c] * (L[n] + (-1)^c L[31-n]); lane (c = lane&31, h = lane>>5) sums n = 8h..8h+7,

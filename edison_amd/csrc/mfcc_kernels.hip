@@ -266,6 +266,7 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 #endif
 	__syncthreads();
 	const int mel_slo4 = tab->mel_slo4[lane], mel_shi4 = tab->mel_shi4[lane];
+	const int band = tab->mel_band[lane]; /* this column's narrow band b; its wide band is 31 - b */
 	const float spec_scale = tab->spec_scale;
 	const float log_offset = tab->log_offset;
 	const bool do_log = tab->always_log || args.use_log;
@@ -431,14 +432,14 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 		const float lhi = do_log ? __logf(ehi + log_offset) : ehi; /* band 31-b */
 		if (STAGES && lane < 16)
 		{
-			if (args.mel) { args.mel[(int64_t)f * 32 + lane] = elo; args.mel[(int64_t)f * 32 + 31 - lane] = ehi; }
-			if (args.logmel) { args.logmel[(int64_t)f * 32 + lane] = llo; args.logmel[(int64_t)f * 32 + 31 - lane] = lhi; }
+			if (args.mel) { args.mel[(int64_t)f * 32 + band] = elo; args.mel[(int64_t)f * 32 + 31 - band] = ehi; }
+			if (args.logmel) { args.logmel[(int64_t)f * 32 + band] = llo; args.logmel[(int64_t)f * 32 + 31 - band] = lhi; }
 		}
 
 		/* ---- 6. DCT-II through cos symmetry: y[c] = sum_{n<16} D[n][c] * (L[n] + (-1)^c L[31-n]);
 		 *         lane (c = lane&31, h = lane>>5) sums n = 8h..8h+7 */
 		float *Lb = xbuf + ED_L_OFF; /* u[16] | v[16], 16-B aligned, behind the spectrum */
-		if (lane < 16) { Lb[lane] = llo + lhi; Lb[16 + lane] = llo - lhi; }
+		if (lane < 16) { Lb[band] = llo + lhi; Lb[16 + band] = llo - lhi; }
 		ed_wave_sync();
 		const float4 *L4 = reinterpret_cast<const float4 *>(Lb + 16 * (lane & 1) + 8 * (lane >> 5));
 		const float4 v0 = L4[0], v1 = L4[1], w0 = dctl[lane], w1 = dctl[64 + lane];
@@ -485,6 +486,14 @@ typedef float ed_f2 __attribute__((ext_vector_type(2)));
 #define ED2_S_OFF 1088    /* float offset of the interleaved spectra: their zero padding lies beyond the 2104 transpose floats */
 #define ED2_L_OFF 2128
 #define ED2_XBUF_FLOATS 2208
+/* timing-only ablations for A/B work (results are WRONG when non-zero): 1 = the frames of the first pair are reused
+ * (no HBM reads in the loop), 2 = no arithmetic (loads, one xor per dword, store) */
+#ifndef ED2_ABLATE
+#define ED2_ABLATE 0
+#endif
+#ifndef ED2_MEL_SWAP
+#define ED2_MEL_SWAP 1
+#endif
 
 /* NOT (ed_f2)(a, b): in C++ that is a cast of the comma expression, i.e. a splat of b */
 __device__ __forceinline__ ed_f2 ed_mk2(float a, float b) { ed_f2 r; r.x = a; r.y = b; return r; }
@@ -570,7 +579,14 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 	{
 		const float4 *src = reinterpret_cast<const float4 *>(&tab->dct4[0][0][0]);
 		float4 *dst = reinterpret_cast<float4 *>(smem);
-		for (int t = threadIdx.x; t < (ED_FIXTAB_FLOATS + (NLO + NHI) * 256) / 4; t += blockDim.x) dst[t] = src[t];
+		for (int t = threadIdx.x; t < (ED_FIXTAB_FLOATS + (NLO + NHI) * 256) / 4; t += blockDim.x)
+		{
+			float4 v = src[t];
+			/* lanes with mel_half = 1 read the two 16-byte halves of a spectrum quad in the opposite order (see the mel
+			 * stage), so their weight quads are stored (z, w, x, y); ED_FIXTAB_FLOATS / 4 is a multiple of 64 */
+			if (ED2_MEL_SWAP && t >= ED_FIXTAB_FLOATS / 4 && tab->mel_half[t & 63]) v = make_float4(v.z, v.w, v.x, v.y);
+			dst[t] = v;
+		}
 	}
 	float t1r[8], t1i[8], t2r[8], t2i[8];
 #pragma unroll
@@ -582,6 +598,8 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 	}
 	__syncthreads();
 	const int mel_slo4 = tab->mel_slo4[lane], mel_shi4 = tab->mel_shi4[lane];
+	const int band = tab->mel_band[lane]; /* this column's narrow band b; its wide band is 31 - b */
+	const int mel_half = tab->mel_half[lane];
 	const float log_offset = tab->log_offset;
 	const bool do_log = tab->always_log || args.use_log;
 	const int k0 = ED_K0(lane);
@@ -604,11 +622,28 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 			re[a] = ed_mk2((float)(int16_t)(rawA[a] & 0xffffu), (float)(int16_t)(rawB[a] & 0xffffu));
 			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
 		}
-		if (p + stride < n_pairs)
+		if (!(ED2_ABLATE & 1) && p + stride < n_pairs)
 		{
 			const uint32_t na = 2 * (p + stride), nb = na + 1 < n_frames ? na + 1 : na;
 			ed_load_frame<ALIGNED>(ed_frame_ptr(args, na), lane, rawA);
 			ed_load_frame<ALIGNED>(ed_frame_ptr(args, nb), lane, rawB);
+		}
+		if (ED2_ABLATE & 1)
+		{
+#pragma unroll
+			for (int a = 0; a < 8; a++) asm volatile("" : "+v"(rawA[a]), "+v"(rawB[a])); /* keeps the unpack in the loop */
+		}
+		if (ED2_ABLATE & 2)
+		{
+			ed_f2 acc = re[0] + im[0];
+#pragma unroll
+			for (int a = 1; a < 8; a++) acc += re[a] + im[a];
+			if (lane < args.n_coef && args.mfcc)
+			{
+				args.mfcc[(int64_t)fA * args.n_coef + lane] = acc.x;
+				if (haveB) args.mfcc[(int64_t)(fA + 1) * args.n_coef + lane] = acc.y;
+			}
+			continue;
 		}
 
 		/* ---- 2a. pass 1 + twiddle W512^(lane*p) */
@@ -689,11 +724,17 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 
 		/* ---- 5. mel filterbank, balanced as above; a spectrum quad of both frames is two 16-byte reads */
 		const float4 *S4 = reinterpret_cast<const float4 *>(S2);
+		/* Every ds_read_b128 serves 16 lanes from 16 slots of 16 bytes; if all lanes took the first half of their quad,
+		 * only the even slots would be used. Half of the lanes therefore start with the second half (their weights are
+		 * swapped to match); tables.c picks them, and the column order, to minimise the passes (mel_half, mel_band). */
+		const int half = ED2_MEL_SWAP ? mel_half : 0;
+		const int qlo_a = 2 * mel_slo4 + half, qlo_b = 2 * mel_slo4 + 1 - half;
+		const int qhi_a = 2 * mel_shi4 + half, qhi_b = 2 * mel_shi4 + 1 - half;
 		ed_f2 alo0 = ed_splat(0.0f), alo1 = alo0, ahi0 = alo0, ahi1 = alo0;
 #pragma unroll
 		for (int t = 0; t < NLO; t++)
 		{
-			const float4 sa = S4[2 * (mel_slo4 + t)], sb = S4[2 * (mel_slo4 + t) + 1], w = melw4[t * 64 + lane];
+			const float4 sa = S4[qlo_a + 2 * t], sb = S4[qlo_b + 2 * t], w = melw4[t * 64 + lane];
 			alo0 = ed_fma2(ed_mk2(sa.x, sa.y), ed_splat(w.x), alo0); alo1 = ed_fma2(ed_mk2(sa.z, sa.w), ed_splat(w.y), alo1);
 			alo0 = ed_fma2(ed_mk2(sb.x, sb.y), ed_splat(w.z), alo0); alo1 = ed_fma2(ed_mk2(sb.z, sb.w), ed_splat(w.w), alo1);
 		}
@@ -701,7 +742,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 		for (int t = 0; t < NHI; t++)
 		{
 			if (t % 2 == 0) __builtin_amdgcn_sched_barrier(0); /* bounds the registers this stage holds in flight */
-			const float4 sa = S4[2 * (mel_shi4 + t)], sb = S4[2 * (mel_shi4 + t) + 1], w = melw4[(NLO + t) * 64 + lane];
+			const float4 sa = S4[qhi_a + 2 * t], sb = S4[qhi_b + 2 * t], w = melw4[(NLO + t) * 64 + lane];
 			ahi0 = ed_fma2(ed_mk2(sa.x, sa.y), ed_splat(w.x), ahi0); ahi1 = ed_fma2(ed_mk2(sa.z, sa.w), ed_splat(w.y), ahi1);
 			ahi0 = ed_fma2(ed_mk2(sb.x, sb.y), ed_splat(w.z), ahi0); ahi1 = ed_fma2(ed_mk2(sb.z, sb.w), ed_splat(w.w), ahi1);
 		}
@@ -716,7 +757,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 
 		/* ---- 6. DCT-II through cos symmetry, both frames */
 		ed_f2 *Lb2 = reinterpret_cast<ed_f2 *>(xbuf + ED2_L_OFF); /* u[16] | v[16] as float2 */
-		if (lane < 16) { Lb2[lane] = llo + lhi; Lb2[16 + lane] = llo - lhi; }
+		if (lane < 16) { Lb2[band] = llo + lhi; Lb2[16 + band] = llo - lhi; }
 		ed_wave_sync();
 		const float4 *L4 = reinterpret_cast<const float4 *>(Lb2 + 16 * (lane & 1) + 8 * (lane >> 5));
 		const float4 v0 = L4[0], v1 = L4[1], v2 = L4[2], v3 = L4[3];
