@@ -15,7 +15,8 @@
  *   Softmax  arm_softmax_q7.c:215-260, portable branch; argmax = first maximum of the last layer (nnom_utils.c:275-284)
  *
  * The shipped kws_conv graph does not come here: cnn_mfma_kernels.hip runs it on the matrix cores. This kernel trades
- * peak speed for generality: 4-channel groups use v_dot4_i32_i8, everything else plain multiply-adds.
+ * peak speed for generality: 4-channel groups use v_dot4_i32_i8, everything else plain multiply-adds; convolutions
+ * with C_out % 4 == 0 are register-blocked (4 channels x 2 pixels per thread).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -68,6 +69,78 @@ __device__ __forceinline__ void en_conv(const ed_net_layer_t &L, const int8_t *i
 		int v = en_ssat8(acc >> L.rs);
 		if (L.relu && v < 0) v = 0;
 		out[idx] = (int8_t)v;
+	}
+}
+
+/* The same convolution, register-blocked for C_out % 4 == 0: a thread owns 4 output channels (oq + j * C_out/4, so
+ * that lanes still read consecutive weights) of EN_PB consecutive pixels. One activation read feeds 4 multiply-adds
+ * and one weight read EN_PB: 4 + EN_PB loads per 4 * EN_PB instead of 8 * EN_PB. Taps outside the image contribute
+ * a zero activation; a pixel tail recomputes the last pixel and stores it once. */
+#ifndef EN_PB
+#define EN_PB 2 /* 4 measured slower on the test graphs: too few work items left in the small late layers */
+#endif
+template <bool C4, bool PADDED>
+__device__ __forceinline__ void en_conv_blocked(const ed_net_layer_t &L, const int8_t *in, int8_t *out, const int8_t *__restrict__ W,
+                                                const int32_t *__restrict__ S)
+{
+	const int oc = L.out_c, oq_n = oc >> 2, cg = C4 ? L.in_c / 4 : L.in_c;
+	const int npix = L.out_h * L.out_w, ngrp = (npix + EN_PB - 1) / EN_PB;
+	for (int idx = threadIdx.x; idx < ngrp * oq_n; idx += EN_THREADS)
+	{
+		const int pg = idx / oq_n, oq = idx - pg * oq_n;
+		int pix[EN_PB], ybase[EN_PB], xbase[EN_PB], acc[EN_PB][4];
+#pragma unroll
+		for (int i = 0; i < EN_PB; i++)
+		{
+			pix[i] = EN_PB * pg + i < npix ? EN_PB * pg + i : npix - 1;
+			const int y = pix[i] / L.out_w;
+			ybase[i] = y * L.sh - L.pad_h;
+			xbase[i] = (pix[i] - y * L.out_w) * L.sw - L.pad_w;
+#pragma unroll
+			for (int j = 0; j < 4; j++) acc[i][j] = S[L.seed_off + oq + j * oq_n];
+		}
+		for (int ky = 0; ky < L.kh; ky++)
+			for (int kx = 0; kx < L.kw; kx++)
+			{
+				bool inside[EN_PB];
+				const int8_t *a[EN_PB];
+#pragma unroll
+				for (int i = 0; i < EN_PB; i++)
+				{
+					const int iy = ybase[i] + ky, ix = xbase[i] + kx;
+					inside[i] = !PADDED || ((unsigned)iy < (unsigned)L.in_h && (unsigned)ix < (unsigned)L.in_w);
+					a[i] = in + (inside[i] ? (iy * L.in_w + ix) * L.in_c : 0);
+				}
+				const int64_t row0 = (int64_t)(ky * L.kw + kx) * cg * oc + oq;
+				for (int c = 0; c < cg; c++)
+				{
+					int v[EN_PB], w[4];
+#pragma unroll
+					for (int i = 0; i < EN_PB; i++)
+						v[i] = !inside[i] ? 0 : C4 ? reinterpret_cast<const int *>(a[i])[c] : (int)a[i][c];
+#pragma unroll
+					for (int j = 0; j < 4; j++)
+						w[j] = C4 ? (reinterpret_cast<const int *>(W + L.w_off) + row0)[(int64_t)c * oc + j * oq_n]
+						          : (int)(W + L.w_off + row0)[(int64_t)c * oc + j * oq_n];
+#pragma unroll
+					for (int i = 0; i < EN_PB; i++)
+#pragma unroll
+						for (int j = 0; j < 4; j++)
+							acc[i][j] = C4 ? __builtin_amdgcn_sdot4(v[i], w[j], acc[i][j], false) : acc[i][j] + v[i] * w[j];
+				}
+			}
+#pragma unroll
+		for (int i = 0; i < EN_PB; i++)
+		{
+			if (EN_PB * pg + i >= npix) continue;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+			{
+				int r = en_ssat8(acc[i][j] >> L.rs);
+				if (L.relu && r < 0) r = 0;
+				out[pix[i] * oc + oq + j * oq_n] = (int8_t)r;
+			}
+		}
 	}
 }
 
@@ -153,7 +226,13 @@ __global__ __launch_bounds__(EN_THREADS) void ed_net_kernel(const ed_net_plan_t 
 			if (L.type == ED_NET_CONV)
 			{
 				const bool padded = (L.pad_h | L.pad_w) != 0; /* VALID layers need no tap tests */
-				if ((L.in_c & 3) == 0) { if (padded) en_conv<true, true>(L, a, o, W, S); else en_conv<true, false>(L, a, o, W, S); }
+				const bool c4 = (L.in_c & 3) == 0;
+				if ((L.out_c & 3) == 0)
+				{
+					if (c4) { if (padded) en_conv_blocked<true, true>(L, a, o, W, S); else en_conv_blocked<true, false>(L, a, o, W, S); }
+					else { if (padded) en_conv_blocked<false, true>(L, a, o, W, S); else en_conv_blocked<false, false>(L, a, o, W, S); }
+				}
+				else if (c4) { if (padded) en_conv<true, true>(L, a, o, W, S); else en_conv<true, false>(L, a, o, W, S); }
 				else { if (padded) en_conv<false, true>(L, a, o, W, S); else en_conv<false, false>(L, a, o, W, S); }
 			}
 			else if (L.type == ED_NET_POOL) en_pool(L, a, o);
