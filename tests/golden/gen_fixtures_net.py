@@ -46,6 +46,13 @@ MODELS = {
     # another classifier with the keyword-spotting geometry (31x13x1 -> 10): goes through edison_kws_* / edison_stream_*
     "kws_small": ((31, 13, 1), [("conv", 8, (3, 3), (2, 1), "SAME", 1), ("pool", (2, 2), (2, 2), "VALID"),
                                 ("dense", 10, 0), ("softmax",)]),
+    # the reference's own other architectures (audio/edison/train/kws_keras.py:170-352) with random parameters:
+    # 'tiny_conv' as written there (:176-198) ...
+    "tiny_conv": ((31, 13, 1), [("conv", 8, (8, 10), (2, 2), "SAME", 1), ("flatten",), ("dense", 10, 0), ("softmax",)]),
+    # ... and 'low_latency_conv' (:322-352: a kernel wider than the image, stride (1,4), three Dense layers) with 10
+    # filters and 32-wide Dense layers instead of 186 / 128, to keep the committed header small
+    "low_latency_small": ((31, 13, 1), [("conv", 10, (8, 31), (1, 4), "SAME", 1), ("flatten",), ("dense", 32, 0),
+                                        ("dense", 32, 0), ("dense", 10, 0), ("softmax",)]),
 }
 
 

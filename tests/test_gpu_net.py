@@ -2,7 +2,7 @@
 NNoM int8 graph, not only the shipped kws_conv one. Integer arithmetic => every comparison is bit for bit.
 
 The expected values in tests/golden/net_golden.npz come from the REFERENCE's own NNoM 0.3.0 + CMSIS-NN compiled around
-four other generated model headers (tests/golden/gen_fixtures_net.py); larger seeded batches are compared with the numpy
+six other generated model headers (tests/golden/gen_fixtures_net.py); larger seeded batches are compared with the numpy
 restatement oracle/net_ref.py, which that script checked against the same reference build.
 """
 import os
@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-NAMES = ["same_stride", "odd_no_softmax", "square", "kws_small"]
+NAMES = ["same_stride", "odd_no_softmax", "square", "kws_small", "tiny_conv", "low_latency_small"]
 
 
 @pytest.fixture(scope="module")
