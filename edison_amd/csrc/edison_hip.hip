@@ -196,7 +196,7 @@ extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t b
 		char why[256];
 		const int fast = ed_parse_model(blob, blob_bytes, h, hm, why, sizeof(why)) == EDISON_OK;
 		e = hipSetDevice(ctx->device);
-		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		if (e == hipSuccess) e = hipDeviceSynchronize(); /* streams of edison_stream objects may still read the old model */
 		if (e == hipSuccess && fast && !ctx->d_model) e = hipMalloc((void **)&ctx->d_model, sizeof(ed_cnn_model_t));
 		if (e == hipSuccess && fast && !ctx->d_model_mfma) e = hipMalloc((void **)&ctx->d_model_mfma, sizeof(ed_cnn_mfma_model_t));
 		if (e == hipSuccess && fast) e = hipMemcpy(ctx->d_model, h, sizeof(ed_cnn_model_t), hipMemcpyHostToDevice);
