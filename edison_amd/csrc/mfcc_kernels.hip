@@ -111,7 +111,9 @@ __device__ __forceinline__ void ed_xchg(float &A, float &B, int lane)
 	}
 	else if (LB == 3)
 	{
-		/* row_shr:8 -> lanes 8..15 of a row (banks 2,3) read lane-8; row_shl:8 -> lanes 0..7 (banks 0,1) read lane+8 */
+		/* row_shr:8 -> lanes 8..15 of a row (banks 2,3) read lane-8; row_shl:8 -> lanes 0..7 (banks 0,1) read lane+8.
+		 * (Whole-register shifts + a select on lane bit 3 cost one instruction more: the select does not fold into a
+		 * v_cndmask DPP form.) */
 		const unsigned na = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x118, 0xf, 0xc, false);
 		const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x108, 0xf, 0x3, false);
 		A = __uint_as_float(na); B = __uint_as_float(nb);
@@ -550,8 +552,20 @@ __device__ __forceinline__ void ed_transpose8_2(ed_f2 (&x)[8], int lane)
 	for (int i = 0; i < 8; i++) x[i] = ed_mk2(a[i], b[i]);
 }
 
-__device__ __forceinline__ ed_f2 ed_sum_halves2(ed_f2 x) { return ed_mk2(ed_sum_halves(x.x), ed_sum_halves(x.y)); }
-__device__ __forceinline__ ed_f2 ed_sum_rows2(ed_f2 x) { return ed_mk2(ed_sum_rows(x.x), ed_sum_rows(x.y)); }
+/* v_permlane32_swap exchanges a's upper half with b's lower half; the sum of the two results is
+ * lanes 0..31: a[l] + a[l+32], lanes 32..63: b[l-32] + b[l] -- both registers folded by one swap and one add */
+__device__ __forceinline__ float ed_fold_halves(float a, float b)
+{
+	const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+	return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+/* v_permlane16_swap exchanges a's odd rows with b's even rows; the sum is
+ * even rows R: a[R] + a[R+1], odd rows R: b[R-1] + b[R] */
+__device__ __forceinline__ float ed_fold_rows(float a, float b)
+{
+	const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+	return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 template <bool ALIGNED, int NLO, int NHI>
 __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
@@ -600,6 +614,9 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 	const int mel_slo4 = tab->mel_slo4[lane], mel_shi4 = tab->mel_shi4[lane];
 	const int band = tab->mel_band[lane]; /* this column's narrow band b; its wide band is 31 - b */
 	const int mel_half = tab->mel_half[lane];
+	/* where this lane puts its DCT input (float index into Lb2 = float2 u[16] | v[16]): rows 0/1 hold frame A's
+	 * u/v of the column's band, rows 2/3 frame B's */
+	const int l_idx = 2 * (16 * ((lane >> 4) & 1) + band) + (lane >> 5);
 	const float log_offset = tab->log_offset;
 	const bool do_log = tab->always_log || args.use_log;
 	const int k0 = ED_K0(lane);
@@ -622,9 +639,12 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 			re[a] = ed_mk2((float)(int16_t)(rawA[a] & 0xffffu), (float)(int16_t)(rawB[a] & 0xffffu));
 			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
 		}
-		if (!(ED2_ABLATE & 1) && p + stride < n_pairs)
+		if (!(ED2_ABLATE & 1))
 		{
-			const uint32_t na = 2 * (p + stride), nb = na + 1 < n_frames ? na + 1 : na;
+			/* unconditional: a conditional load makes the frame registers a merge of two definitions and costs 16
+			 * copies per iteration; the last iteration of a wave re-reads the batch's last pair instead (L2 hits) */
+			const uint32_t np = p + stride < n_pairs ? p + stride : n_pairs - 1;
+			const uint32_t na = 2 * np, nb = na + 1 < n_frames ? na + 1 : na;
 			ed_load_frame<ALIGNED>(ed_frame_ptr(args, na), lane, rawA);
 			ed_load_frame<ALIGNED>(ed_frame_ptr(args, nb), lane, rawB);
 		}
@@ -747,17 +767,21 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 			ahi0 = ed_fma2(ed_mk2(sb.x, sb.y), ed_splat(w.z), ahi0); ahi1 = ed_fma2(ed_mk2(sb.z, sb.w), ed_splat(w.w), ahi1);
 		}
 		__builtin_amdgcn_sched_barrier(0);
-		const ed_f2 elo = ed_sum_rows2(alo0 + alo1), ehi = ed_sum_rows2(ahi0 + ahi1);
-		ed_f2 llo = elo, lhi = ehi;
-		if (do_log)
-		{
-			llo = ed_mk2(__logf(elo.x + log_offset), __logf(elo.y + log_offset));
-			lhi = ed_mk2(__logf(ehi.x + log_offset), __logf(ehi.y + log_offset));
-		}
+		/* The four row-quarters of a band are summed with the swap instructions, and because a swap exchanges halves
+		 * of TWO registers, two sums are folded at once: first frame A's and frame B's partial sums over the wave
+		 * halves (lanes 0..31 then hold A, 32..63 B), then the narrow and the wide band over the row pairs. One
+		 * register ends up with  row 0: band b of A,  row 1: band 31-b of A,  row 2: b of B,  row 3: 31-b of B. */
+		const ed_f2 plo = alo0 + alo1, phi = ahi0 + ahi1;
+		float t = ed_fold_rows(ed_fold_halves(plo.x, plo.y), ed_fold_halves(phi.x, phi.y));
+		if (do_log) t = __logf(t + log_offset);
 
-		/* ---- 6. DCT-II through cos symmetry, both frames */
-		ed_f2 *Lb2 = reinterpret_cast<ed_f2 *>(xbuf + ED2_L_OFF); /* u[16] | v[16] as float2 */
-		if (lane < 16) { Lb2[band] = llo + lhi; Lb2[16 + band] = llo - lhi; }
+		/* ---- 6. DCT-II through cos symmetry, both frames: u = L[b] + L[31-b] (even rows), v = L[b] - L[31-b] (odd) */
+		ed_f2 *Lb2 = reinterpret_cast<ed_f2 *>(xbuf + ED2_L_OFF); /* u[16] | v[16] as float2 (A, B) */
+		{
+			const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+			const float tb = __uint_as_float(r[0]), to = __uint_as_float(r[1]); /* [r0 r0 r2 r2], [r1 r1 r3 r3] */
+			reinterpret_cast<float *>(Lb2)[l_idx] = (lane & 16) ? tb - to : tb + to;
+		}
 		ed_wave_sync();
 		const float4 *L4 = reinterpret_cast<const float4 *>(Lb2 + 16 * (lane & 1) + 8 * (lane >> 5));
 		const float4 v0 = L4[0], v1 = L4[1], v2 = L4[2], v3 = L4[3];
@@ -766,25 +790,19 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 		d = ed_fma2(ed_mk2(v0.z, v0.w), ed_splat(w0.y), d); d1 = ed_fma2(ed_mk2(v2.z, v2.w), ed_splat(w1.y), d1);
 		d = ed_fma2(ed_mk2(v1.x, v1.y), ed_splat(w0.z), d); d1 = ed_fma2(ed_mk2(v3.x, v3.y), ed_splat(w1.z), d1);
 		d = ed_fma2(ed_mk2(v1.z, v1.w), ed_splat(w0.w), d); d1 = ed_fma2(ed_mk2(v3.z, v3.w), ed_splat(w1.w), d1);
-		d = ed_sum_halves2(d + d1);
+		d = d + d1;
+		/* the two halves of the sum, again for both frames with one swap: lanes 0..31 get coefficient `lane` of
+		 * frame A, lanes 32..63 coefficient `lane - 32` of frame B */
+		const float coef = ed_fold_halves(d.x, d.y);
 		ed_wave_sync(); /* Lb2 / S2 are rewritten by the next pair */
 
-		/* ---- 7. store */
-		if (lane < args.n_coef)
+		/* ---- 7. store: A's and B's rows are adjacent in memory, one instruction writes both */
+		const int c = lane & 31;
+		if (c < args.n_coef && (lane < 32 || haveB))
 		{
-			const int64_t at = (int64_t)fA * args.n_coef + lane;
-			if (args.mfcc)
-			{
-				args.mfcc[at] = d.x;
-				if (haveB) args.mfcc[at + args.n_coef] = d.y;
-			}
-			if (args.feat)
-			{
-				ed_f2 q = d * ed_splat(args.feat_scale);
-				const float qa = fminf(fmaxf(q.x, -128.0f), 127.0f), qb = fminf(fmaxf(q.y, -128.0f), 127.0f);
-				args.feat[at] = (int8_t)__float2int_rn(qa);
-				if (haveB) args.feat[at + args.n_coef] = (int8_t)__float2int_rn(qb);
-			}
+			const int64_t at = (int64_t)(fA + (lane >> 5)) * args.n_coef + c;
+			if (args.mfcc) args.mfcc[at] = coef;
+			if (args.feat) args.feat[at] = (int8_t)__float2int_rn(fminf(fmaxf(coef * args.feat_scale, -128.0f), 127.0f));
 		}
 	}
 }
