@@ -370,9 +370,11 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 		/* ---- stage 1: real samples become (re, 0) */
 #pragma unroll
 		for (int i = 0; i < 16; i++) e[i] = (u32)raw[i];
-		if (f + fstride < n_frames && f + fstride > f)
 		{
-			const int16_t *src = eq_frame_ptr(a, f + fstride);
+			/* unconditional (a conditional load would make raw[] a merge of two definitions: 16 copies per frame at the
+			 * loop latch); a wave's last iteration re-reads the batch's last frame, an L2 hit */
+			const uint32_t fn = (f + fstride < n_frames && f + fstride > f) ? f + fstride : n_frames - 1;
+			const int16_t *src = eq_frame_ptr(a, fn);
 #pragma unroll
 			for (int i = 0; i < 16; i++) raw[i] = (unsigned short)src[lane + 64 * (i >> 2) + 256 * (i & 3)];
 		}
