@@ -10,14 +10,14 @@
 
 #include "edison_ctx.h"
 
-extern "C" int ed_launch_mfcc_f32(const ed_mfcc_f32_args_t *args, const ed_f32_tables_t *dev_tab, int n_cu, hipStream_t stream);
+extern "C" int ed_launch_mfcc_f32(const ed_mfcc_f32_args_t *args, const ed_f32_tables_t *dev_tab, int padded, int n_cu, hipStream_t stream);
 
 /* the handle: opaque to callers (the firmware's struct fields are its private scratch) */
 struct _mfcc_t
 {
 	edison_ctx *ctx;
 	ed_f32_tables_t *d_tab;
-	int n_out, frame_len;
+	int n_out, frame_len, padded;
 };
 
 extern "C" mfcc_t *edison_mfcc_f32_create(edison_ctx *ctx, int num_mfcc_features, int feature_offset, int frame_len,
@@ -29,6 +29,7 @@ extern "C" mfcc_t *edison_mfcc_f32_create(edison_ctx *ctx, int num_mfcc_features
 	if (!h || !m) { free(h); free(m); ed_set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed"); return NULL; }
 	int r = ed_build_f32_tables(num_mfcc_features, feature_offset, frame_len, mfcc_dec_bits, preemph, h, ctx->err, sizeof(ctx->err));
 	hipError_t e = hipSuccess;
+	const int padded = r == EDISON_OK ? h->padded : 0; /* the kernel's per-wave LDS buffer is sized by it */
 	if (r == EDISON_OK)
 	{
 		e = hipSetDevice(ctx->device);
@@ -46,6 +47,7 @@ extern "C" mfcc_t *edison_mfcc_f32_create(edison_ctx *ctx, int num_mfcc_features
 	m->ctx = ctx;
 	m->n_out = num_mfcc_features - feature_offset;
 	m->frame_len = frame_len;
+	m->padded = padded;
 	return m;
 }
 
@@ -66,7 +68,7 @@ extern "C" int edison_mfcc_f32_batch_dev(mfcc_t *mfcc, const int16_t *audio, int
 	edison_ctx *ctx = mfcc->ctx;
 	ed_mfcc_f32_args_t a;
 	a.audio = audio; a.n_frames = n_frames; a.frame_step = frame_step; a.out = out; a.out_f32 = out_f32; a.logmel = logmel;
-	int e = ed_launch_mfcc_f32(&a, mfcc->d_tab, ctx->n_cu, ctx->stream);
+	int e = ed_launch_mfcc_f32(&a, mfcc->d_tab, mfcc->padded, ctx->n_cu, ctx->stream);
 	if (e != 0)
 	{
 		snprintf(ctx->err, sizeof(ctx->err), "float32 MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)e));

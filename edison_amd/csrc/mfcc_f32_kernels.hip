@@ -26,16 +26,22 @@ __device__ __forceinline__ void ef_wave_sync() { __builtin_amdgcn_wave_barrier()
 
 __global__ __launch_bounds__(64 * EF_WPB) void ed_mfcc_f32_kernel(ed_mfcc_f32_args_t a, const ed_f32_tables_t *__restrict__ T)
 {
-	__shared__ float2 s_buf[EF_WPB][ED_F32_MAX_FRAME];
+	extern __shared__ __attribute__((aligned(16))) float2 s_buf[]; /* [EF_WPB][padded]: sized by the launcher */
 	__shared__ float2 s_tw[ED_F32_MAX_FRAME / 2];
 	__shared__ float s_lm[EF_WPB][32];
+	__shared__ float s_melw[ED_F32_MAX_W];
+	__shared__ float s_dct[ED_F32_NUM_FBANK * ED_F32_NUM_FBANK];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const int N = T->frame_len, P = T->padded, L2 = T->log2p, half = P >> 1;
 	const int n_out = T->n_features - T->offset;
 	const float preempha = T->preempha, scale = T->scale;
 	for (int i = threadIdx.x; i < half; i += 64 * EF_WPB) s_tw[i] = make_float2(T->tw[i][0], T->tw[i][1]);
+	/* mel weights and DCT rows are read serially by few lanes (the firmware's summation order is kept): from LDS,
+	 * with the loads of several taps in flight, not one global load per dependent add */
+	for (int i = threadIdx.x; i < ED_F32_MAX_W; i += 64 * EF_WPB) s_melw[i] = T->mel_w[i];
+	for (int i = threadIdx.x; i < ED_F32_NUM_FBANK * ED_F32_NUM_FBANK; i += 64 * EF_WPB) s_dct[i] = T->dct[i];
 	__syncthreads();
-	float2 *buf = s_buf[w];
+	float2 *buf = s_buf + w * P;
 	float *mag = reinterpret_cast<float *>(buf); /* magnitudes overwrite the transform in place (k <= P/2 < P floats) */
 	float *lm = s_lm[w];
 
@@ -94,9 +100,12 @@ __global__ __launch_bounds__(64 * EF_WPB) void ed_mfcc_f32_kernel(ed_mfcc_f32_ar
 		{
 			float e = 0.0f;
 			const int first = T->mel_first[lane], last = T->mel_last[lane];
-			const float *wgt = T->mel_w + T->mel_off[lane];
+			const float *wgt = s_melw + T->mel_off[lane];
 			if (first >= 0)
+			{
+#pragma unroll 8
 				for (int i = first; i <= last; i++) e += mag[i] * wgt[i - first];
+			}
 			if (e == 0.0f) e = FLT_MIN;
 			const float l = logf(e);
 			lm[lane] = l;
@@ -106,8 +115,9 @@ __global__ __launch_bounds__(64 * EF_WPB) void ed_mfcc_f32_kernel(ed_mfcc_f32_ar
 		/* 5. DCT rows, scale, round half away from zero, saturate */
 		if (lane < n_out)
 		{
-			const float *row = T->dct + (T->offset + lane) * ED_F32_NUM_FBANK;
+			const float *row = s_dct + (T->offset + lane) * ED_F32_NUM_FBANK;
 			float sum = 0.0f;
+#pragma unroll
 			for (int j = 0; j < ED_F32_NUM_FBANK; j++) sum += row[j] * lm[j];
 			sum *= scale;
 			if (a.out_f32) a.out_f32[f * n_out + lane] = sum;
@@ -118,12 +128,16 @@ __global__ __launch_bounds__(64 * EF_WPB) void ed_mfcc_f32_kernel(ed_mfcc_f32_ar
 	}
 }
 
-extern "C" int ed_launch_mfcc_f32(const ed_mfcc_f32_args_t *args, const ed_f32_tables_t *dev_tab, int n_cu, hipStream_t stream)
+extern "C" int ed_launch_mfcc_f32(const ed_mfcc_f32_args_t *args, const ed_f32_tables_t *dev_tab, int padded, int n_cu, hipStream_t stream)
 {
 	if (args->n_frames <= 0) return 0;
 	int64_t blocks = (args->n_frames + EF_WPB - 1) / EF_WPB;
-	const int64_t cap = (int64_t)n_cu * 4;
+	const size_t lds = (size_t)EF_WPB * (size_t)padded * sizeof(float2);
+	int per_cu = (int)((160u * 1024u) / (lds + 12u * 1024u)); /* + the static tables */
+	if (per_cu > 8) per_cu = 8;
+	if (per_cu < 1) per_cu = 1;
+	const int64_t cap = (int64_t)n_cu * per_cu;
 	if (blocks > cap) blocks = cap;
-	hipLaunchKernelGGL(ed_mfcc_f32_kernel, dim3((unsigned)blocks), dim3(64 * EF_WPB), 0, stream, *args, dev_tab);
+	hipLaunchKernelGGL(ed_mfcc_f32_kernel, dim3((unsigned)blocks), dim3(64 * EF_WPB), lds, stream, *args, dev_tab);
 	return (int)hipGetLastError();
 }
