@@ -292,3 +292,35 @@ def test_shard_range():
     assert shard_range(2097152, 3, 8) == (786432, 1048576)
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+@pytest.mark.parametrize("variant,nbins,scale", [(0, 512, 0.5), (1, 513, 0.5 / 1024.0 / np.sqrt(2.0))])
+def test_mfcc_lane_tables_hold_the_whole_filterbank(built_lib, mfcc_golden, variant, nbins, scale):
+    """tables.c spreads the mel matrix over the wavefront (quarter r of band pair (b, 31-b) per lane) and is free to
+    choose the column order and the half order (bank-conflict-aware assignment): whatever it chooses, putting the
+    lane tables back together must give the reference's matrix (x the variant's spectrum scale), each weight once."""
+    from edison_amd import _lib
+    built_lib.ed_build_mfcc_tables.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                               ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    buf = (ctypes.c_char * 65536)()
+    err = ctypes.create_string_buffer(256)
+    assert built_lib.ed_build_mfcc_tables(variant, 16000.0, 80.0, 7600.0, 128.0, buf, err, 256) == _lib.OK, err.value
+    i32 = np.frombuffer(buf, dtype=np.int32)
+    f32 = np.frombuffer(buf, dtype=np.float32)
+    o = 2 * 8 * 64 * 2                                            # tw1, tw2 (floats)
+    slo, shi, band, half = (i32[o + 64 * k:o + 64 * (k + 1)] for k in range(4))
+    o += 4 * 64 + 2 * 64 * 4 + 4 * 64 * 2                         # + dct4, twp
+    w4 = f32[o:o + 9 * 64 * 4].reshape(9, 64, 4)
+    nlo, nhi = int(i32[o + 9 * 64 * 4]), int(i32[o + 9 * 64 * 4 + 1])
+    assert (nlo, nhi) == (2, 5)
+    assert sorted(band[:16].tolist()) == list(range(16)) and all((band[16 * r:16 * r + 16] == band[:16]).all() for r in range(4))
+    assert set(half.tolist()) <= {0, 1}
+    W = np.zeros((516, 32))
+    for lane in range(64):
+        for part, (first, n, base) in enumerate(((slo[lane], nlo, 0), (shi[lane], nhi, nlo))):
+            j = band[lane] if part == 0 else 31 - band[lane]
+            for t in range(n):
+                W[4 * (first + t):4 * (first + t) + 4, j] += w4[base + t, lane]
+    ref = mfcc_golden["mel_W512" if nbins == 512 else "mel_W513"] * scale
+    np.testing.assert_allclose(W[:nbins], ref, rtol=2e-7, atol=1e-12)
+    assert not W[nbins:].any()
