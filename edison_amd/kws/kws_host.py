@@ -45,8 +45,9 @@ def infer_utterances(audio, ctx=None):
     return ctx.kws(np.ascontiguousarray(a), n_utt=a.shape[0], utt_stride=a.shape[1])
 
 
-def report(res, i=0, out=sys.stdout):
+def report(res, i=0, out=None):
     """Prediction line in the spirit of kws_on_mcu.report (:148-157): int8 softmax / 127 and the class."""
+    out = out or sys.stdout  # looked up per call: a default bound at import time may be a stream that is closed by now
     np.set_printoptions(precision=3, suppress=True)
     probs = res["softmax"][i].astype(np.float32) / 127.0
     k = int(res["argmax"][i])
@@ -70,9 +71,10 @@ def rmse(a, b):
     return np.sqrt(np.mean((a - b) ** 2))
 
 
-def compare(data_a, data_b, name, out=sys.stdout):
+def compare(data_a, data_b, name, out=None):
     """The comparison block of kws_on_mcu.compare (:159-168), same wording and number formats."""
     dev = 100.0 * (1.0 - (data_b.ravel() + 1e-9) / (data_a.ravel() + 1e-9))
+    out = out or sys.stdout
     print('_________________________________________________________________', file=out)
     print('Comparing: %s' % (name), file=out)
     print("Deviation: max %.3f%% min %.3f%% avg %.3f%% \nrmse %.3f" % (
@@ -82,11 +84,12 @@ def compare(data_a, data_b, name, out=sys.stdout):
     print('_________________________________________________________________', file=out)
 
 
-def frame_inference(path, ctx=None, out=sys.stdout):
+def frame_inference(path, ctx=None, out=None):
     """`kws mcu file <wav>` = kws_on_mcu.frameInference (:310-401): the wav (edge-padded to 2 s) through the host
     leg (MFCC variant B) and through the board's leg -- here the GPU's variant C, i.e. the firmware's own Q15
     arithmetic -- each followed by the int8 network, then the two comparison blocks the reference prints
     (README.md:121-139 shows them for data/edison_16k_16b.wav)."""
+    out = out or sys.stdout
     from .. import _lib
     ctx = ctx or default_context()
     data = pad_or_cut(read_wav(path), mode="edge")
@@ -107,8 +110,9 @@ def frame_inference(path, ctx=None, out=sys.stdout):
     return dict(host=host, mcu=mcu, host_mfcc=host_mfcc, mcu_mfcc=mcu_mfcc)
 
 
-def single_inference(repeat=1, ctx=None, out=sys.stdout):
+def single_inference(repeat=1, ctx=None, out=None):
     """`kws mcu single [n]` = kws_on_mcu.singleInference (:236-270), nnom branch: the all-zero int8 net input."""
+    out = out or sys.stdout
     ctx = ctx or default_context()
     res = None
     for _ in range(max(1, int(repeat))):

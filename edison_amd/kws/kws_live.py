@@ -16,7 +16,8 @@ from ..stream import Fsm, Stream
 from .kws_host import read_wav
 
 
-def run(path, q15=False, ctx=None, out=sys.stdout, alpha=0.9, threshold=0.5):
+def run(path, q15=False, ctx=None, out=None, alpha=0.9, threshold=0.5):
+    out = out or sys.stdout
     ctx = ctx or default_context()
     data = read_wav(path)
     hop = cfg.frame_length
