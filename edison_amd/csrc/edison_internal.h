@@ -69,6 +69,8 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 #define ED_Q15_NLO_MAX 8
 #define ED_Q15_NHI_MAX 24
 #define ED_Q15_TAPS_MAX (ED_Q15_NLO_MAX + ED_Q15_NHI_MAX)
+#define ED_Q15_PAIRS(n) (((n) + 2) / 2)
+#define ED_Q15_PAIRS_MAX (ED_Q15_PAIRS(ED_Q15_NLO_MAX) + ED_Q15_PAIRS(ED_Q15_NHI_MAX))
 
 typedef struct {
 	/* complex Q15 coefficients as the two packed operands of v_dot2_i32_i16 (see tables_q15.c):
@@ -78,6 +80,11 @@ typedef struct {
 	uint32_t rfa[16], rfb[16]; /* real-FFT split of the DCT stage, pair 256*i of realCoefA/BQ15: (A.re,-A.im), (B.re,B.im) */
 	int32_t mel_tap[ED_Q15_TAPS_MAX][64]; /* [t][lane]: t < mel_nlo narrow-band taps, then mel_nhi wide-band taps (0 = padding) */
 	int32_t mel_lo_bin[64], mel_hi_bin[64]; /* first spectrum bin of the lane's two runs (every read stays below 513) */
+	/* the same taps as the kernel reads them: the spectrum sits in LDS as int16, a lane reads it as dwords (bins 2p,
+	 * 2p+1) from pair mel_*_pair[lane] on and multiplies with v_dot2_i32_i16 against (tap[2p] | tap[2p+1] << 16);
+	 * (n+2)/2 pairs cover n taps from an odd or even first bin, the taps outside the run are 0 */
+	uint32_t mel_tap2[ED_Q15_PAIRS_MAX][64];
+	int32_t mel_lo_pair[64], mel_hi_pair[64];
 	int32_t mel_nlo, mel_nhi;
 	int32_t mel_scale, n_mel_coef;
 	int32_t need_nyquist; /* some band reads spectrum bin 512 */

@@ -332,7 +332,8 @@ template <bool STAGES, int NLO, int NHI>
 __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(ed_mfcc_q15_args_t a, const ed_q15_tables_t *__restrict__ T)
 {
 	__shared__ u32 s_buf[EQ_WPB][EQ_BUF];
-	__shared__ int s_tap[NLO + NHI][64];
+	constexpr int NLOP = ED_Q15_PAIRS(NLO), NHIP = ED_Q15_PAIRS(NHI); /* dword reads of the int16 spectrum */
+	__shared__ u32 s_tap[NLOP + NHIP][64];
 	__shared__ int s_melb[EQ_WPB][EQ_NB * 32];
 	__shared__ u32 s_zb[EQ_WPB][EQ_NB * 16];
 	__shared__ u32 s_sqbit[1024];
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	int *melb = s_melb[w];
 	u32 *zb = s_zb[w];
 
-	for (int i = threadIdx.x; i < (NLO + NHI) * 64; i += 64 * EQ_WPB) (&s_tap[0][0])[i] = (&T->mel_tap[0][0])[i];
+	for (int i = threadIdx.x; i < (NLOP + NHIP) * 64; i += 64 * EQ_WPB) (&s_tap[0][0])[i] = (&T->mel_tap2[0][0])[i];
 	for (int i = threadIdx.x; i < 1024; i += 64 * EQ_WPB) s_sqbit[i] = T->sqbit[i];
 	__syncthreads();
 
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	__syncthreads(); /* s_tw12 was written by wave 0 */
 #endif
 	const eq_tw3 t3 = eq_load_tw(T->tw1024, T->tw1024x, 16 * j3);     /* stage 3: ic = 16 j               */
-	const int mel_lo_bin = T->mel_lo_bin[lane], mel_hi_bin = T->mel_hi_bin[lane];
+	const int mel_lo_pair = T->mel_lo_pair[lane], mel_hi_pair = T->mel_hi_pair[lane];
 	const int mel_scale = T->mel_scale;
 	const bool need_nyquist = STAGES || T->need_nyquist != 0; /* a band that reaches bin 512 (not the shipped filterbank) */
 	const int rev6 = eq_bitrev(lane, 6);
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 		eq_wave_sync();
 
 		/* ---- magnitudes: register m = X[64 bitrev4(m) + bitrev6(lane)]; bins 0..511 are the even registers */
-		int *spec = (int *)buf;
+		short *spec = (short *)buf; /* int16: the mel stage reads two bins per dword */
 		int mag[8];
 		if (EQ_ABLATE & 1)
 		{
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 #pragma unroll
 		for (int kk = 0; kk < 8; kk++)
 		{
-			spec[64 * kk + rev6] = mag[kk];
+			spec[64 * kk + rev6] = (short)mag[kk];
 			if (STAGES)
 			{
 				const int64_t k = 64 * kk + rev6;
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 			const u32 pw512 = (u32)eq_dot2<false>(e[1], e[1]);
 			int mag512;
 			if (!eq_mag_fast(pw512, mag512)) mag512 = eq_mag_fix(pw512, mag512, s_sqbit);
-			spec[512] = mag512;
+			spec[512] = (short)mag512;
 			if (STAGES && a.fft) { a.fft[((int64_t)f * 513 + 512) * 2] = (int16_t)re; a.fft[((int64_t)f * 513 + 512) * 2 + 1] = (int16_t)im; }
 			if (STAGES && a.spec) a.spec[(int64_t)f * 513 + 512] = (int16_t)mag512;
 		}
@@ -504,13 +505,17 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 
 		/* ---- compact mel matrix: lane (b, r) sums quarter r of band b and of band 31-b; 32-bit wrap-around like the MCU */
 		u32 acc_lo = 0, acc_hi = 0;
-		if (EQ_ABLATE & 4) { acc_lo = (u32)spec[mel_lo_bin]; acc_hi = (u32)spec[mel_hi_bin]; }
+		const u32 *spec2 = buf; /* the int16 spectrum, two bins per dword */
+		if (EQ_ABLATE & 4) { acc_lo = spec2[mel_lo_pair]; acc_hi = spec2[mel_hi_pair]; }
 		else
 		{
+			/* two taps per v_dot2_i32_i16 (no clamp: the same wrap-around sum); magnitudes and taps fit 16 bits */
 #pragma unroll
-			for (int t = 0; t < NLO; t++) acc_lo += (u32)__mul24(spec[mel_lo_bin + t], s_tap[t][lane]); /* both fit 16 bits */
+			for (int t = 0; t < NLOP; t++)
+				acc_lo = (u32)__builtin_amdgcn_sdot2(eq_s(spec2[mel_lo_pair + t]), eq_s(s_tap[t][lane]), (int)acc_lo, false);
 #pragma unroll
-			for (int t = 0; t < NHI; t++) acc_hi += (u32)__mul24(spec[mel_hi_bin + t], s_tap[NLO + t][lane]);
+			for (int t = 0; t < NHIP; t++)
+				acc_hi = (u32)__builtin_amdgcn_sdot2(eq_s(spec2[mel_hi_pair + t]), eq_s(s_tap[NLOP + t][lane]), (int)acc_hi, false);
 		}
 		acc_lo = eq_sum_rows(acc_lo);
 		acc_hi = eq_sum_rows(acc_hi);

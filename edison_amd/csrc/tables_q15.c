@@ -169,6 +169,24 @@ int ed_build_q15_tables(double sample_rate, double lower_edge_hertz, double uppe
 		}
 	}
 	free(W);
+	/* packed form for the kernel (see edison_internal.h) */
+	for (int l = 0; l < 64; l++)
+		for (int part = 0; part < 2; part++)
+		{
+			const int n = part == 0 ? nlo : nhi, s = part == 0 ? out->mel_lo_bin[l] : out->mel_hi_bin[l];
+			const int row0 = part == 0 ? 0 : nlo, pair0 = part == 0 ? 0 : ED_Q15_PAIRS(nlo);
+			if (part == 0) out->mel_lo_pair[l] = s >> 1; else out->mel_hi_pair[l] = s >> 1;
+			for (int tp = 0; tp < ED_Q15_PAIRS(n); tp++)
+			{
+				uint32_t v = 0;
+				for (int h = 0; h < 2; h++)
+				{
+					const int t = 2 * ((s >> 1) + tp) + h - s; /* tap index of bin 2(p0+tp)+h */
+					if (t >= 0 && t < n) v |= ((uint32_t)out->mel_tap[row0 + t][l] & 0xffffu) << (16 * h);
+				}
+				out->mel_tap2[pair0 + tp][l] = v;
+			}
+		}
 	out->mel_scale = scale;
 	out->n_mel_coef = total;
 	return EDISON_OK;
