@@ -201,12 +201,17 @@ __device__ __forceinline__ int eq_bitrev(int v, int bits) { return (int)(__built
 __device__ __forceinline__ void eq_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
 /* sum over the four 16-lane rows in every lane (wrap-around): v_permlane16_swap, then v_permlane32_swap */
-__device__ __forceinline__ u32 eq_sum_rows(u32 x)
+/* lanes 0..31: a[l] + a[l+32], lanes 32..63: b[l-32] + b[l] (a's upper half is exchanged with b's lower half) */
+__device__ __forceinline__ u32 eq_fold_halves(u32 a, u32 b)
+{
+	const auto q = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+	return q[0] + q[1];
+}
+/* every row gets the sum of its row pair (rows 0+1, rows 2+3) */
+__device__ __forceinline__ u32 eq_sum_row_pairs(u32 x)
 {
 	const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-	const u32 y = r[0] + r[1];
-	const auto q = __builtin_amdgcn_permlane32_swap(y, y, false, false);
-	return q[0] + q[1];
+	return r[0] + r[1];
 }
 
 /* First sample of frame f: (f / fpg) * group_stride + (f % fpg) * frame_step (f is wave-uniform, < 2^31). */
@@ -517,12 +522,13 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 			for (int t = 0; t < NHIP; t++)
 				acc_hi = (u32)__builtin_amdgcn_sdot2(eq_s(spec2[mel_hi_pair + t]), eq_s(s_tap[NLOP + t][lane]), (int)acc_hi, false);
 		}
-		acc_lo = eq_sum_rows(acc_lo);
-		acc_hi = eq_sum_rows(acc_hi);
-		if (lane < 32)
+		/* both sums with one v_permlane32_swap (it exchanges halves of TWO registers: lanes 0..31 then hold the
+		 * narrow band's half sums, 32..63 the wide band's), then the row pairs: rows 0,1 = band b, rows 2,3 = 31-b */
+		const u32 acc = eq_sum_row_pairs(eq_fold_halves(acc_lo, acc_hi));
+		if (!(lane & 16))
 		{
-			const int band = lane < 16 ? lane : 47 - lane; /* lanes 16..31 hold band 31 - (lane & 15) */
-			const int melv = (int)(short)((int)(lane < 16 ? acc_lo : acc_hi) / mel_scale);
+			const int band = lane < 32 ? lane : 63 - lane; /* row 0: band b = lane, row 2: band 31 - (lane & 15) */
+			const int melv = (int)(short)((int)acc / mel_scale);
 			melb[32 * slot + band] = melv;
 			if (STAGES && a.mel) a.mel[(int64_t)f * 32 + band] = (int16_t)melv;
 		}
