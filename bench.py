@@ -89,7 +89,8 @@ def hbm_traffic_from_profiles(key):
 
 def timed_region(step_fn, steps, warmup, world, settle_ms=0.0, settle_chunk=256):
     """W untimed + exactly K timed steps, barrier + synchronize on both sides; returns (wall ms/step, event ms/step).
-    settle_ms > 0: before the W warm-up steps the same step is repeated, untimed, for that long -- the board's power
+    settle_ms > 0 (only for steps WITHOUT collectives: the count differs per rank): before the W warm-up steps the
+    same step is repeated, untimed, for that long -- the board's power
     management needs ~100 ms of sustained load before its clocks stop moving; with microsecond
     steps a small W alone would time the transient."""
     if settle_ms > 0:
@@ -323,7 +324,9 @@ def main():
             ctx.kws_t(audio, nu, 31 * 1024, feat=feat, logits=logits, softmax=soft, argmax=am)
             if gather is not None:
                 gather(logits)
-        kw_ms, kev_ms = timed_region(kws_step, args.steps, min(args.warmup, 50), world, args.settle_ms, 8)  # 7 ms steps: 50 = 0.35 s of warm-up
+        # 7 ms steps: up to 50 warm-up steps = 0.35 s. No time-based settle phase here: for N > 1 the step ends in a
+        # collective, and ranks must execute the same number of steps.
+        kw_ms, kev_ms = timed_region(kws_step, args.steps, min(args.warmup, 50), world)
         inf_per_s = world * nu / (kw_ms * 1e-3)
         kach = KWS_BYTES_PER_UTT * nu / (kev_ms * 1e-3) / 1e9
         hist = torch.bincount(am.to(torch.int64), minlength=10).tolist()
