@@ -10,7 +10,9 @@ kws_keras.py:450, kws_on_mcu.py:293,343,...) can import this module in its place
   mfcc                    mfcc_utils.py:134-199   -> edison_mfcc_stages, variant A
   mfcc_mcu                mfcc_utils.py:255-323   -> edison_mfcc_stages, variant B
 
-Not mirrored: ``mfcc_tf`` (needs TensorFlow; comparison-only) and ``dct2Makhoul`` (helper of the board tools).
+  dct2Makhoul             mfcc_utils.py:324-343   (host numpy helper of the board tools: DCT-II through one FFT)
+  mfcc_tf                 mfcc_utils.py:201-253   TensorFlow's own MFCC, a comparison curve of mfcc.py only: raises
+                                                  (TensorFlow is not a dependency of this path)
 
 The GPU path is specialised for the reference's shipped geometry: 1024-sample frames and 32 mel bins
 (audio/config.py:15,19). Other values raise NotImplementedError rather than silently taking another path.
@@ -153,3 +155,23 @@ def mfcc_mcu(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, me
         frame['mfcc'] = st['mfcc'][f].astype(np.float64)
         output.append(frame)
     return output
+
+
+def dct2Makhoul(x):
+    """DCT-II of a 1-D array through one FFT of the same length (Makhoul 1980), as the board tools use it to look at
+    the firmware's dct2_q15 stage by stage (mfcc_utils.py:324-343, mfcc_on_mcu.py:370). Returns the same triple:
+    (the DCT-II = scipy.fftpack.dct(x, 2), the even/odd reordered input, its FFT)."""
+    x = np.asarray(x)
+    n = x.shape[0]
+    half = (n + 1) // 2
+    v = np.empty_like(x)
+    v[:half] = x[0::2]                       # even samples ascending ...
+    v[half:] = x[1::2][::-1]                 # ... then the odd ones descending
+    V = np.fft.fft(v)
+    twiddle = 2.0 * np.exp(-1j * np.pi * np.arange(n) / (2.0 * n))
+    return (V * twiddle).real, v, V
+
+
+def mfcc_tf(*args, **kwargs):
+    """tf.signal's MFCC (mfcc_utils.py:201-253): only a comparison curve in mfcc.py, needs TensorFlow."""
+    raise NotImplementedError("mfcc_tf needs TensorFlow, which this path does not depend on; use mfcc() / mfcc_mcu()")

@@ -324,3 +324,17 @@ def test_mfcc_lane_tables_hold_the_whole_filterbank(built_lib, mfcc_golden, vari
     ref = mfcc_golden["mel_W512" if nbins == 512 else "mel_W513"] * scale
     np.testing.assert_allclose(W[:nbins], ref, rtol=2e-7, atol=1e-12)
     assert not W[nbins:].any()
+
+
+def test_dct2_makhoul_helper_and_tf_stub():
+    """mfcc_utils.dct2Makhoul (mfcc_utils.py:324-343) = scipy's DCT-II, with the reordered input and its FFT."""
+    from scipy.fftpack import dct
+    from edison_amd.mfcc import mfcc_utils as mfu
+    rng = np.random.default_rng(5)
+    for n in (32, 31, 2, 1):
+        x = rng.normal(size=n)
+        d, v, V = mfu.dct2Makhoul(x)
+        np.testing.assert_allclose(d, dct(x, 2), rtol=1e-12, atol=1e-12)
+        assert sorted(v.tolist()) == sorted(x.tolist()) and np.allclose(V, np.fft.fft(v))
+    with pytest.raises(NotImplementedError):
+        mfu.mfcc_tf(np.zeros(1024), 16000)
