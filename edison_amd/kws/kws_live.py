@@ -16,6 +16,17 @@ from ..stream import Fsm, Stream
 from .kws_host import read_wav
 
 
+def netOutFilt(net_outs, alpha):
+    """The host-side moving average of the reference's live view (kws_live.py:139-152): row 0 is all zeros, row i+1 =
+    alpha * row i + (1 - alpha) * net_outs[i], in float64 like the reference's Python floats. (The firmware's own
+    filter -- float32 state, double arithmetic, app.c:332-356 -- is the stream's `output_filter` option.)"""
+    x = np.asarray(net_outs, dtype=np.float64)
+    flt = np.zeros((x.shape[0] + 1, x.shape[1]), dtype=np.float64)
+    for i in range(x.shape[0]):
+        flt[i + 1] = alpha * flt[i] + (1.0 - alpha) * x[i]
+    return flt
+
+
 def run(path, q15=False, ctx=None, out=None, alpha=0.9, threshold=0.5):
     out = out or sys.stdout
     ctx = ctx or default_context()

@@ -338,3 +338,15 @@ def test_dct2_makhoul_helper_and_tf_stub():
         assert sorted(v.tolist()) == sorted(x.tolist()) and np.allclose(V, np.fft.fft(v))
     with pytest.raises(NotImplementedError):
         mfu.mfcc_tf(np.zeros(1024), 16000)
+
+
+def test_net_out_filt_mirror():
+    """kws_live.netOutFilt (kws_live.py:139-152): same recurrence, same leading zero row, float64."""
+    from edison_amd.kws import kws_live
+    rng = np.random.default_rng(6)
+    outs = rng.uniform(0, 1, (40, 10)).tolist()
+    got = kws_live.netOutFilt(outs, 0.9)
+    ref = [10 * [0]]
+    for o in outs:                                        # the reference's loop, element by element
+        ref.append([0.9 * ref[-1][i] + (1.0 - 0.9) * o[i] for i in range(10)])
+    assert got.shape == (41, 10) and np.array_equal(got, np.array(ref))
