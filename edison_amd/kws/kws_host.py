@@ -121,6 +121,20 @@ def single_inference(repeat=1, ctx=None, out=None):
     return res
 
 
+# the reference's own function names and call conventions (kws_on_mcu.py:243,273,310: `args` = the CLI's remaining
+# arguments, args[0] = the wav file)
+def singleInference(repeat=1):
+    return single_inference(repeat)
+
+
+def fileInference(args):
+    return file_inference(args[0])
+
+
+def frameInference(args):
+    return frame_inference(args[0])
+
+
 def main(argv):
     """``kws mcu <mode> [file]`` of the reference's CLI (main.py:146-165, kws_on_mcu.py:650-690). The modes that record
     from a microphone (mic, host, hostcont, hostsingle, miccont) are not part of this port."""
