@@ -99,6 +99,7 @@ SIGNATURES = {
     "edison_fsm_step": (c_int, [ctypes.POINTER(Fsm), c_float, ctypes.c_uint32, ctypes.c_uint32, c_double]),
     # legacy firmware call surface
     "aiInitialize": (c_int, []),
+    "aiPrintInfo": (None, []),
     "aiGetInputShape": (None, [ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint16)]),
     "aiRunInference": (c_int, [c_void_p, c_void_p]),
     "aiGetKeywordFromIndex": (c_char_p, [ctypes.c_uint32]),

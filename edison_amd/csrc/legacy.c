@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/edison_hip.h"
 
@@ -27,6 +28,7 @@ static const char *const g_keywords[EDISON_NET_OUT] = {"edison", "cinema", "bedr
 static edison_ctx *g_ctx = NULL;
 static int8_t g_net_in[EDISON_NET_IN];   /* nnom_input_data[403] (weights.h:136) and app.c's netInput */
 static int8_t g_net_out[EDISON_NET_OUT]; /* nnom_output_data[10] (weights.h:137)                      */
+static uint32_t g_last_inference_us;     /* lastInferenceTimeUs (ai.c:86)                             */
 
 #define NNOM_INPUT_SCALE 1 /* weights.h:162-164 */
 #define NNOM_INPUT_MIN (-128)
@@ -90,10 +92,38 @@ int aiNnomRunInference(void *in_data, void *out_data)
 		if (r != EDISON_OK) return r;
 	}
 	memcpy(g_net_in, in_data, sizeof(g_net_in)); /* ai_nnom.c:74 */
+	struct timespec t0, t1; /* utilTic / utilToc around the inference (ai.c:233-239) */
+	clock_gettime(CLOCK_MONOTONIC, &t0);
 	int r = edison_cnn_batch(g_ctx, g_net_in, 1, NULL, g_net_out, NULL);
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	g_last_inference_us = (uint32_t)((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000L);
 	if (r != EDISON_OK) return r;
 	memcpy(out_data, g_net_out, sizeof(g_net_out)); /* ai_nnom.c:80 */
 	return EDISON_OK;
+}
+
+/* ai.c:189-196,261-267: the net's description and the duration of the last inference, on stdout */
+void aiPrintInfo(void)
+{
+	printf("-------------------------------------------------------------\n");
+	printf("AI net information\n");
+	edison_net_info info;
+	if (g_ctx && edison_net_get_info(g_ctx, &info) == EDISON_OK)
+	{
+		printf(" NNoM int8 graph on the GPU: input (%d, %d, %d), %d compute layers, %d outputs%s\n", info.in_h, info.in_w,
+		       info.in_c, info.n_layers, info.n_out, info.accelerated ? ", kws_conv on the matrix cores" : ", general kernel");
+		for (int i = 0; i < info.n_layers; i++)
+		{
+			edison_net_layer_info_t li;
+			static const char *const names[5] = {"?", "Conv2D", "MaxPool", "Dense", "Softmax"};
+			if (edison_net_layer_info(g_ctx, i, &li) != EDISON_OK) break;
+			printf("  #%d %-8s -> (%d, %d, %d)%s\n", i + 1, names[li.type >= 1 && li.type <= 4 ? li.type : 0], li.out_h, li.out_w, li.out_c,
+			       li.relu ? " ReLU" : "");
+		}
+	}
+	else
+		printf(" no model loaded (aiInitialize)\n");
+	printf("\n\n last inference time: %.2fms\n", (float)g_last_inference_us / 1000.0);
 }
 
 int aiRunInference(void *in_data, void *out_data) { return aiNnomRunInference(in_data, out_data); }

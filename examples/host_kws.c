@@ -53,5 +53,6 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	printf("batched:        %s (%d/127)\n", aiGetKeywordFromIndex((uint32_t)am), soft[am]);
+	aiPrintInfo(); /* the net's description and the last inference time, as the firmware prints them (ai.c:189-196) */
 	return best == am ? 0 : 3;
 }

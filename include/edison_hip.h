@@ -277,6 +277,7 @@ int edison_fsm_step(edison_fsm *f, float pred_max, uint32_t pred_idx, uint32_t d
 /* firmware/src/ai/ai.h:74-80. aiInitialize() creates the global context on device $EDISON_DEVICE (default 0)
  * and loads $EDISON_MODEL (default: kws_nnom.ednn next to the library). in_data: 403 int8, out_data: 10 int8. */
 int aiInitialize(void);
+void aiPrintInfo(void);
 void aiGetInputShape(uint16_t *x, uint16_t *y);
 int aiRunInference(void *in_data, void *out_data);
 const char *aiGetKeywordFromIndex(uint32_t idx);

@@ -373,3 +373,4 @@ def test_c_program_links_against_the_abi(built_lib, ctx, kws_golden, tmp_path):
     out = subprocess.run([exe, pcm], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "firmware-style: edison" in out.stdout and "batched:        edison" in out.stdout
+    assert "AI net information" in out.stdout and "last inference time:" in out.stdout and "#8 Softmax" in out.stdout
