@@ -105,6 +105,8 @@ SIGNATURES = {
     "aiGetKeywordFromIndex": (c_char_p, [ctypes.c_uint32]),
     "aiGetKeywordCount": (ctypes.c_uint32, []),
     "aiNnomInit": (None, []),
+    "aiNnomTest": (None, []),
+    "aiNnomPrintInfo": (None, []),
     "aiNnomRunInference": (c_int, [c_void_p, c_void_p]),
     "aiNnomPredict": (c_int, [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(c_float)]),
     "aiNnomGetInputBuffer": (c_void_p, []),
@@ -116,6 +118,7 @@ SIGNATURES = {
     "mfcc_create": (c_void_p, [c_int, c_int, c_int, c_int, c_float]),
     "mfcc_delete": (None, [c_void_p]),
     "mfcc_compute": (None, [c_void_p, c_void_p, c_void_p]),
+    "create_dct_matrix": (c_void_p, [ctypes.c_int32, ctypes.c_int32]),
     "edison_mfcc_f32_create": (c_void_p, [c_void_p, c_int, c_int, c_int, c_int, c_float]),
     "edison_mfcc_f32_n_out": (c_int, [c_void_p]),
     "edison_mfcc_f32_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -102,11 +102,9 @@ int aiNnomRunInference(void *in_data, void *out_data)
 	return EDISON_OK;
 }
 
-/* ai.c:189-196,261-267: the net's description and the duration of the last inference, on stdout */
-void aiPrintInfo(void)
+/* ai_nnom.h:7 (the firmware prints NNoM's model_stat table): the loaded graph, layer by layer */
+void aiNnomPrintInfo(void)
 {
-	printf("-------------------------------------------------------------\n");
-	printf("AI net information\n");
 	edison_net_info info;
 	if (g_ctx && edison_net_get_info(g_ctx, &info) == EDISON_OK)
 	{
@@ -123,7 +121,23 @@ void aiPrintInfo(void)
 	}
 	else
 		printf(" no model loaded (aiInitialize)\n");
+}
+
+/* ai.c:189-196,261-267: the net's description and the duration of the last inference, on stdout */
+void aiPrintInfo(void)
+{
+	printf("-------------------------------------------------------------\n");
+	printf("AI net information\n");
+	aiNnomPrintInfo();
 	printf("\n\n last inference time: %.2fms\n", (float)g_last_inference_us / 1000.0);
+}
+
+/* ai_nnom.c:50-56 (NNOM_VERIFICATION): create the model and run it once on whatever the input buffer holds */
+void aiNnomTest(void)
+{
+	int8_t out[EDISON_NET_OUT];
+	if (!g_ctx && aiInitialize() != EDISON_OK) return;
+	(void)aiNnomRunInference(g_net_in, out);
 }
 
 int aiRunInference(void *in_data, void *out_data) { return aiNnomRunInference(in_data, out_data); }

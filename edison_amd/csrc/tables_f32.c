@@ -8,6 +8,7 @@
  */
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/edison_hip.h"
@@ -72,10 +73,22 @@ int ed_build_f32_tables(int num_mfcc_features, int feature_offset, int frame_len
 		}
 		out->mel_first[b] = first; out->mel_last[b] = last;
 	}
-	const float normalizer = sqrtf(2.0f / (float)ED_F32_NUM_FBANK);
-	for (int k = 0; k < num_mfcc_features; k++)
-		for (int n = 0; n < ED_F32_NUM_FBANK; n++)
-			out->dct[k * ED_F32_NUM_FBANK + n] =
-			    normalizer * cosf(((float)3.14159265358979323846264338327950288) / ED_F32_NUM_FBANK * (n + 0.5f) * k);
+	float *dct = create_dct_matrix(ED_F32_NUM_FBANK, num_mfcc_features);
+	if (!dct) return EDISON_E_NO_MEMORY;
+	memcpy(out->dct, dct, sizeof(float) * ED_F32_NUM_FBANK * (size_t)num_mfcc_features);
+	free(dct);
 	return EDISON_OK;
+}
+
+/* mfcc.c:101-115 under its own name: M[k][n] = sqrt(2/N) cos(pi/N (n + 1/2) k), all in float32 */
+float *create_dct_matrix(int32_t input_length, int32_t coefficient_count)
+{
+	if (input_length < 1 || coefficient_count < 1) return NULL;
+	float *m = (float *)malloc(sizeof(float) * (size_t)input_length * (size_t)coefficient_count);
+	if (!m) return NULL;
+	const float normalizer = sqrtf(2.0f / (float)input_length);
+	for (int32_t k = 0; k < coefficient_count; k++)
+		for (int32_t n = 0; n < input_length; n++)
+			m[k * input_length + n] = normalizer * cosf(((float)3.14159265358979323846264338327950288) / input_length * (n + 0.5f) * k);
+	return m;
 }

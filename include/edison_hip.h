@@ -283,7 +283,9 @@ int aiRunInference(void *in_data, void *out_data);
 const char *aiGetKeywordFromIndex(uint32_t idx);
 uint32_t aiGetKeywordCount(void);
 /* firmware/src/ai/ai_nnom.c:64-132 */
+void aiNnomTest(void);
 void aiNnomInit(void);
+void aiNnomPrintInfo(void);
 int aiNnomRunInference(void *in_data, void *out_data);
 int aiNnomPredict(uint32_t *label, float *prob);
 int8_t *aiNnomGetInputBuffer(void);
@@ -308,6 +310,8 @@ typedef struct _mfcc_t mfcc_t;
 mfcc_t *mfcc_create(int num_mfcc_features, int feature_offset, int frame_len, int mfcc_dec_bits, float preemph);
 void mfcc_delete(mfcc_t *mfcc);
 void mfcc_compute(mfcc_t *mfcc, const int16_t *audio_data, int8_t *mfcc_out);
+/* mfcc.h:61, mfcc.c:101-115: the DCT-II matrix of that extractor, float32, [coefficient][input], malloc'd (host) */
+float *create_dct_matrix(int32_t input_length, int32_t coefficient_count);
 /* the same on an explicit context, and batched: frame i starts at audio + i*frame_step; out [n][n_out] q7,
  * out_f32 [n][n_out] (the scaled sums before round/saturate) and logmel [n][26] may be NULL */
 mfcc_t *edison_mfcc_f32_create(edison_ctx *ctx, int num_mfcc_features, int feature_offset, int frame_len,

@@ -350,3 +350,15 @@ def test_net_out_filt_mirror():
     for o in outs:                                        # the reference's loop, element by element
         ref.append([0.9 * ref[-1][i] + (1.0 - 0.9) * o[i] for i in range(10)])
     assert got.shape == (41, 10) and np.array_equal(got, np.array(ref))
+
+
+def test_create_dct_matrix_host(built_lib):
+    """create_dct_matrix (firmware/src/audio/mfcc.h:61, mfcc.c:101-115): sqrt(2/N) cos(pi/N (n + 1/2) k) in float32."""
+    built_lib.create_dct_matrix.restype = ctypes.POINTER(ctypes.c_float)
+    built_lib.create_dct_matrix.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    p = built_lib.create_dct_matrix(26, 13)
+    m = np.ctypeslib.as_array(p, shape=(13, 26)).copy()
+    ctypes.CDLL(None).free(p)
+    k, n = np.arange(13)[:, None], np.arange(26)[None, :]
+    np.testing.assert_allclose(m, np.sqrt(2.0 / 26) * np.cos(np.pi / 26 * (n + 0.5) * k), rtol=0, atol=3e-7)
+    assert not built_lib.create_dct_matrix(0, 3)
