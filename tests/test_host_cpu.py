@@ -359,6 +359,9 @@ def test_create_dct_matrix_host(built_lib):
     p = built_lib.create_dct_matrix(26, 13)
     m = np.ctypeslib.as_array(p, shape=(13, 26)).copy()
     ctypes.CDLL(None).free(p)
-    k, n = np.arange(13)[:, None], np.arange(26)[None, :]
-    np.testing.assert_allclose(m, np.sqrt(2.0 / 26) * np.cos(np.pi / 26 * (n + 0.5) * k), rtol=0, atol=3e-7)
+    k, n = np.arange(13, dtype=np.float32)[:, None], np.arange(26, dtype=np.float32)[None, :]
+    f = np.float32
+    ang = f(np.pi) / f(26) * (n + f(0.5)) * k                                 # the firmware's float32 operation order
+    np.testing.assert_allclose(m, np.sqrt(f(2.0) / f(26)) * np.cos(ang), rtol=0, atol=2e-7)
+    np.testing.assert_allclose(m, np.sqrt(2.0 / 26) * np.cos(np.pi / 26 * (n.astype(float) + 0.5) * k), rtol=0, atol=2e-6)
     assert not built_lib.create_dct_matrix(0, 3)
