@@ -225,7 +225,7 @@ __global__ __launch_bounds__(EN_THREADS) void ed_net_kernel(const ed_net_plan_t 
 			int8_t *o = en_lds + L.out_buf;
 			if (L.type == ED_NET_CONV)
 			{
-				const bool padded = (L.pad_h | L.pad_w) != 0; /* VALID layers need no tap tests */
+				const bool padded = L.check_taps != 0; /* windows that stay inside the image need no tap tests */
 				const bool c4 = (L.in_c & 3) == 0;
 				if ((L.out_c & 3) == 0)
 				{

@@ -209,7 +209,9 @@ typedef struct {
 	int32_t in_buf, out_buf; /* LDS byte offsets                                                             */
 	int32_t in_n, out_n;     /* elements                                                                     */
 	int32_t acts_off; /* offset of the layer's output inside one utterance's activation dump                  */
-	int32_t pad_[2];
+	int32_t check_taps; /* some window reaches outside the image: padding, or SAME with an even kernel / stride (the
+	                     * output is ceil(in/stride) wide, so the last windows overhang the right / bottom edge)   */
+	int32_t pad_;
 } ed_net_layer_t;
 
 typedef struct {

@@ -80,6 +80,8 @@ int ed_plan_net(const void *blob, size_t blob_bytes, ed_net_plan_t *plan, int8_t
 			L->out_w = same ? ceil_div(w, L->sw) : ceil_div(w - L->kw + 1, L->sw);
 			if (L->out_h < 1 || L->out_w < 1)
 			{ rc = fail(err, err_cap, EDISON_E_SIZE, "layer %d: kernel larger than its %d-row input", i, h); break; }
+			L->check_taps = L->pad_h > 0 || L->pad_w > 0 || (L->out_h - 1) * L->sh - L->pad_h + L->kh > h ||
+			                (L->out_w - 1) * L->sw - L->pad_w + L->kw > w;
 			const int square_in = h == w;
 			if (v[0] == ED_NET_CONV)
 			{

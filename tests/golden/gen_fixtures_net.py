@@ -53,6 +53,10 @@ MODELS = {
     # filters and 32-wide Dense layers instead of 186 / 128, to keep the committed header small
     "low_latency_small": ((31, 13, 1), [("conv", 10, (8, 31), (1, 4), "SAME", 1), ("flatten",), ("dense", 32, 0),
                                         ("dense", 32, 0), ("dense", 10, 0), ("softmax",)]),
+    # SAME padding whose pad is 0 (kernel extent 1 or 2) but whose last windows still overhang the right / bottom edge,
+    # because the output is ceil(in/stride) wide: a graph tools/fuzz_net.py found the kernel wrong on
+    "even_same": ((4, 20, 4), [("conv", 3, (2, 3), (2, 1), "SAME", 0), ("conv", 1, (1, 2), (1, 1), "SAME", 1),
+                               ("pool", (2, 2), (1, 1), "VALID"), ("softmax",)]),
 }
 
 

@@ -153,7 +153,7 @@ def test_softmax_saturation_cases(oracle_mod, oracle_model, cnn_golden):
     assert cnn_golden["softmax"][i][d.argmin()] == 0
 
 
-@pytest.mark.parametrize("name", ["same_stride", "odd_no_softmax", "square", "kws_small", "tiny_conv", "low_latency_small"])
+@pytest.mark.parametrize("name", ["same_stride", "odd_no_softmax", "square", "kws_small", "tiny_conv", "low_latency_small", "even_same"])
 def test_net_restatement_matches_reference_nnom(name):
     """oracle/net_ref.py (any sequential NNoM graph) against layer outputs of the reference's own NNoM 0.3.0 + CMSIS-NN
     compiled around six other generated model headers (tests/golden/gen_fixtures_net.py), through the importer."""
