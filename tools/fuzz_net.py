@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random sequential int8 graphs through the general network kernel against oracle/net_ref.py (which is pinned to
 the reference's NNoM on six graphs): shapes, kernels, strides, paddings and channel counts the fixtures do not hold.
-Graphs the planner refuses (reference quirks, LDS budget) are counted and skipped.   usage (box): tools/fuzz_net.py [n]"""
+Graphs the planner refuses (reference quirks, LDS budget) are counted and skipped.   usage (box): tools/fuzz_net.py [n_graphs [seed]]"""
 import os
 import sys
 
@@ -54,7 +54,7 @@ def random_graph(rng):
 
 def main():
     n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
     ctx = Context(0, model_path=None)
     ran = refused = 0
     while ran + refused < n_graphs:
