@@ -483,7 +483,7 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
  */
 typedef float ed_f2 __attribute__((ext_vector_type(2)));
 #ifndef ED2_WPB
-#define ED2_WPB 4
+#define ED2_WPB 12  /* wavefronts per workgroup = per CU: 3 per SIMD (150 VGPRs, 116 KB LDS) */
 #endif
 #define ED2_S_OFF 1088    /* float offset of the interleaved spectra: their zero padding lies beyond the 2104 transpose floats */
 #define ED2_L_OFF 2128
@@ -495,6 +495,48 @@ typedef float ed_f2 __attribute__((ext_vector_type(2)));
 #endif
 #ifndef ED2_MEL_SWAP
 #define ED2_MEL_SWAP 1
+#endif
+/* timing-only ablations by phase (tools/lab; results are WRONG when non-zero): 1 transpose 1, 2 transpose 2, 4 the three
+ * radix-8 passes and their twiddles, 8 ds_bpermute, 16 sqrt, 32 mel reads + fma, 64 split arithmetic, 128 spectrum
+ * write, 256 int16 -> float conversion */
+#ifndef ED2_SKIP
+#define ED2_SKIP 0
+#endif
+#ifndef ED2_T1_LDS
+#define ED2_T1_LDS 0      /* 1: transpose 1 through LDS as well (ds_write/read_b128) instead of VALU swaps + DPP */
+#endif
+#ifndef ED2_TW_LDS
+#define ED2_TW_LDS 0      /* 1: pass-1/2 twiddles read from LDS (14 ds_read_b64 per pair) instead of 28 registers */
+#endif
+#define ED2_TWTAB_FLOATS (ED2_TW_LDS ? 2 * 7 * 64 * 2 : 0)
+#ifndef ED2_UNPACK_SB
+#define ED2_UNPACK_SB 0   /* 1: scheduling barrier between the unpack and the next pair's loads */
+#endif
+
+/* Diagnostic build only (-DED2_STAMP=1, tools/lab): s_memtime stamps at the phase boundaries of ed_mfcc2_kernel; per-wave
+ * cycle sums per phase go to a debug buffer that nothing else reads. The product build contains no stamp. */
+#ifndef ED2_STAMP
+#define ED2_STAMP 0
+#endif
+#if ED2_STAMP
+#define ED2_NPH 17
+__device__ unsigned long long *g_ed2_dbg = nullptr;
+extern "C" void ed_set_debug_buffer(void *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ed2_dbg), &p, sizeof(p)); }
+__device__ __forceinline__ unsigned long long ed2_now()
+{
+	unsigned long long t;
+	__builtin_amdgcn_sched_barrier(0);
+	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+	__builtin_amdgcn_sched_barrier(0);
+	return t;
+}
+#if ED2_STAMP == 1
+#define ED2_ST(i) { const unsigned long long n_ = ed2_now(); ph[i] += n_ - tlast; tlast = n_; }
+#else /* 2: only the loop as a whole (clock, fixed cost per launch) */
+#define ED2_ST(i)
+#endif
+#else
+#define ED2_ST(i)
 #endif
 
 /* NOT (ed_f2)(a, b): in C++ that is a cast of the comma expression, i.e. a splat of b */
@@ -567,8 +609,42 @@ __device__ __forceinline__ float ed_fold_rows(float a, float b)
 	return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <bool ALIGNED, int NLO, int NHI>
-__global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
+/* The two frames of pair `pr`: A = 2 pr, B = 2 pr + 1 (the last pair of an odd batch repeats A). PLAIN: one group, frame f
+ * starts at f * frame_step; otherwise f = (g, i) with ONE division per pair, B follows A by increment. */
+template <bool PLAIN>
+__device__ __forceinline__ void ed_pair_ptrs(const ed_mfcc_args_t &a, uint32_t pr, const int16_t *&pa, const int16_t *&pb)
+{
+	const uint32_t fA = 2 * pr;
+	const bool haveB = fA + 1 < (uint32_t)a.n_frames;
+	if (PLAIN)
+	{
+		pa = a.audio + (int64_t)fA * a.frame_step;
+		pb = haveB ? pa + a.frame_step : pa;
+	}
+	else
+	{
+		const uint32_t fpg = (uint32_t)a.frames_per_group;
+		const uint32_t g = fA / fpg, i = fA - g * fpg;
+		pa = a.audio + ((int64_t)g * a.group_stride + (int64_t)i * a.frame_step);
+		pb = !haveB ? pa : (i + 1 < fpg ? pa + a.frame_step : a.audio + (int64_t)(g + 1) * a.group_stride);
+	}
+}
+
+/*
+ * Work distribution. One workgroup of ED2_WPB wavefronts per CU owns a contiguous slice of the frame pairs and hands
+ * them to its waves through a counter in LDS (ds_add_rtn_u32): a wave that runs faster simply draws more pairs. With a
+ * static stride per wave the kernel drained unevenly -- the SIMD arbitrates VALU issue by age, so the waves of the
+ * workgroups dispatched first ran their pairs in 3.0 us each, the youngest third in 4.6 us, and the last 25 % of the
+ * launch ran with a third of the waves (profiles/r02_mfcc_timeline.txt). The draw for the pair after next is issued at
+ * the top of an iteration and read at its end, so the LDS round trip is never waited for.
+ */
+#ifdef ED2_WAVES_PER_EU
+#define ED2_OCC __attribute__((amdgpu_waves_per_eu(ED2_WAVES_PER_EU, ED2_WAVES_PER_EU)))
+#else
+#define ED2_OCC
+#endif
+template <bool ALIGNED, bool PLAIN, int NLO, int NHI>
+__global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
 {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	const int lane = threadIdx.x & 63;
@@ -576,32 +652,41 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 	const float4 *dctl = reinterpret_cast<const float4 *>(smem);                     /* [2][64] x 4 coefficients */
 	const float2 *tpl = reinterpret_cast<const float2 *>(smem + 512);                /* [4][64] split twiddles   */
 	const float4 *melw4 = reinterpret_cast<const float4 *>(smem + ED_FIXTAB_FLOATS); /* [NLO+NHI][64] quads      */
-	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + wave * ED2_XBUF_FLOATS; /* wave-private          */
+	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_TWTAB_FLOATS + wave * ED2_XBUF_FLOATS; /* wave-private */
+	unsigned *queue = reinterpret_cast<unsigned *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_TWTAB_FLOATS + ED2_WPB * ED2_XBUF_FLOATS);
+#if ED2_STAMP
+	unsigned long long rt_entry;
+	asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_entry) :: "memory");
+#endif
 
-	/* frame pair p of this wave: frames 2p (A) and 2p+1 (B; the last pair of an odd batch repeats A and drops B) */
+	/* this workgroup's slice of the pairs; slots 0..WPB-1 and WPB..2WPB-1 of it are the waves' first two pairs */
 	const uint32_t n_frames = (uint32_t)args.n_frames;
 	const uint32_t n_pairs = (n_frames + 1) >> 1;
-	const uint32_t stride = gridDim.x * ED2_WPB;
-	uint32_t p = blockIdx.x * ED2_WPB + wave;
+	const uint32_t s0 = (uint32_t)(((uint64_t)blockIdx.x * n_pairs) / gridDim.x);
+	const uint32_t cnt = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_pairs) / gridDim.x) - s0;
+	uint32_t i_cur = wave, i_next = wave + ED2_WPB;
 	uint32_t rawA[8], rawB[8];
-	if (p < n_pairs)
+	if (i_cur < cnt)
 	{
-		const uint32_t fb = 2 * p + 1 < n_frames ? 2 * p + 1 : 2 * p;
-		ed_load_frame<ALIGNED>(ed_frame_ptr(args, 2 * p), lane, rawA);
-		ed_load_frame<ALIGNED>(ed_frame_ptr(args, fb), lane, rawB);
+		const int16_t *pa, *pb;
+		ed_pair_ptrs<PLAIN>(args, s0 + i_cur, pa, pb);
+		ed_load_frame<ALIGNED>(pa, lane, rawA);
+		ed_load_frame<ALIGNED>(pb, lane, rawB);
 	}
+	/* every table load of the prologue goes in flight before the first wait */
+#if ED2_TW_LDS
+	/* per-lane twiddle tables [q - 1][lane] as float2, conflict-free ds_read_b64 */
+	const float2 *tw1l = reinterpret_cast<const float2 *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256) + lane;
+	const float2 *tw2l = tw1l + 7 * 64;
 	{
-		const float4 *src = reinterpret_cast<const float4 *>(&tab->dct4[0][0][0]);
-		float4 *dst = reinterpret_cast<float4 *>(smem);
-		for (int t = threadIdx.x; t < (ED_FIXTAB_FLOATS + (NLO + NHI) * 256) / 4; t += blockDim.x)
+		float2 *dst = reinterpret_cast<float2 *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256);
+		for (int t = threadIdx.x; t < 7 * 64; t += 64 * ED2_WPB)
 		{
-			float4 v = src[t];
-			/* lanes with mel_half = 1 read the two 16-byte halves of a spectrum quad in the opposite order (see the mel
-			 * stage), so their weight quads are stored (z, w, x, y); ED_FIXTAB_FLOATS / 4 is a multiple of 64 */
-			if (ED2_MEL_SWAP && t >= ED_FIXTAB_FLOATS / 4 && tab->mel_half[t & 63]) v = make_float4(v.z, v.w, v.x, v.y);
-			dst[t] = v;
+			dst[t] = *reinterpret_cast<const float2 *>(&tab->tw1[1 + t / 64][t & 63][0]);
+			dst[7 * 64 + t] = *reinterpret_cast<const float2 *>(&tab->tw2[1 + t / 64][t & 63][0]);
 		}
 	}
+#else
 	float t1r[8], t1i[8], t2r[8], t2i[8];
 #pragma unroll
 	for (int q = 1; q < 8; q++)
@@ -610,15 +695,32 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 		const float2 b = *reinterpret_cast<const float2 *>(&tab->tw2[q][lane][0]);
 		t1r[q] = a.x; t1i[q] = a.y; t2r[q] = b.x; t2i[q] = b.y;
 	}
-	__syncthreads();
+#endif
 	const int mel_slo4 = tab->mel_slo4[lane], mel_shi4 = tab->mel_shi4[lane];
 	const int band = tab->mel_band[lane]; /* this column's narrow band b; its wide band is 31 - b */
 	const int mel_half = tab->mel_half[lane];
+	const float log_offset = tab->log_offset;
+	const bool do_log = tab->always_log || args.use_log;
+	{
+		const float4 *src = reinterpret_cast<const float4 *>(&tab->dct4[0][0][0]);
+		float4 *dst = reinterpret_cast<float4 *>(smem);
+		constexpr int n4 = (ED_FIXTAB_FLOATS + (NLO + NHI) * 256) / 4;
+		/* lanes with mel_half = 1 read the two 16-byte halves of a spectrum quad in the opposite order (see the mel
+		 * stage), so their weight quads are stored (z, w, x, y); quad t belongs to lane t & 63 (ED_FIXTAB_FLOATS / 4 is
+		 * a multiple of 64) and threadIdx.x + k * blockDim.x keeps that lane: the flag is this thread's own mel_half */
+		static_assert((64 * ED2_WPB) % 64 == 0 && (ED_FIXTAB_FLOATS / 4) % 64 == 0, "weight quad <-> lane mapping");
+		for (int t = threadIdx.x; t < n4; t += 64 * ED2_WPB)
+		{
+			float4 v = src[t];
+			if (ED2_MEL_SWAP && t >= ED_FIXTAB_FLOATS / 4 && mel_half) v = make_float4(v.z, v.w, v.x, v.y);
+			dst[t] = v;
+		}
+		if (threadIdx.x == 0) *queue = 2 * ED2_WPB;
+	}
+	__syncthreads();
 	/* where this lane puts its DCT input (float index into Lb2 = float2 u[16] | v[16]): rows 0/1 hold frame A's
 	 * u/v of the column's band, rows 2/3 frame B's */
 	const int l_idx = 2 * (16 * ((lane >> 4) & 1) + band) + (lane >> 5);
-	const float log_offset = tab->log_offset;
-	const bool do_log = tab->always_log || args.use_log;
 	const int k0 = ED_K0(lane);
 	const int k0p = (64 - k0) & 63;
 	const int pull = (ED_T2_LDS ? k0p : (((k0p & 7) << 3) | (k0p >> 3))) << 2;
@@ -627,27 +729,39 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 	ed_f2 *S2 = reinterpret_cast<ed_f2 *>(xbuf + ED2_S_OFF);
 	if (lane < 3) S2[513 + lane] = ed_splat(0.0f);
 
-	for (; p < n_pairs; p += stride)
+#if ED2_STAMP
+	unsigned long long ph[ED2_NPH];
+	for (int i_ = 0; i_ < ED2_NPH; i_++) ph[i_] = 0;
+	unsigned long long rt0, rt1;
+	asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) :: "memory");
+	const unsigned long long tfirst = ed2_now();
+	unsigned long long tlast = tfirst;
+#endif
+	while (i_cur < cnt)
 	{
-		const uint32_t fA = 2 * p;
+		const uint32_t fA = 2 * (s0 + i_cur);
 		const bool haveB = fA + 1 < n_frames;
-		/* ---- 1. unpack both frames, put the next pair's loads in flight */
+		/* ---- 1. unpack both frames, put the next pair's loads in flight, draw the pair after next */
 		ed_f2 re[8], im[8];
 #pragma unroll
 		for (int a = 0; a < 8; a++)
 		{
 			re[a] = ed_mk2((float)(int16_t)(rawA[a] & 0xffffu), (float)(int16_t)(rawB[a] & 0xffffu));
 			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
+			if (ED2_SKIP & 256) { re[a] = ed_mk2(__uint_as_float(rawA[a]), __uint_as_float(rawB[a])); im[a] = re[a]; }
 		}
+		if (ED2_UNPACK_SB) __builtin_amdgcn_sched_barrier(0);
 		if (!(ED2_ABLATE & 1))
 		{
 			/* unconditional: a conditional load makes the frame registers a merge of two definitions and costs 16
-			 * copies per iteration; the last iteration of a wave re-reads the batch's last pair instead (L2 hits) */
-			const uint32_t np = p + stride < n_pairs ? p + stride : n_pairs - 1;
-			const uint32_t na = 2 * np, nb = na + 1 < n_frames ? na + 1 : na;
-			ed_load_frame<ALIGNED>(ed_frame_ptr(args, na), lane, rawA);
-			ed_load_frame<ALIGNED>(ed_frame_ptr(args, nb), lane, rawB);
+			 * copies per iteration; a wave's last iteration re-reads the slice's last pair instead (L2 hits) */
+			const int16_t *pa, *pb;
+			ed_pair_ptrs<PLAIN>(args, s0 + (i_next < cnt ? i_next : cnt - 1), pa, pb);
+			ed_load_frame<ALIGNED>(pa, lane, rawA);
+			ed_load_frame<ALIGNED>(pb, lane, rawB);
 		}
+		uint32_t drawn = 0;
+		if (lane == 0) drawn = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		if (ED2_ABLATE & 1)
 		{
 #pragma unroll
@@ -663,60 +777,100 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 				args.mfcc[(int64_t)fA * args.n_coef + lane] = acc.x;
 				if (haveB) args.mfcc[(int64_t)(fA + 1) * args.n_coef + lane] = acc.y;
 			}
+			i_cur = i_next; i_next = __builtin_amdgcn_readfirstlane(drawn);
 			continue;
 		}
 
+		ED2_ST(0)
 		/* ---- 2a. pass 1 + twiddle W512^(lane*p) */
-		ed_radix8_2(re, im);
+		if (!(ED2_SKIP & 4)) ed_radix8_2(re, im);
 #pragma unroll
-		for (int q = 1; q < 8; q++)
+		for (int q = 1; q < 8 && !(ED2_SKIP & 4); q++)
 		{
+#if ED2_TW_LDS
+			const float2 w_ = tw1l[64 * (q - 1)];
+			const ed_f2 wr = ed_splat(w_.x), wi = ed_splat(w_.y);
+#else
 			const ed_f2 wr = ed_splat(t1r[q]), wi = ed_splat(t1i[q]);
+#endif
 			const ed_f2 xr = re[q], xi = im[q];
 			re[q] = xr * wr - xi * wi;
 			im[q] = xr * wi + xi * wr;
 		}
-		ed_transpose8_2<3, 4, 5>(re, lane);
-		ed_transpose8_2<3, 4, 5>(im, lane);
-
-		/* ---- 2b. pass 2 + twiddle W64^(c*q) */
-		ed_radix8_2(re, im);
+		ED2_ST(1)
+#if ED2_T1_LDS
+		/* transpose 1 through LDS: (lane 8b+c, reg p) -> (lane 8p+c, reg b); slot 64b + 8p + c: the ds_write_b128 of a
+		 * lane group (8 consecutive lanes) and the ds_read_b128 (slot 64b' + lane) are both conflict-free */
 #pragma unroll
-		for (int q = 1; q < 8; q++)
+		for (int q = 0; q < 8; q++) xc4[64 * hi3 + lo3 + 8 * q] = make_float4(re[q].x, re[q].y, im[q].x, im[q].y);
+		ed_wave_sync();
+#pragma unroll
+		for (int b = 0; b < 8; b++)
 		{
+			const float4 v = xc4[64 * b + lane];
+			re[b] = ed_mk2(v.x, v.y); im[b] = ed_mk2(v.z, v.w);
+		}
+		ed_wave_sync();
+#else
+		if (!(ED2_SKIP & 1))
+		{
+			ed_transpose8_2<3, 4, 5>(re, lane);
+			ed_transpose8_2<3, 4, 5>(im, lane);
+		}
+#endif
+
+		ED2_ST(2)
+		/* ---- 2b. pass 2 + twiddle W64^(c*q) */
+		if (!(ED2_SKIP & 4)) ed_radix8_2(re, im);
+#pragma unroll
+		for (int q = 1; q < 8 && !(ED2_SKIP & 4); q++)
+		{
+#if ED2_TW_LDS
+			const float2 w_ = tw2l[64 * (q - 1)];
+			const ed_f2 wr = ed_splat(w_.x), wi = ed_splat(w_.y);
+#else
 			const ed_f2 wr = ed_splat(t2r[q]), wi = ed_splat(t2i[q]);
+#endif
 			const ed_f2 xr = re[q], xi = im[q];
 			re[q] = xr * wr - xi * wi;
 			im[q] = xr * wi + xi * wr;
 		}
+		ED2_ST(3)
 		/* transpose 2 through LDS, both frames in one 16-byte slot: (lane 8p+c, reg q) -> (lane p+8q, reg c); slot
 		 * 66c + p + 8q keeps the ds_write_b128 (8-lane groups, stride 66 slots = 8 banks mod 64) and the ds_read_b128
 		 * (consecutive slots) free of bank conflicts */
 #pragma unroll
-		for (int q = 0; q < 8; q++) xc4[66 * lo3 + hi3 + 8 * q] = make_float4(re[q].x, re[q].y, im[q].x, im[q].y); /* pairs stay pairs */
+		for (int q = 0; q < 8 && !(ED2_SKIP & 2); q++) xc4[66 * lo3 + hi3 + 8 * q] = make_float4(re[q].x, re[q].y, im[q].x, im[q].y); /* pairs stay pairs */
 		ed_wave_sync();
 #pragma unroll
-		for (int c = 0; c < 8; c++)
+		for (int c = 0; c < 8 && !(ED2_SKIP & 2); c++)
 		{
 			const float4 v = xc4[66 * c + lane];
 			re[c] = ed_mk2(v.x, v.y); im[c] = ed_mk2(v.z, v.w);
 		}
 		ed_wave_sync();
 
+		ED2_ST(4)
 		/* ---- 2c. pass 3: reg r holds Z[k0 + 64r] of both frames */
-		ed_radix8_2(re, im);
+		if (!(ED2_SKIP & 4)) ed_radix8_2(re, im);
 
+		ED2_ST(5)
 		/* ---- 3. real-FFT split (see ed_mfcc_kernel); the partner values come per frame through ds_bpermute */
 		ed_f2 slo[4], shi[4];
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 		{
 			ed_f2 pzr, pzi;
-			pzr.x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].x)));
-			pzr.y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].y)));
-			pzi.x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].x)));
-			pzi.y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].y)));
+			if (!(ED2_SKIP & 8))
+			{
+				pzr.x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].x)));
+				pzr.y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].y)));
+				pzi.x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].x)));
+				pzi.y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].y)));
+			}
+			if (ED2_SKIP & 8) { pzr = re[7 - m]; pzi = im[7 - m]; }
 			if (lane == 0) { pzr = re[(8 - m) & 7]; pzi = im[(8 - m) & 7]; }
+			if (ED2_SKIP & 64) { slo[m] = re[m] + pzr; shi[m] = im[m] + pzi; continue; }
 			const float2 tw = tpl[64 * m + lane];
 			const ed_f2 twx = ed_splat(tw.x), twy = ed_splat(tw.y);
 			const ed_f2 ar = re[m] + pzr, ai = im[m] - pzi;
@@ -728,13 +882,15 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 			const ed_f2 e0 = xr * xr + xi * xi, e1 = yr * yr + yi * yi;
 			slo[m] = ed_mk2(__builtin_amdgcn_sqrtf(e0.x), __builtin_amdgcn_sqrtf(e0.y));
 			shi[m] = ed_mk2(__builtin_amdgcn_sqrtf(e1.x), __builtin_amdgcn_sqrtf(e1.y));
+			if (ED2_SKIP & 16) { slo[m] = e0; shi[m] = e1; }
 		}
 		const ed_f2 e256 = re[4] * re[4] + im[4] * im[4];
 		const ed_f2 s256 = ed_mk2(2.0f * __builtin_amdgcn_sqrtf(e256.x), 2.0f * __builtin_amdgcn_sqrtf(e256.y));
 
+		ED2_ST(6)
 		/* ---- 4. both spectra to LDS, interleaved: S2[k] = (|2X_A[k]|, |2X_B[k]|) */
 #pragma unroll
-		for (int m = 0; m < 4; m++)
+		for (int m = 0; m < 4 && !(ED2_SKIP & 128); m++)
 		{
 			S2[k0 + 64 * m] = slo[m];
 			S2[512 - k0 - 64 * m] = shi[m];
@@ -742,6 +898,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 		if (lane == 0) S2[256] = s256;
 		ed_wave_sync();
 
+		ED2_ST(7)
 		/* ---- 5. mel filterbank, balanced as above; a spectrum quad of both frames is two 16-byte reads */
 		const float4 *S4 = reinterpret_cast<const float4 *>(S2);
 		/* Every ds_read_b128 serves 16 lanes from 16 slots of 16 bytes; if all lanes took the first half of their quad,
@@ -751,15 +908,16 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 		const int qlo_a = 2 * mel_slo4 + half, qlo_b = 2 * mel_slo4 + 1 - half;
 		const int qhi_a = 2 * mel_shi4 + half, qhi_b = 2 * mel_shi4 + 1 - half;
 		ed_f2 alo0 = ed_splat(0.0f), alo1 = alo0, ahi0 = alo0, ahi1 = alo0;
+		if (ED2_SKIP & 32) { alo0 = slo[0] + slo[1]; alo1 = slo[2] + slo[3]; ahi0 = shi[0] + shi[1]; ahi1 = shi[2] + shi[3]; }
 #pragma unroll
-		for (int t = 0; t < NLO; t++)
+		for (int t = 0; t < NLO && !(ED2_SKIP & 32); t++)
 		{
 			const float4 sa = S4[qlo_a + 2 * t], sb = S4[qlo_b + 2 * t], w = melw4[t * 64 + lane];
 			alo0 = ed_fma2(ed_mk2(sa.x, sa.y), ed_splat(w.x), alo0); alo1 = ed_fma2(ed_mk2(sa.z, sa.w), ed_splat(w.y), alo1);
 			alo0 = ed_fma2(ed_mk2(sb.x, sb.y), ed_splat(w.z), alo0); alo1 = ed_fma2(ed_mk2(sb.z, sb.w), ed_splat(w.w), alo1);
 		}
 #pragma unroll
-		for (int t = 0; t < NHI; t++)
+		for (int t = 0; t < NHI && !(ED2_SKIP & 32); t++)
 		{
 			if (t % 2 == 0) __builtin_amdgcn_sched_barrier(0); /* bounds the registers this stage holds in flight */
 			const float4 sa = S4[qhi_a + 2 * t], sb = S4[qhi_b + 2 * t], w = melw4[(NLO + t) * 64 + lane];
@@ -771,10 +929,12 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 		 * of TWO registers, two sums are folded at once: first frame A's and frame B's partial sums over the wave
 		 * halves (lanes 0..31 then hold A, 32..63 B), then the narrow and the wide band over the row pairs. One
 		 * register ends up with  row 0: band b of A,  row 1: band 31-b of A,  row 2: b of B,  row 3: 31-b of B. */
+		ED2_ST(8)
 		const ed_f2 plo = alo0 + alo1, phi = ahi0 + ahi1;
 		float t = ed_fold_rows(ed_fold_halves(plo.x, plo.y), ed_fold_halves(phi.x, phi.y));
 		if (do_log) t = __logf(t + log_offset);
 
+		ED2_ST(9)
 		/* ---- 6. DCT-II through cos symmetry, both frames: u = L[b] + L[31-b] (even rows), v = L[b] - L[31-b] (odd) */
 		ed_f2 *Lb2 = reinterpret_cast<ed_f2 *>(xbuf + ED2_L_OFF); /* u[16] | v[16] as float2 (A, B) */
 		{
@@ -796,6 +956,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 		const float coef = ed_fold_halves(d.x, d.y);
 		ed_wave_sync(); /* Lb2 / S2 are rewritten by the next pair */
 
+		ED2_ST(10)
 		/* ---- 7. store: A's and B's rows are adjacent in memory, one instruction writes both */
 		const int c = lane & 31;
 		if (c < args.n_coef && (lane < 32 || haveB))
@@ -804,11 +965,23 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 			if (args.mfcc) args.mfcc[at] = coef;
 			if (args.feat) args.feat[at] = (int8_t)__float2int_rn(fminf(fmaxf(coef * args.feat_scale, -128.0f), 127.0f));
 		}
+		ED2_ST(11)
+		i_cur = i_next; i_next = __builtin_amdgcn_readfirstlane(drawn);
 	}
+#if ED2_STAMP
+	asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) :: "memory");
+	ph[12] = ed2_now() - tfirst; ph[13] = rt1 - rt0; ph[14] = rt_entry; ph[15] = rt0; ph[16] = rt1;
+	if (g_ed2_dbg && lane == 0)
+	{
+		unsigned long long *dbg = g_ed2_dbg + (size_t)(blockIdx.x * ED2_WPB + wave) * ED2_NPH;
+		ph[11] = i_cur; /* not a time: how far this wave got in the slice */
+		for (int i_ = 0; i_ < ED2_NPH; i_++) dbg[i_] = ph[i_];
+	}
+#endif
 }
 
 static int g_mfcc_blocks_per_cu[2] = {-1, -1};
-static int g_mfcc2_blocks_per_cu[2] = {-1, -1};
+static int g_mfcc2_blocks_per_cu[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
 
 template <int NLO, int NHI>
 static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
@@ -834,25 +1007,33 @@ static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables
 	static const int one_frame = getenv("ED_MFCC_ONE_FRAME") ? atoi(getenv("ED_MFCC_ONE_FRAME")) : 0; /* A/B knob */
 	if (!stages && !one_frame)
 	{
-		/* the fast path: two frames per wavefront in packed fp32 */
-		const size_t lds2 = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_WPB * ED2_XBUF_FLOATS);
-		int *bpc2 = &g_mfcc2_blocks_per_cu[NLO == 2 ? 0 : 1];
+		/* the fast path: two frames per wavefront in packed fp32, one ED2_WPB-wave workgroup per CU */
+		const size_t lds2 = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_TWTAB_FLOATS + ED2_WPB * ED2_XBUF_FLOATS) + 16 /* queue */;
+		const bool plain = args->frames_per_group >= args->n_frames;
+		const void *fn = aligned ? (plain ? (const void *)ed_mfcc2_kernel<true, true, NLO, NHI> : (const void *)ed_mfcc2_kernel<true, false, NLO, NHI>)
+		                         : (plain ? (const void *)ed_mfcc2_kernel<false, true, NLO, NHI> : (const void *)ed_mfcc2_kernel<false, false, NLO, NHI>);
+		int *bpc2 = &g_mfcc2_blocks_per_cu[(NLO == 2 ? 0 : 4) + (aligned ? 2 : 0) + (plain ? 1 : 0)];
 		if (*bpc2 < 0)
 		{
+			/* more than 64 KB of dynamic LDS has to be asked for, once per kernel instance */
+			if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return (int)hipGetLastError();
 			int nb = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ed_mfcc2_kernel<true, NLO, NHI>, 64 * ED2_WPB, lds2) != hipSuccess || nb < 1)
-				nb = 1;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * ED2_WPB, lds2) != hipSuccess || nb < 1) nb = 1;
 			const char *env = getenv("ED_MFCC_BLOCKS_PER_CU");
 			if (env && atoi(env) > 0 && atoi(env) < nb) nb = atoi(env);
+#ifdef ED2_MAX_BPC /* A/B knob (tools/lab): cap the resident workgroups per CU at compile time */
+			if (nb > ED2_MAX_BPC) nb = ED2_MAX_BPC;
+#endif
 			*bpc2 = nb;
 		}
 		const int64_t n_pairs = (args->n_frames + 1) / 2;
 		int64_t blocks2 = (n_pairs + ED2_WPB - 1) / ED2_WPB;
 		if (blocks2 > (int64_t)n_cu * *bpc2) blocks2 = (int64_t)n_cu * *bpc2;
-		dim3 grid2((unsigned)blocks2), block2(64 * ED2_WPB);
-		if (aligned) hipLaunchKernelGGL((ed_mfcc2_kernel<true, NLO, NHI>), grid2, block2, lds2, stream, *args, dev_tab);
-		else hipLaunchKernelGGL((ed_mfcc2_kernel<false, NLO, NHI>), grid2, block2, lds2, stream, *args, dev_tab);
-		return (int)hipGetLastError();
+#ifdef ED2_MAX_WGS /* A/B knob (tools/lab): run on a part of the chip */
+		if (blocks2 > ED2_MAX_WGS) blocks2 = ED2_MAX_WGS;
+#endif
+		void *kargs[] = {(void *)args, (void *)&dev_tab};
+		return (int)hipLaunchKernel(fn, dim3((unsigned)blocks2), dim3(64 * ED2_WPB), kargs, lds2, stream);
 	}
 	dim3 grid((unsigned)blocks), block(64 * ED_WPB);
 	if (stages)
