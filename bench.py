@@ -171,54 +171,78 @@ def stream_bench(ctx, dev):
                                 realtime_factor=round(n_push * chunk * hop / 16000.0 / dt, 1)))
 
 
-def cpu_baseline(n_threads):
-    """The oracle's C restatement (checker code, timed here only as the reported CPU baseline)."""
+def _synth_frames_np(n_frames, seed):
+    """SURVEY.md 8(d) generator on the host: clip(N(0, 3000^2)) + the two-tone of mfcc_on_mcu.py:314-315 with a random
+    phase per frame -> int16 (the same distribution as synth_frames; the GPU tensors never leave the device)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(1024, dtype=np.float32) / 16000.0
+    x = rng.normal(0, 3000, (n_frames, 1024)).astype(np.float32)
+    ph = rng.random((n_frames, 2), dtype=np.float32) * (2 * np.pi)
+    x += 1000.0 * np.cos(2 * np.pi * 1000.0 * t[None, :] + ph[:, 0:1])
+    x += 500.0 * np.cos(2 * np.pi * 125.0 * t[None, :] + ph[:, 1:2])
+    return np.clip(x, -32768, 32767).astype(np.int16).reshape(-1)
+
+
+def _median_rate(fn, units, passes=3):
+    """one warm-up pass, then >= 3 timed passes, the median."""
+    fn()
+    ts = []
+    for _ in range(passes):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return units / sorted(ts)[len(ts) // 2]
+
+
+def cpu_baseline():
+    """The oracle's C restatement (checker code, timed here only as the reported CPU baseline), as BASELINE.md
+    section 3 prescribes: built -O3 -march=native on this host, (i) one thread, (ii) all host cores (static partition
+    over frames / utterances, OpenMP), one warm-up pass and the median of 3 timed passes, core count printed."""
     from oracle import oracle
-    oracle.build()
-    rng = np.random.default_rng(20)
+    oracle.use_native_build()
+    nproc = os.cpu_count()
+    n_all = len(os.sched_getaffinity(0))
+    print("cpu_baseline: nproc=%d, usable cores (affinity)=%d; legs: 1 thread and %d threads" % (nproc, n_all, n_all),
+          file=sys.stderr, flush=True)
+    host = dict(nproc=nproc, usable_cores=n_all, build="gcc -O3 -march=native -fopenmp (oracle/Makefile native)", passes=3)
     res = {}
-    # MFCC variant B, float64 like the reference's numpy path; sample sized for ~10 s
-    n = 65536
-    x = np.clip(rng.normal(0, 3000, n * 1024), -32768, 32767).astype(np.int16)
-    oracle.mfcc(x[:4096 * 1024], oracle.VARIANT_B, n_threads=n_threads)     # warm-up (thread pool, page faults)
-    reps, t0 = 0, time.perf_counter()
-    while reps < 1 or (time.perf_counter() - t0 < 8.0 and reps < 200):      # ~8-10 s of CPU work
-        oracle.mfcc(x, oracle.VARIANT_B, n_threads=n_threads)
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    res["mfcc"] = dict(value=n / dt, unit="frames/s", cores=n_threads, kind="port",
-                       sample="%d frames x %d passes, oracle/mfcc_ref.c variant B float64, %d OpenMP threads" % (n, reps, n_threads))
-    # MFCC variant C (Q15), ~4 s
-    oracle.mfcc_q15(x[:4096 * 1024], n_threads=n_threads)
-    reps, t0 = 0, time.perf_counter()
-    while reps < 1 or (time.perf_counter() - t0 < 4.0 and reps < 200):
-        oracle.mfcc_q15(x, n_threads=n_threads)
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    res["q15"] = dict(value=n / dt, unit="frames/s", cores=n_threads, kind="port",
-                      sample="%d frames x %d passes, oracle/mfcc_q15_ref.c, %d OpenMP threads" % (n, reps, n_threads))
-    # full KWS: MFCC B + int8 CNN restatement, all threads
-    nu = 2048
-    a = np.clip(rng.normal(0, 3000, nu * 31744), -32768, 32767).astype(np.int16)
+    x = _synth_frames_np(65536, 20)                                   # seed 20: SURVEY.md 8(d) config 2
+    n1 = 4096                                                         # 1-thread sample: ~0.1-0.2 s per pass
+
+    def leg(fn_1, units_1, fn_all, units_all, unit, what):
+        r1 = _median_rate(fn_1, units_1)
+        ra = _median_rate(fn_all, units_all)
+        return dict(value=ra, unit=unit, cores=n_all, kind="port", single_thread=dict(value=r1, cores=1, sample_units=units_1),
+                    sample="%s; all-cores leg %d units, 1-thread leg %d units; median of 3 passes after 1 warm-up" % (what, units_all, units_1),
+                    host=host)
+    # MFCC variant B (the features the net was trained on), float64 like the reference's numpy path it restates
+    res["mfcc"] = leg(lambda: oracle.mfcc(x[:n1 * 1024], oracle.VARIANT_B, n_threads=1), n1,
+                      lambda: oracle.mfcc(x, oracle.VARIANT_B, n_threads=n_all), 65536, "frames/s",
+                      "oracle/mfcc_ref.c variant B float64, SURVEY 8(d) generator (noise + two-tone), seed 20")
+    res["mfcc_variant_a"] = leg(lambda: oracle.mfcc(x[:n1 * 1024], oracle.VARIANT_A, n_threads=1), n1,
+                                lambda: oracle.mfcc(x, oracle.VARIANT_A, n_threads=n_all), 65536, "frames/s",
+                                "oracle/mfcc_ref.c variant A float64, same frames")
+    # MFCC variant C = the firmware's own C path (Q15 CMSIS-DSP arithmetic restated)
+    res["q15"] = leg(lambda: oracle.mfcc_q15(x[:n1 * 1024], n_threads=1), n1,
+                     lambda: oracle.mfcc_q15(x, n_threads=n_all), 65536, "frames/s",
+                     "oracle/mfcc_q15_ref.c (firmware audioCalcMFCCs arithmetic), same frames")
+    # full KWS: MFCC B + int8 CNN restatement; 4096 utterances (126 976 frames) for the all-cores leg keeps the whole
+    # baseline inside ~30 s of CPU work on a 16-core host
+    nu_all, nu_1 = 4096, 128
+    a = _synth_frames_np(nu_all * 31, 21)                             # utterances of 31 frames, seed 21 (config 3)
     model = oracle.Model()
 
-    def kws_once():
-        m = oracle.mfcc(a, oracle.VARIANT_B, n_threads=n_threads)[:, :13]
-        f = oracle.net_input(m).reshape(nu, 403)
-        return oracle.cnn(model, f, n_threads=n_threads)
-    kws_once()
-    reps, t0 = 0, time.perf_counter()
-    while reps < 1 or (time.perf_counter() - t0 < 8.0 and reps < 200):
-        kws_once()
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    res["kws"] = dict(value=nu / dt, unit="inferences/s", cores=n_threads, kind="port",
-                      sample="%d utterances x %d passes, oracle MFCC B + int8 CNN restatement, %d OpenMP threads" % (nu, reps, n_threads))
+    def kws(n, th):
+        m = oracle.mfcc(a[:n * 31744], oracle.VARIANT_B, n_threads=th)[:, :13]
+        return oracle.cnn(model, oracle.net_input(m).reshape(n, 403), n_threads=th)
+    res["kws"] = leg(lambda: kws(nu_1, 1), nu_1, lambda: kws(nu_all, n_all), nu_all, "inferences/s",
+                     "oracle MFCC B + int8 CNN restatement (NNoM arithmetic), utterances of 31 frames, seed 21")
     if oracle.have_ref():
+        rng = np.random.default_rng(5)
         f = rng.integers(-128, 128, (2000, 403)).astype(np.int8)
-        t0 = time.perf_counter(); oracle.nnom_ref_batch(f); dt = time.perf_counter() - t0
-        res["cnn_reference"] = dict(value=2000 / dt, unit="inferences/s", cores=1, kind="reference",
-                                    sample="2000 random inputs, reference NNoM 0.3.0 + CMSIS-NN + weights.h (oracle/_ref), CNN only, 1 thread")
+        r = _median_rate(lambda: oracle.nnom_ref_batch(f), 2000)
+        res["cnn_reference"] = dict(value=r, unit="inferences/s", cores=1, kind="reference",
+                                    sample="2000 random inputs, reference NNoM 0.3.0 + CMSIS-NN + weights.h (oracle/_ref, gcc -O2), CNN only, 1 thread, median of 3")
     return res
 
 
@@ -360,8 +384,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.skip_cpu:
         try:
-            n_threads = min(len(os.sched_getaffinity(0)), 16)
-            cpu = cpu_baseline(n_threads)
+            cpu = cpu_baseline()
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU numbers
             cpu = dict(error=repr(e))
 
@@ -386,6 +409,7 @@ def main():
             if "mfcc" in cpu:
                 line["cpu_baseline"] = cpu["mfcc"]
                 line["cpu_baseline_kws"] = cpu.get("kws")
+                variant_a["cpu_baseline"] = cpu.get("mfcc_variant_a")
                 if "cnn_reference" in cpu:
                     line["cpu_baseline_cnn_reference"] = cpu["cnn_reference"]
             else:

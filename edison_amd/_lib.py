@@ -68,6 +68,8 @@ SIGNATURES = {
     "edison_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     "edison_dev_download": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     "edison_mfcc_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_float]),
+    "edison_mfcc_rows_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_float]),
+    "edison_mfcc_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_float]),
     "edison_mfcc_stages_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
     "edison_cnn_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -104,6 +104,21 @@ class Context:
                                               _np_ptr(feat), float(feat_scale)))
         return (out, feat) if want_feat else out
 
+    def mfcc_rows(self, data, frames_per_row, frame_step=FRAME_LEN, variant=MFCC_B, n_coef=NUM_MEL, use_log=False):
+        """data: int16 [n_rows, samples] -> fp32 [n_rows, frames_per_row, n_coef] in ONE launch (the reference's
+        batch_mfcc shape, mfcc_utils.py:75-131)."""
+        x = np.ascontiguousarray(data, dtype=np.int16)
+        if x.ndim != 2:
+            raise ValueError("data must be [n_rows, samples]")
+        n_rows, ns = x.shape
+        if frames_per_row > 0 and (frames_per_row - 1) * frame_step + FRAME_LEN > ns:
+            raise ValueError("rows too short for %d frames" % frames_per_row)
+        out = np.zeros((n_rows, max(frames_per_row, 0), n_coef), np.float32)
+        v = variant | (MFCC_USE_LOG if use_log else 0)
+        self._check(self._L.edison_mfcc_rows(self._h, _np_ptr(x), n_rows, ns, int(frames_per_row), int(frame_step), v,
+                                             int(n_coef), _np_ptr(out), None, 1.0))
+        return out
+
     def mfcc_stages(self, audio, n_frames=None, frame_step=FRAME_LEN, variant=MFCC_B, use_log=False):
         x = np.ascontiguousarray(audio, dtype=np.int16).ravel()
         if n_frames is None:

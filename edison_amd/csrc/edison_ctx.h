@@ -43,6 +43,7 @@ struct edison_ctx
 	ed_cnn_mfma_model_t *d_model_mfma; /* MFMA fast path                                       */
 	int have_model;                    /* a model is loaded (any graph the planner accepts)    */
 	int fast_model;                    /* ... and it is the kws_conv graph the two kernels above are specialised for */
+	int tables_epoch;                  /* counts edison_mfcc_configure calls: captured graphs also bake in the table shape and addresses */
 	int model_epoch;                   /* counts loads: captured graphs (edison_stream) hold device addresses of one load */
 	/* the general layer-by-layer path (cnn_net_kernels.hip): plan (host copy + device copy), weights, seeds */
 	ed_net_plan_t net;

@@ -19,6 +19,12 @@ static int set_err(edison_ctx *ctx, int code, const char *msg) { return ed_set_e
 
 static int upload_tables(edison_ctx *ctx, double fs, double lo, double hi, double scale)
 {
+	/* Tables are treated like the model: graphs captured by edison_stream objects hold the kernel instance picked for the
+	 * table shape (mel_NLO / mel_NHI), the table addresses and, for variant C, d_q15 itself, and they run on the streams'
+	 * private HIP streams. So: wait for the whole device before a table is overwritten or freed, and bump the epoch that
+	 * edison_stream_push* checks -- a stream created before this call refuses further pushes. */
+	ED_HIP(ctx, hipDeviceSynchronize());
+	ctx->tables_epoch++;
 	for (int v = 0; v < 2; v++)
 	{
 		ed_mfcc_tables_t *h = (ed_mfcc_tables_t *)malloc(sizeof(ed_mfcc_tables_t));
@@ -347,6 +353,17 @@ extern "C" int edison_mfcc_batch_dev(edison_ctx *ctx, const int16_t *audio, int6
 	                   feat_scale, 0, NULL, NULL, NULL, NULL);
 }
 
+extern "C" int edison_mfcc_rows_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_rows, int64_t row_stride,
+                                    int64_t frames_per_row, int64_t frame_step, int variant, int n_coef, float *mfcc,
+                                    int8_t *feat, float feat_scale)
+{
+	if (!ctx || n_rows < 0 || frames_per_row < 0 || row_stride < 0) return EDISON_E_ARGUMENT;
+	if (n_rows == 0 || frames_per_row == 0) return EDISON_OK;
+	if (n_rows > INT32_MAX / frames_per_row) return set_err(ctx, EDISON_E_SIZE, "edison_mfcc_rows: more than 2^31 frames in one call");
+	return mfcc_launch(ctx, audio, n_rows * frames_per_row, frames_per_row, row_stride, frame_step, variant, n_coef, mfcc, feat,
+	                   feat_scale, 0, NULL, NULL, NULL, NULL);
+}
+
 extern "C" int edison_mfcc_stages_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step,
                                       int variant, float *fft, float *spec, float *mel, float *logmel, float *mfcc32)
 {
@@ -475,6 +492,30 @@ extern "C" int edison_mfcc_batch(edison_ctx *ctx, const int16_t *audio, int64_t 
 	if (r != EDISON_OK) return r;
 	ED_DOWN(ctx, mfcc, m.p, (size_t)n_frames * n_coef * sizeof(float));
 	ED_DOWN(ctx, feat, q.p, (size_t)n_frames * n_coef);
+	ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return EDISON_OK;
+}
+
+extern "C" int edison_mfcc_rows(edison_ctx *ctx, const int16_t *audio, int64_t n_rows, int64_t row_stride, int64_t frames_per_row,
+                                int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale)
+{
+	if (!ctx || n_rows < 0 || frames_per_row < 0 || row_stride < 0 || frame_step < 0 || (!audio && n_rows > 0)) return EDISON_E_ARGUMENT;
+	if (n_rows == 0 || frames_per_row == 0) return EDISON_OK;
+	if (n_coef < 1 || n_coef > EDISON_NUM_MEL) return set_err(ctx, EDISON_E_ARGUMENT, "n_coef must be 1..32");
+	if (n_rows > INT32_MAX / frames_per_row) return set_err(ctx, EDISON_E_SIZE, "edison_mfcc_rows: more than 2^31 frames in one call");
+	ED_HIP(ctx, hipSetDevice(ctx->device));
+	dev_buf a, m, q;
+	const size_t n = (size_t)(n_rows * frames_per_row);
+	const size_t na = ((size_t)(n_rows - 1) * (size_t)row_stride + audio_span(frames_per_row, frame_step)) * sizeof(int16_t);
+	ED_HIP(ctx, a.alloc(na));
+	if (mfcc) ED_HIP(ctx, m.alloc(n * n_coef * sizeof(float)));
+	if (feat) ED_HIP(ctx, q.alloc(n * n_coef));
+	ED_UP(ctx, a.p, audio, na);
+	int r = edison_mfcc_rows_dev(ctx, (const int16_t *)a.p, n_rows, row_stride, frames_per_row, frame_step, variant, n_coef,
+	                             (float *)m.p, (int8_t *)q.p, feat_scale);
+	if (r != EDISON_OK) return r;
+	ED_DOWN(ctx, mfcc, m.p, n * n_coef * sizeof(float));
+	ED_DOWN(ctx, feat, q.p, n * n_coef);
 	ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return EDISON_OK;
 }

@@ -51,6 +51,7 @@ struct edison_stream
 	hipGraphExec_t exec_h;
 	int last_push_staged;
 	int64_t frames_seen;
+	int tables_epoch;     /* likewise for the MFCC tables (edison_mfcc_configure) */
 	int model_epoch;      /* the graphs hold the device addresses of the model that was loaded when they were captured */
 };
 
@@ -210,6 +211,7 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 	s->ctx = ctx; s->hop = hop; s->chunk = chunk_frames; s->tail = EDISON_FRAME_LEN - hop;
 	s->variant = o->mfcc_variant;
 	s->model_epoch = ctx->model_epoch;
+	s->tables_epoch = ctx->tables_epoch;
 	s->filter = o->filter ? 1 : 0;
 	s->alpha = o->filter_alpha;
 	s->one_minus_alpha = 1.0 - o->filter_alpha; /* the firmware's (1.0-NET_OUT_MOVING_AVG_ALPHA), folded in double */
@@ -312,6 +314,7 @@ extern "C" int edison_stream_push_dev(edison_stream *s, const int16_t *samples, 
 	if (!s || !samples) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
 	if (s->model_epoch != ctx->model_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: the model was reloaded after this stream was created; create a new stream");
+	if (s->tables_epoch != ctx->tables_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: edison_mfcc_configure was called after this stream was created; create a new stream");
 	const size_t nnew = (size_t)s->chunk * s->hop;
 	/* the caller produced `samples` on the context's stream: the private stream waits for that point ... */
 	ED_HIP(ctx, hipEventRecord(s->ev_in, ctx->stream));
@@ -335,6 +338,7 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 	if (!s || !samples) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
 	if (s->model_epoch != ctx->model_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: the model was reloaded after this stream was created; create a new stream");
+	if (s->tables_epoch != ctx->tables_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: edison_mfcc_configure was called after this stream was created; create a new stream");
 	const size_t nnew = (size_t)s->chunk * s->hop;
 	if (s->exec_h)
 	{

@@ -89,8 +89,10 @@ int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, ed_
 		const int32_t *v = r[i].v;
 		int ok = v[0] == expect[i][0];
 		if (ok && v[0] == T_CONV) ok = v[1] == expect[i][1] && v[2] == expect[i][2] && v[3] == expect[i][3] && v[4] == 1 && v[5] == 1 && v[8] == 1;
-		if (ok && v[0] == T_POOL) ok = v[2] == 2 && v[3] == 1 && v[4] == 2 && v[5] == 1;
-		if (ok && v[0] == T_DENSE) ok = v[1] == ED_FC_O && v[11] == ED_FC_I;
+		/* v[8]: bit 0 = ReLU tail, bit 1 = PADDING_SAME. The matrix-core kernel implements valid pooling (27 -> 13 rows)
+		 * and a dense layer without ReLU only; anything else falls through to the general plan (model_net.c) */
+		if (ok && v[0] == T_POOL) ok = v[2] == 2 && v[3] == 1 && v[4] == 2 && v[5] == 1 && v[8] == 0;
+		if (ok && v[0] == T_DENSE) ok = v[1] == ED_FC_O && v[11] == ED_FC_I && v[8] == 0;
 		if (ok && (v[0] == T_CONV || v[0] == T_DENSE))
 			ok = v[6] >= 0 && v[6] < 24 && v[7] >= 0 && v[7] < 31 && v[9] >= 0 && v[10] >= 0 && v[9] < payload_bytes && v[10] < payload_bytes;
 		if (!ok) return fail(err, err_cap, "model layer list does not match the kws_conv graph (weights.h:138-161)");

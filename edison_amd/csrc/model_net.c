@@ -55,8 +55,12 @@ int ed_plan_net(const void *blob, size_t blob_bytes, ed_net_plan_t *plan, int8_t
 	plan->n_layers = n_layers;
 	plan->in_h = h; plan->in_w = w; plan->in_c = c; plan->in_n = h * w * c;
 
-	int8_t *wbuf = (int8_t *)calloc((size_t)payload_bytes + 16 * ((size_t)n_layers + 1), 1); /* every tensor re-aligned to 16 */
-	int32_t *sbuf = (int32_t *)calloc((size_t)payload_bytes + 16, sizeof(int32_t)); /* one seed per bias byte at most */
+	/* every tensor re-aligned to 16; one seed per bias byte at most. Tensors of a well-formed blob are disjoint, so their
+	 * sizes add up to at most the payload; records that point at overlapping ranges are refused when the sum outgrows
+	 * these buffers (w_cap / s_cap checks below), not written past their end. */
+	const size_t w_cap = (size_t)payload_bytes + 16 * ((size_t)n_layers + 1), s_cap = (size_t)payload_bytes + 16;
+	int8_t *wbuf = (int8_t *)calloc(w_cap, 1);
+	int32_t *sbuf = (int32_t *)calloc(s_cap, sizeof(int32_t));
 	if (!wbuf || !sbuf) { free(wbuf); free(sbuf); return fail(err, err_cap, EDISON_E_NO_MEMORY, "host allocation failed", 0, 0); }
 	int w_used = 0, s_used = 0, acts = 0, max_act = (plan->in_n + 15) & ~15, rc = EDISON_OK;
 
@@ -96,6 +100,8 @@ int ed_plan_net(const void *blob, size_t blob_bytes, ed_net_plan_t *plan, int8_t
 				if (v[9] < 0 || v[10] < 0 || v[9] + wn > payload_bytes || (int64_t)v[10] + L->out_c > payload_bytes)
 				{ rc = fail(err, err_cap, EDISON_E_SIZE, "layer %d: weight tensor outside the payload", i, 0); break; }
 				w_used = (w_used + 15) & ~15;
+				if ((size_t)w_used + (size_t)wn > w_cap || (size_t)s_used + (size_t)L->out_c > s_cap)
+				{ rc = fail(err, err_cap, EDISON_E_SIZE, "layer %d: tensors overlap (their sizes exceed the %d-byte payload)", i, payload_bytes); break; }
 				L->w_off = w_used;
 				/* stored OHWI (arm_convolve_HWC_q7_basic_nonsquare.c:209-211 reads w[o][ky][kx][ci]); the kernel wants the
 				 * output channel innermost so that consecutive lanes read consecutive addresses: [k/4][o] dwords of four
@@ -131,6 +137,8 @@ int ed_plan_net(const void *blob, size_t blob_bytes, ed_net_plan_t *plan, int8_t
 			if (v[9] < 0 || v[10] < 0 || v[9] + wn > payload_bytes || (int64_t)v[10] + v[1] > payload_bytes)
 			{ rc = fail(err, err_cap, EDISON_E_SIZE, "layer %d: dense tensor outside the payload", i, 0); break; }
 			w_used = (w_used + 15) & ~15;
+			if ((size_t)w_used + (size_t)wn > w_cap || (size_t)s_used + (size_t)v[1] > s_cap)
+			{ rc = fail(err, err_cap, EDISON_E_SIZE, "layer %d: tensors overlap (their sizes exceed the %d-byte payload)", i, payload_bytes); break; }
 			L->w_off = w_used;
 			memcpy(wbuf + w_used, payload + v[9], (size_t)wn); /* [out][in], de-interleaved by the importer */
 			w_used += (int)wn;

@@ -99,10 +99,9 @@ def batch_mfcc(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, 
     frame_count = _frame_count(frame_count, nSamples, frame_len, frame_step)
     data = _as_int16(data)
     print("Running mfcc for %d frames with %d step on %d samples" % (frame_count, frame_step, data.shape[0]))
-    output = np.zeros((data.shape[0], frame_count, mel_nbins))
-    for i in range(data.shape[0]):  # one C-ABI call per row keeps rows of any length independent
-        output[i] = ctx.mfcc(data[i], n_frames=frame_count, frame_step=frame_step, variant=_lib.MFCC_A, n_coef=mel_nbins)
-    return output
+    data = np.atleast_2d(data)
+    # one C-ABI call, one kernel launch for all rows (the kernel's grouped addressing: row = group, row stride = samples)
+    return ctx.mfcc_rows(data, frame_count, frame_step=frame_step, variant=_lib.MFCC_A, n_coef=mel_nbins).astype(np.float64)
 
 
 def mfcc(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, mel_nbins, mel_lower_hz, mel_upper_hz,

@@ -148,6 +148,15 @@ int edison_mfcc_batch_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_frame
                           int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale);
 
 /*
+ * The same over n_rows independent rows of samples (the reference's batch_mfcc, mfcc_utils.py:75-131: one utterance per
+ * row of data[n, samples]): row r starts at audio + r*row_stride (samples), its frame i at + i*frame_step; every row
+ * yields frames_per_row frames. Outputs are [n_rows * frames_per_row][n_coef], row-major over (row, frame). ONE kernel
+ * launch for the whole array (the kernel's grouped addressing), not one call per row.
+ */
+int edison_mfcc_rows_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_rows, int64_t row_stride, int64_t frames_per_row,
+                         int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale);
+
+/*
  * Same, plus every intermediate the reference returns in its per-frame dict (mfcc_utils.py:161-197):
  *   fft   [n][513][2] fp32  un-normalised X[k], k=0..512 (re,im)      spec   [n][513] fp32 |X[k]| (A) or |X[k]|/1024/sqrt2 (B)
  *   mel   [n][32] fp32 mel_spectrogram                                 logmel [n][32] fp32 log_mel_spectrogram
@@ -207,6 +216,8 @@ int edison_mfcc_batch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, i
                       int n_coef, float *mfcc, int8_t *feat, float feat_scale);
 int edison_mfcc_stages(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step, int variant,
                        float *fft, float *spec, float *mel, float *logmel, float *mfcc32);
+int edison_mfcc_rows(edison_ctx *ctx, const int16_t *audio, int64_t n_rows, int64_t row_stride, int64_t frames_per_row,
+                     int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale);
 int edison_cnn_batch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *logits, int8_t *softmax,
                      int32_t *argmax);
 int edison_cnn_layers(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int8_t *acts);

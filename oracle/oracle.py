@@ -41,6 +41,15 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
+def use_native_build():
+    """bench.py's cpu_baseline leg only: (re)build the restatement with -march=native ON THIS MACHINE and make port()
+    load that library. Must be called before the first port() of the process."""
+    global PORT_SO
+    assert _port is None, "use_native_build() must come before the first use of the checker"
+    subprocess.check_call(["make", "-C", _HERE, "-B", "native"], stdout=subprocess.DEVNULL)
+    PORT_SO = os.path.join(_HERE, "_build", "liboracle_native.so")
+
+
 class _Layer(ctypes.Structure):
     _fields_ = [("type", ctypes.c_int32), ("out_ch", ctypes.c_int32), ("kh", ctypes.c_int32), ("kw", ctypes.c_int32),
                 ("sh", ctypes.c_int32), ("sw", ctypes.c_int32), ("bias_lshift", ctypes.c_int32),

@@ -374,3 +374,31 @@ def test_c_program_links_against_the_abi(built_lib, ctx, kws_golden, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "firmware-style: edison" in out.stdout and "batched:        edison" in out.stdout
     assert "AI net information" in out.stdout and "last inference time:" in out.stdout and "#8 Softmax" in out.stdout
+
+
+def test_batch_mfcc_rows_in_one_launch(ctx, oracle_mod):
+    """edison_mfcc_rows (the mirror of batch_mfcc, mfcc_utils.py:75-131) handles all rows with ONE launch through the
+    kernel's grouped addressing: the result must equal the per-row calls bit for bit -- on the reference's config-2
+    shape (rows of exactly one frame: every frame pair straddles two rows) and on rows of several overlapping frames
+    with slack behind the last frame -- and the oracle within the variant-A tolerance."""
+    from edison_amd import _lib
+    rng = np.random.default_rng(75)
+    data = np.clip(rng.normal(0, 3000, (4096, 1024)), -32768, 32767).astype(np.int16)
+    got = ctx.mfcc_rows(data, 1, frame_step=1024, variant=_lib.MFCC_A, n_coef=32)
+    assert got.shape == (4096, 1, 32)
+    flat = ctx.mfcc(data.reshape(-1), n_frames=4096, frame_step=1024, variant=_lib.MFCC_A, n_coef=32)
+    assert np.array_equal(got[:, 0, :], flat)              # rows of one frame = the plain batch
+    for r in (0, 1, 2047, 4095):
+        assert np.array_equal(got[r, 0], ctx.mfcc(data[r], n_frames=1, variant=_lib.MFCC_A, n_coef=32)[0])
+    ref = oracle_mod.mfcc(data[:64].reshape(-1), oracle_mod.VARIANT_A)
+    assert np.all(np.abs(got[:64, 0, :] - ref) <= 1e-3 + 1e-4 * np.abs(ref))
+    # odd number of rows, 5 frames per row at hop 512 inside rows of 3100 samples (28 unused samples per row)
+    data = np.clip(rng.normal(0, 3000, (37, 3100)), -32768, 32767).astype(np.int16)
+    got = ctx.mfcc_rows(data, 5, frame_step=512, variant=_lib.MFCC_B, n_coef=13)
+    for r in range(37):
+        assert np.array_equal(got[r], ctx.mfcc(data[r], n_frames=5, frame_step=512, variant=_lib.MFCC_B, n_coef=13)), r
+    # the Python mirror goes through it
+    from edison_amd.mfcc import mfcc_utils as mfu
+    out = mfu.batch_mfcc(data[:3, :2048], 16000, 2048, 1024, 1024, 0, 1024, 32, 80, 7600)
+    assert out.shape == (3, 2, 32) and out.dtype == np.float64
+    assert np.array_equal(out[1].astype(np.float32), ctx.mfcc(data[1, :2048], n_frames=2, variant=_lib.MFCC_A, n_coef=32))

@@ -123,3 +123,33 @@ def test_stream_argument_checks(ctx):
     with pytest.raises(ValueError):
         st.push(np.zeros(1000, np.int16))
     st.close()
+
+
+def test_stream_refuses_pushes_after_reconfigure(oracle_mod, oracle_model):
+    """A captured stream graph bakes in the MFCC kernel instance chosen for the table shape and the table addresses.
+    edison_mfcc_configure after the stream was created must therefore stop that stream (a new one works and agrees
+    with the batch path on the new filterbank) instead of silently running the old kernel on re-laid tables."""
+    from edison_amd import _lib
+    from edison_amd._lib import EdisonError
+    from edison_amd.context import Context
+    from edison_amd.stream import Stream
+    c = Context(0)                                         # private context: the shared fixture keeps its filterbank
+    try:
+        rng = np.random.default_rng(77)
+        audio = np.clip(rng.normal(0, 2500, 8 * 1024), -32768, 32767).astype(np.int16)
+        st = Stream(c, hop=1024, chunk_frames=4)
+        st.push(audio[:4096])
+        c.configure_mfcc(16000, 20.0, 4000.0, 128)         # a filterbank that needs the wide table shape
+        with pytest.raises(EdisonError) as e:
+            st.push(audio[4096:])
+        assert "edison_mfcc_configure" in str(e.value)
+        st.close()
+        st2 = Stream(c, hop=1024, chunk_frames=4)
+        outs = [st2.push(audio[:4096]), st2.push(audio[4096:])]
+        soft = np.concatenate([o["softmax"] for o in outs])
+        _, feat = c.mfcc(audio, n_frames=8, frame_step=1024, variant=_lib.MFCC_B, n_coef=13, want_feat=True)
+        ref = c.cnn(_windows_from_features(feat))
+        assert np.array_equal(soft, ref["softmax"])
+        st2.close()
+    finally:
+        c.close()
