@@ -15,26 +15,40 @@
  *   - B = activations straight from the HWC int8 buffers in LDS: the 16 bytes a lane needs are 16 consecutive
  *     input channels of one tap (conv2-4) or one 16-byte-padded input row (conv1, Toeplitz form), i.e. one
  *     aligned ds_read_b128 -- no im2col buffer;
+ *   - C = the accumulator seeds (bias << bias_lshift) + NN_ROUND(out_rshift) of the tile's rows, so the epilogue is
+ *     shift, clamp, pack;
  *   - D puts 4 consecutive output channels of one pixel into 4 consecutive registers of a lane, so the
  *     epilogue packs them into one dword and stores HWC int8 directly where the next layer reads.
  *   - the two rows of a max-pool window are computed as two accumulator tiles over the same lanes
  *     (even / odd input row), pooled by an element-wise max.
  *
- * One 512-thread workgroup (8 waves) processes 32 utterances per iteration; tiles of a layer are dealt
- * round-robin to the waves and layers are separated by workgroup barriers. LDS: 61 KB of weight fragments +
- * 32 x 2992 B of activations (two aliased regions per utterance) = 157 KB -> one workgroup per CU.
+ * Work distribution (round 2). A WAVEFRONT owns a group of EDM_G = 4 utterances and takes it through all layers by
+ * itself in wave-private LDS: there is NO workgroup barrier in the loop. The round-1 kernel dealt the tiles of a layer
+ * to the 8 waves of a workgroup with a barrier between layers; all waves were then in the same phase at the same time
+ * (matrix pipe busy 27 % of the time, VALU 35 %, profiles/r02_cnn_phase_ablation_r1_kernel.txt), tile counts 13/35/15/3
+ * did not divide the waves and the dense + softmax stage ran on one wave. Independent waves drift apart, so the
+ * requantisation epilogue (VALU) of one wave runs under the MFMAs of its SIMD partner. Per group the column tiles are
+ * 52 / 140 / 60 / 12 / 4 columns in 2 / 5 / 2 / 1 / 1 tiles of 32 (167 MFMAs per 4 utterances against 133 before: the
+ * price of the independence). Logits are parked in LDS and the serial softmax / argmax runs once per 8 groups on 32
+ * lanes. Groups are handed out through a counter in LDS (ds_add_rtn_u32) as in the MFCC kernel.
+ * LDS: 61 KB of weight fragments + 8 waves x (4 x 2992 B activations + 512 B parked logits) = 157 KB.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "edison_internal.h"
 
-#define EDM_U 32
+#ifndef EDM_INTERLEAVE
+#define EDM_INTERLEAVE 1 /* 1: requantisation VALU is woven between the next tile's MFMAs (sched_group_barrier); 0: after them */
+#endif
+#define EDM_G 4       /* utterances per wavefront group */
 #define EDM_WAVES 8
 #define EDM_THREADS (64 * EDM_WAVES)
 #define EDM_REGA 1120 /* in' [31][16] (496)  ->  p2 [5][7][32] (1120)  ->  c4 [3][32] (96)   */
 #define EDM_REGB 1872 /* p1 [13][9][16] (1872)  ->  c3 [3][5][64] (960)                        */
 #define EDM_UTT (EDM_REGA + EDM_REGB)
+#define EDM_PARK 8    /* groups whose logits are parked before one softmax pass (8 x 4 = 32 lanes) */
+#define EDM_WAVE_LDS (EDM_G * EDM_UTT + EDM_PARK * EDM_G * 16 + 64)
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -43,17 +57,97 @@ __device__ __forceinline__ v4i edm_ld16(const unsigned char *p) { return *reinte
 
 __device__ __forceinline__ int edm_med3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-/* requantise 4 consecutive accumulators (+ their seeds) with ReLU and pack them into one HWC dword */
-__device__ __forceinline__ uint32_t edm_pack_relu(int a0, int a1, int a2, int a3, const int32_t *seed, int rs)
+/* requantise 4 consecutive accumulators with ReLU and pack them into one HWC dword. The accumulators already hold the
+ * seeds (bias << bias_lshift) + NN_ROUND(out_rshift): they are the C operand of each tile's first MFMA. */
+__device__ __forceinline__ uint32_t edm_pack_relu(int a0, int a1, int a2, int a3, int rs)
 {
-	const uint32_t b0 = (uint32_t)edm_med3((a0 + seed[0]) >> rs, 0, 127);
-	const uint32_t b1 = (uint32_t)edm_med3((a1 + seed[1]) >> rs, 0, 127);
-	const uint32_t b2 = (uint32_t)edm_med3((a2 + seed[2]) >> rs, 0, 127);
-	const uint32_t b3 = (uint32_t)edm_med3((a3 + seed[3]) >> rs, 0, 127);
+	const uint32_t b0 = (uint32_t)edm_med3(a0 >> rs, 0, 127);
+	const uint32_t b1 = (uint32_t)edm_med3(a1 >> rs, 0, 127);
+	const uint32_t b2 = (uint32_t)edm_med3(a2 >> rs, 0, 127);
+	const uint32_t b3 = (uint32_t)edm_med3(a3 >> rs, 0, 127);
 	return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
 }
 
+/* the accumulator tile that starts a 32-row output tile: D register r of lane half h is row (r&3) + 8*(r>>2) + 4*h, so
+ * register group g (4 registers) is rows 8*g + 4*h .. +3 */
+__device__ __forceinline__ v16i edm_seed_tile(const int32_t *seed4h)
+{
+	v16i c;
+#pragma unroll
+	for (int g = 0; g < 4; g++)
+	{
+		const v4i s = *reinterpret_cast<const v4i *>(seed4h + 8 * g);
+		c[4 * g] = s.x; c[4 * g + 1] = s.y; c[4 * g + 2] = s.z; c[4 * g + 3] = s.w;
+	}
+	return c;
+}
+
 __device__ __forceinline__ int edm_max(int a, int b) { return a > b ? a : b; }
+
+/* Weave: N times (1 MFMA, V VALU instructions) in the scheduling region that ends here. An MFMA holds vector issue for
+ * 8 of its 32 cycles, so ~5 VALU instructions fit under each one (guide: cycle constants); placed in one block after
+ * the MFMAs they would only start when the last MFMA has been issued. */
+#if EDM_INTERLEAVE
+#define EDM_WEAVE(N, V)                                                        \
+	_Pragma("unroll") for (int w_ = 0; w_ < (N); w_++)                           \
+	{                                                                           \
+		__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       \
+		__builtin_amdgcn_sched_group_barrier(0x002, (V), 0);                     \
+	}
+#define EDM_FENCE()
+#else
+#define EDM_WEAVE(N, V)
+#define EDM_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+/* The four packed dwords of a lane are channels 8g + 4h .. +3 (g = 0..3): 4-byte pieces, 8 bytes apart, interleaved with
+ * those of the lane 32 further up (h = 1). Stored one by one they hit LDS as ds_write_b32 at the pixel stride -- 8-way
+ * bank conflicts (55 % of all LDS cycles of the first version of this kernel, profiles/r02_cnn_counters.txt). Two
+ * v_permlane32_swap trade pieces between the two lane halves so that lane h = 0 holds bytes 0..15 of its pixel record and
+ * lane h = 1 bytes 16..31 (conv1: the record of the tile's second x position): one ds_write_b128 each. */
+__device__ __forceinline__ uint4 edm_gather16(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3)
+{
+	const auto r02 = __builtin_amdgcn_permlane32_swap(d0, d2, false, false); /* h0: d0(h0), d0(h1)   h1: d2(h0), d2(h1) */
+	const auto r13 = __builtin_amdgcn_permlane32_swap(d1, d3, false, false);
+	return make_uint4(r02[0], r02[1], r13[0], r13[1]);
+}
+
+/* Order this wave's LDS writes before its following LDS reads: DS instructions of a wave are issued and serviced in
+ * order, the (code-less) wave barrier only keeps the compiler from moving memory operations across. */
+__device__ __forceinline__ void edm_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
+/* The 13-byte feature rows of one group, one row per lane and pass (4 x 31 = 124 rows over 2 x 64 lanes), as 16 bytes with
+ * the 3 padding bytes zeroed. A row is read with ONE unaligned 16-byte load (gfx950 under HSA runs with unaligned access
+ * enabled; the compiler picks the instruction from the memcpy's alignment-1 source); only the very last row of the batch
+ * must not touch the 3 bytes behind it (they may lie beyond the allocation) and is read byte by byte. */
+__device__ __forceinline__ void edm_load_rows(const int8_t *feat, int64_t feat_stride, int64_t base, int nb, int64_t n_utt,
+                                              int lane, uint4 (&rows)[2])
+{
+#pragma unroll
+	for (int pass = 0; pass < 2; pass++)
+	{
+		const int r = lane + 64 * pass;
+		const int u = r / ED_IN_H, y = r - u * ED_IN_H;
+		uint4 d = make_uint4(0, 0, 0, 0);
+		if (r < EDM_G * ED_IN_H && u < nb)
+		{
+			const uint8_t *g = reinterpret_cast<const uint8_t *>(feat) + (base + u) * feat_stride + y * ED_IN_W;
+			if (base + u == n_utt - 1 && y == ED_IN_H - 1)
+			{
+				uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+				for (int j = 0; j < ED_IN_W; j++) w[j >> 2] |= (uint32_t)g[j] << (8 * (j & 3));
+				d = make_uint4(w[0], w[1], w[2], w[3]);
+			}
+			else
+			{
+				__builtin_memcpy(&d, g, 16);
+				d.w &= 0xffu; /* bytes 13..15 belong to the next row */
+			}
+		}
+		rows[pass] = d;
+	}
+}
 
 __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_mfma_model_t *__restrict__ model,
                                                                  const int8_t *__restrict__ feat, int64_t n_utt,
@@ -63,147 +157,256 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const ed_cnn_mfma_model_t &M = *reinterpret_cast<const ed_cnn_mfma_model_t *>(smem);
-	unsigned char *acts = smem + sizeof(ed_cnn_mfma_model_t);
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	unsigned char *acts = smem + sizeof(ed_cnn_mfma_model_t) + wave * EDM_WAVE_LDS; /* wave-private */
+	unsigned char *park = acts + EDM_G * EDM_UTT;                                     /* [EDM_PARK][EDM_G][16] logits */
+	int *park_group = reinterpret_cast<int *>(park + EDM_PARK * EDM_G * 16);          /* [EDM_PARK] group index      */
+	unsigned char *dummy = park + EDM_PARK * EDM_G * 16 + 32 + 16 * (lane >> 5);      /* where idle columns store: no branch */
+	unsigned *queue = reinterpret_cast<unsigned *>(smem + sizeof(ed_cnn_mfma_model_t) + EDM_WAVES * EDM_WAVE_LDS);
 
 	{ /* stage the weight fragments once per workgroup */
 		const v4i *src = reinterpret_cast<const v4i *>(model);
 		v4i *dst = reinterpret_cast<v4i *>(smem);
 		for (int i = threadIdx.x; i < (int)(sizeof(ed_cnn_mfma_model_t) / 16); i += EDM_THREADS) dst[i] = src[i];
+		if (threadIdx.x == 0) *queue = EDM_WAVES;
 	}
-	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	__syncthreads();
 	const int col = lane & 31, h = lane >> 5;
 	const unsigned char *afrag = reinterpret_cast<const unsigned char *>(&M) + lane * 16;
 	const int a1_off = (int)offsetof(ed_cnn_mfma_model_t, a1), a2_off = (int)offsetof(ed_cnn_mfma_model_t, a2);
 	const int a3_off = (int)offsetof(ed_cnn_mfma_model_t, a3), a4_off = (int)offsetof(ed_cnn_mfma_model_t, a4);
 	const int afc_off = (int)offsetof(ed_cnn_mfma_model_t, afc);
+	/* the output shifts live in scalar registers: read from LDS inside the epilogues they cost a wait per dword */
+	const int rs1 = __builtin_amdgcn_readfirstlane(M.rs1), rs2 = __builtin_amdgcn_readfirstlane(M.rs2);
+	const int rs3 = __builtin_amdgcn_readfirstlane(M.rs3), rs4 = __builtin_amdgcn_readfirstlane(M.rs4);
+	const int rsfc = __builtin_amdgcn_readfirstlane(M.rsfc);
 
-	for (int64_t base = (int64_t)blockIdx.x * EDM_U; base < n_utt; base += (int64_t)gridDim.x * EDM_U)
+	/* this workgroup's contiguous slice of the utterance groups; its waves draw from it */
+	const int64_t n_groups = (n_utt + EDM_G - 1) / EDM_G;
+	const int64_t g_lo = (int64_t)blockIdx.x * n_groups / gridDim.x;
+	const uint32_t cnt = (uint32_t)((int64_t)(blockIdx.x + 1) * n_groups / gridDim.x - g_lo);
+	int parked = 0;
+
+	/* the rows of a wave's next group are fetched while it works on the current one */
+	uint4 rows[2];
+	if ((uint32_t)wave < cnt)
 	{
-		const int nb = (int)((n_utt - base) < EDM_U ? (n_utt - base) : EDM_U);
-		__syncthreads(); /* previous iteration's dense stage has finished reading region A */
+		const int64_t b0 = (g_lo + wave) * EDM_G;
+		edm_load_rows(feat, feat_stride, b0, (int)((n_utt - b0) < EDM_G ? (n_utt - b0) : EDM_G), n_utt, lane, rows);
+	}
+	for (uint32_t idx = wave; idx < cnt;)
+	{
+		/* the group after this one: drawn now, its index is needed only after the input rows are in LDS */
+		uint32_t drawn = 0;
+		if (lane == 0) drawn = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 
 		/* ---- input: feat[u][31][13] -> in'[u][31][16] (3 zero bytes of padding per row) */
-		for (int r = threadIdx.x; r < EDM_U * ED_IN_H; r += EDM_THREADS)
-		{
-			const int u = r / ED_IN_H, y = r - u * ED_IN_H;
-			uint32_t d[4] = {0, 0, 0, 0};
-			if (u < nb)
-			{
-				const uint8_t *g = reinterpret_cast<const uint8_t *>(feat) + (base + u) * feat_stride + y * ED_IN_W;
 #pragma unroll
-				for (int j = 0; j < ED_IN_W; j++) d[j >> 2] |= (uint32_t)g[j] << (8 * (j & 3));
+		for (int pass = 0; pass < 2; pass++)
+		{
+			const int r = lane + 64 * pass;
+			if (r < EDM_G * ED_IN_H)
+			{
+				const int u = r / ED_IN_H, y = r - u * ED_IN_H;
+				*reinterpret_cast<uint4 *>(acts + u * EDM_UTT + y * 16) = rows[pass];
 			}
-			*reinterpret_cast<uint4 *>(acts + u * EDM_UTT + y * 16) = make_uint4(d[0], d[1], d[2], d[3]);
 		}
-		__syncthreads();
+		const uint32_t next = __builtin_amdgcn_readfirstlane(drawn);
+		if (next < cnt)
+		{
+			const int64_t bn = (g_lo + next) * EDM_G;
+			edm_load_rows(feat, feat_stride, bn, (int)((n_utt - bn) < EDM_G ? (n_utt - bn) : EDM_G), n_utt, lane, rows);
+		}
+		edm_wave_sync();
 
 		/* ---- conv1 5x5x1->16 + ReLU + pool(2,1): Toeplitz GEMM, 144 rows (x,o) x 80 k (5 padded input rows).
-		 *      columns = (utt, pooled row py): 32 x 13 = 13 column tiles; two accumulators = input rows 2py / 2py+1 */
-		for (int t = wave; t < 13; t += EDM_WAVES)
+		 *      columns = (utt, pooled row py): 4 x 13 = 52 in 2 column tiles; two accumulators = input rows 2py / 2py+1 */
 		{
-			const int q = t * 32 + col, u = q / 13, py = q - u * 13;
-			const unsigned char *inb = acts + u * EDM_UTT + (2 * py) * 16;
-			v4i be[3], bo[3];
-#pragma unroll
-			for (int s = 0; s < 3; s++)
+			/* rows of a conv1 tile are (x, o): register group g holds channels 8*(g&1) + 4h .. +3 of x = 2 rt + (g >> 1) */
+			v16i seed1;
 			{
-				const int c = (2 * s + h) < 4 ? (2 * s + h) : 4; /* k-chunk = input row y + c; chunk 5 meets zero weights */
-				be[s] = edm_ld16(inb + c * 16);
-				bo[s] = edm_ld16(inb + (c + 1) * 16);
+				const v4i s0 = *reinterpret_cast<const v4i *>(&M.b1[4 * h]), s1 = *reinterpret_cast<const v4i *>(&M.b1[8 + 4 * h]);
+				seed1[0] = s0.x; seed1[1] = s0.y; seed1[2] = s0.z; seed1[3] = s0.w; seed1[4] = s1.x; seed1[5] = s1.y; seed1[6] = s1.z; seed1[7] = s1.w;
+				seed1[8] = s0.x; seed1[9] = s0.y; seed1[10] = s0.z; seed1[11] = s0.w; seed1[12] = s1.x; seed1[13] = s1.y; seed1[14] = s1.z; seed1[15] = s1.w;
 			}
-			unsigned char *p1 = acts + u * EDM_UTT + EDM_REGA + (py * 9) * 16;
+			/* the 15 weight fragments stay in registers for both column tiles: the MFMA stream then never waits for LDS */
+			v4i A1[15];
+#pragma unroll
+			for (int i = 0; i < 15; i++) A1[i] = edm_ld16(afrag + a1_off + i * 1024);
 #pragma unroll 1
-			for (int rt = 0; rt < 5; rt++)
+			for (int t = 0; t < 2; t++)
 			{
-				v16i ae = {0}, ao = {0};
+				const int q = t * 32 + col;
+				const bool live = q < EDM_G * 13;
+				const int qq = live ? q : EDM_G * 13 - 1; /* idle columns recompute the last one and store nothing */
+				const int u = qq / 13, py = qq - u * 13;
+				const unsigned char *inb = acts + u * EDM_UTT + (2 * py) * 16;
+				v4i be[3], bo[3];
 #pragma unroll
 				for (int s = 0; s < 3; s++)
 				{
-					const v4i a = edm_ld16(afrag + a1_off + (rt * 3 + s) * 1024);
-					ae = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, be[s], ae, 0, 0, 0);
-					ao = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bo[s], ao, 0, 0, 0);
+					const int c = (2 * s + h) < 4 ? (2 * s + h) : 4; /* k-chunk = input row y + c; chunk 5 meets zero weights */
+					be[s] = edm_ld16(inb + c * 16);
+					bo[s] = edm_ld16(inb + (c + 1) * 16);
 				}
+				unsigned char *p1 = acts + u * EDM_UTT + EDM_REGA + (py * 9) * 16;
+				/* software pipeline: the MFMAs of row tile rt + 1 are issued BEFORE the requantisation of row tile rt, so
+				 * that VALU work runs while the matrix pipe is busy (an MFMA blocks vector issue for 8 of its 32 cycles) */
+				v16i ae[2], ao[2];
+				auto issue = [&](int rt, int slot) {
+					ae[slot] = seed1; ao[slot] = seed1;
 #pragma unroll
-				for (int g = 0; g < 4; g++)
+					for (int s = 0; s < 3; s++)
+					{
+						ae[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1[rt * 3 + s], be[s], ae[slot], 0, 0, 0);
+						ao[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1[rt * 3 + s], bo[s], ao[slot], 0, 0, 0);
+					}
+				};
+				issue(0, 0);
+#pragma unroll
+				for (int rt = 0; rt < 5; rt++)
 				{
-					const int x = 2 * rt + (g >> 1), o0 = 4 * h + 8 * (g & 1);
-					if (x < 9)
-						*reinterpret_cast<uint32_t *>(p1 + x * 16 + o0) =
-						    edm_pack_relu(edm_max(ae[4 * g], ao[4 * g]), edm_max(ae[4 * g + 1], ao[4 * g + 1]),
-						                  edm_max(ae[4 * g + 2], ao[4 * g + 2]), edm_max(ae[4 * g + 3], ao[4 * g + 3]),
-						                  &M.b1[o0], M.rs1);
+					if (rt + 1 < 5) issue(rt + 1, (rt + 1) & 1);
+					EDM_FENCE();
+					const v16i &e = ae[rt & 1], &o = ao[rt & 1];
+					uint32_t d[4];
+#pragma unroll
+					for (int g = 0; g < 4; g++)
+						d[g] = edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
+						                     edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs1);
+					/* groups 0, 1 are channels 4h.. and 8+4h.. of x = 2 rt, groups 2, 3 the same of x = 2 rt + 1: after the
+					 * exchange lane half h owns the whole 16-byte record of x = 2 rt + h */
+					const uint4 rec = edm_gather16(d[0], d[1], d[2], d[3]);
+					*reinterpret_cast<uint4 *>((2 * rt + h < 9 && live) ? p1 + (2 * rt + h) * 16 : dummy) = rec;
+					if (rt + 1 < 5) { EDM_WEAVE(6, 13) }
+					__builtin_amdgcn_sched_barrier(0);
 				}
 			}
 		}
-		__syncthreads();
+		edm_wave_sync();
 
 		/* ---- conv2 3x3x16->32 + ReLU + pool(2,1): K = 9 taps x 16 ch (5 k-steps of 2 taps); columns =
-		 *      (utt, py, x): 32 x 35 = 35 column tiles; two accumulators = conv rows 2py / 2py+1 */
-		for (int t = wave; t < 35; t += EDM_WAVES)
+		 *      (utt, py, x): 4 x 35 = 140 in 5 column tiles; two accumulators = conv rows 2py / 2py+1 */
 		{
-			const int q = t * 32 + col, u = q / 35, r = q - u * 35, py = r / 7, x = r - py * 7;
-			const unsigned char *p1 = acts + u * EDM_UTT + EDM_REGA + ((2 * py) * 9 + x) * 16;
-			v16i ae = {0}, ao = {0};
+			const v16i seed2 = edm_seed_tile(&M.b2[4 * h]);
+			/* three-stage software pipeline per column tile: fetch (LDS reads of the B fragments) two tiles ahead, MFMAs
+			 * one tile ahead, requantisation of the current tile -- the matrix pipe never waits for LDS and the VALU work
+			 * runs under the MFMAs. The 5 weight fragments stay in registers. */
+			v4i A2[5];
 #pragma unroll
-			for (int s = 0; s < 5; s++)
-			{
-				const int tap = (2 * s + h) < 8 ? (2 * s + h) : 8; /* tap 9 meets zero weights */
-				const int ky = tap / 3, kx = tap - 3 * ky;
-				const v4i a = edm_ld16(afrag + a2_off + s * 1024);
-				const v4i b0 = edm_ld16(p1 + (ky * 9 + kx) * 16);
-				const v4i b1 = edm_ld16(p1 + ((ky + 1) * 9 + kx) * 16);
-				ae = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, ae, 0, 0, 0);
-				ao = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, ao, 0, 0, 0);
-			}
-			unsigned char *p2 = acts + u * EDM_UTT + (py * 7 + x) * 32;
+			for (int i = 0; i < 5; i++) A2[i] = edm_ld16(afrag + a2_off + i * 1024);
+			v4i B0[2][5], B1[2][5];
+			v16i ae[2], ao[2];
+			unsigned char *p2[3];
+			bool live[3];
+			auto fetch = [&](int t) {
+				const int q = t * 32 + col;
+				live[t % 3] = q < EDM_G * 35;
+				const int qq = live[t % 3] ? q : EDM_G * 35 - 1;
+				const int u = qq / 35, r = qq - u * 35, py = r / 7, x = r - py * 7;
+				const unsigned char *p1 = acts + u * EDM_UTT + EDM_REGA + ((2 * py) * 9 + x) * 16;
+				p2[t % 3] = acts + u * EDM_UTT + (py * 7 + x) * 32;
 #pragma unroll
-			for (int g = 0; g < 4; g++)
+				for (int s = 0; s < 5; s++)
+				{
+					const int tap = (2 * s + h) < 8 ? (2 * s + h) : 8; /* tap 9 meets zero weights */
+					const int ky = tap / 3, kx = tap - 3 * ky;
+					B0[t & 1][s] = edm_ld16(p1 + (ky * 9 + kx) * 16);
+					B1[t & 1][s] = edm_ld16(p1 + ((ky + 1) * 9 + kx) * 16);
+				}
+			};
+			auto mma = [&](int t) {
+				ae[t & 1] = seed2; ao[t & 1] = seed2;
+#pragma unroll
+				for (int s = 0; s < 5; s++)
+				{
+					ae[t & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A2[s], B0[t & 1][s], ae[t & 1], 0, 0, 0);
+					ao[t & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A2[s], B1[t & 1][s], ao[t & 1], 0, 0, 0);
+				}
+			};
+			fetch(0); fetch(1);
+			mma(0);
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int t = 0; t < 5; t++)
 			{
-				const int o0 = 8 * g + 4 * h;
-				*reinterpret_cast<uint32_t *>(p2 + o0) =
-				    edm_pack_relu(edm_max(ae[4 * g], ao[4 * g]), edm_max(ae[4 * g + 1], ao[4 * g + 1]),
-				                  edm_max(ae[4 * g + 2], ao[4 * g + 2]), edm_max(ae[4 * g + 3], ao[4 * g + 3]), &M.b2[o0],
-				                  M.rs2);
+				if (t + 1 < 5) mma(t + 1);
+				EDM_FENCE();
+				if (t + 2 < 5) fetch(t + 2); /* into the fragment registers tile t's MFMAs have consumed */
+				const v16i &e = ae[t & 1], &o = ao[t & 1];
+				{
+					uint32_t d[4];
+#pragma unroll
+					for (int g = 0; g < 4; g++)
+						d[g] = edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
+						                     edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs2);
+					const uint4 rec = edm_gather16(d[0], d[1], d[2], d[3]); /* channels 16h .. 16h + 15 */
+					*reinterpret_cast<uint4 *>(live[t % 3] ? p2[t % 3] + 16 * h : dummy) = rec;
+				}
+				if (t + 1 < 5) { EDM_WEAVE(10, 7) }
+				__builtin_amdgcn_sched_barrier(0);
 			}
 		}
-		__syncthreads();
+		edm_wave_sync();
 
-		/* ---- conv3 3x3x32->64 + ReLU: 9 k-steps (tap, 16-channel half); columns = (utt, y, x): 32 x 15 = 15
+		/* ---- conv3 3x3x32->64 + ReLU: 9 k-steps (tap, 16-channel half); columns = (utt, y, x): 4 x 15 = 60 in 2
 		 *      column tiles; two accumulators = output channels 0-31 / 32-63 */
-		for (int t = wave; t < 15; t += EDM_WAVES)
 		{
-			const int q = t * 32 + col, u = q / 15, r = q - u * 15, y = r / 5, x = r - y * 5;
-			const unsigned char *p2 = acts + u * EDM_UTT + (y * 7 + x) * 32 + 16 * h;
-			v16i a0 = {0}, a1 = {0};
+			const v16i seed3a = edm_seed_tile(&M.b3[4 * h]), seed3b = edm_seed_tile(&M.b3[32 + 4 * h]);
+			v16i a0[2], a1[2];
+			unsigned char *c3[2];
+			bool live[2];
+			auto issue = [&](int t, int slot) {
+				const int q = t * 32 + col;
+				live[slot] = q < EDM_G * 15;
+				const int qq = live[slot] ? q : EDM_G * 15 - 1;
+				const int u = qq / 15, r = qq - u * 15, y = r / 5, x = r - y * 5;
+				const unsigned char *p2 = acts + u * EDM_UTT + (y * 7 + x) * 32 + 16 * h;
+				c3[slot] = acts + u * EDM_UTT + EDM_REGA + (y * 5 + x) * 64;
+				a0[slot] = seed3a; a1[slot] = seed3b;
 #pragma unroll
-			for (int s = 0; s < 9; s++)
-			{
-				const int ky = s / 3, kx = s - 3 * ky;
-				const v4i b = edm_ld16(p2 + (ky * 7 + kx) * 32);
-				a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(edm_ld16(afrag + a3_off + s * 1024), b, a0, 0, 0, 0);
-				a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(edm_ld16(afrag + a3_off + (9 + s) * 1024), b, a1, 0, 0, 0);
-			}
-			unsigned char *c3 = acts + u * EDM_UTT + EDM_REGA + (y * 5 + x) * 64;
+				for (int s = 0; s < 9; s++)
+				{
+					const int ky = s / 3, kx = s - 3 * ky;
+					const v4i b = edm_ld16(p2 + (ky * 7 + kx) * 32);
+					a0[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(edm_ld16(afrag + a3_off + s * 1024), b, a0[slot], 0, 0, 0);
+					a1[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(edm_ld16(afrag + a3_off + (9 + s) * 1024), b, a1[slot], 0, 0, 0);
+				}
+			};
+			issue(0, 0);
 #pragma unroll
-			for (int g = 0; g < 4; g++)
+			for (int t = 0; t < 2; t++)
 			{
-				const int o0 = 8 * g + 4 * h;
-				*reinterpret_cast<uint32_t *>(c3 + o0) =
-				    edm_pack_relu(a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3], &M.b3[o0], M.rs3);
-				*reinterpret_cast<uint32_t *>(c3 + 32 + o0) =
-				    edm_pack_relu(a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3], &M.b3[32 + o0], M.rs3);
+				if (t + 1 < 2) issue(t + 1, (t + 1) & 1);
+				EDM_FENCE();
+				const v16i &x0 = a0[t & 1], &x1 = a1[t & 1];
+				{
+					uint32_t d0[4], d1[4];
+#pragma unroll
+					for (int g = 0; g < 4; g++)
+					{
+						d0[g] = edm_pack_relu(x0[4 * g], x0[4 * g + 1], x0[4 * g + 2], x0[4 * g + 3], rs3);
+						d1[g] = edm_pack_relu(x1[4 * g], x1[4 * g + 1], x1[4 * g + 2], x1[4 * g + 3], rs3);
+					}
+					const uint4 ra = edm_gather16(d0[0], d0[1], d0[2], d0[3]), rb = edm_gather16(d1[0], d1[1], d1[2], d1[3]);
+					*reinterpret_cast<uint4 *>(live[t & 1] ? c3[t & 1] + 16 * h : dummy) = ra;      /* channels 16h .. */
+					*reinterpret_cast<uint4 *>(live[t & 1] ? c3[t & 1] + 32 + 16 * h : dummy) = rb; /* channels 32 + 16h .. */
+				}
+				if (t + 1 < 2) { EDM_WEAVE(18, 6) }
+				__builtin_amdgcn_sched_barrier(0);
 			}
 		}
-		__syncthreads();
+		edm_wave_sync();
 
 		/* ---- conv4 3x3x64->32 + ReLU: 18 k-steps (tap, 32-channel half, 16-channel lane half); columns =
-		 *      (utt, x): 32 x 3 = 3 column tiles */
-		for (int t = wave; t < 3; t += EDM_WAVES)
+		 *      (utt, x): 4 x 3 = 12 in one column tile */
 		{
-			const int q = t * 32 + col, u = q / 3, x = q - u * 3;
+			const bool live = col < EDM_G * 3;
+			const int qq = live ? col : EDM_G * 3 - 1;
+			const int u = qq / 3, x = qq - u * 3;
 			const unsigned char *c3 = acts + u * EDM_UTT + EDM_REGA + x * 64 + 16 * h;
-			v16i acc = {0};
+			v16i acc = edm_seed_tile(&M.b4[4 * h]);
 #pragma unroll
 			for (int s = 0; s < 18; s++)
 			{
@@ -212,80 +415,99 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 				acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(edm_ld16(afrag + a4_off + s * 1024), b, acc, 0, 0, 0);
 			}
 			unsigned char *c4 = acts + u * EDM_UTT + x * 32;
-#pragma unroll
-			for (int g = 0; g < 4; g++)
 			{
-				const int o0 = 8 * g + 4 * h;
-				*reinterpret_cast<uint32_t *>(c4 + o0) =
-				    edm_pack_relu(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], &M.b4[o0], M.rs4);
+				uint32_t d[4];
+#pragma unroll
+				for (int g = 0; g < 4; g++) d[g] = edm_pack_relu(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], rs4);
+				const uint4 rec = edm_gather16(d[0], d[1], d[2], d[3]);
+				if (live) *reinterpret_cast<uint4 *>(c4 + 16 * h) = rec;
 			}
 		}
-		__syncthreads();
+		edm_wave_sync();
 
-		/* ---- dense 96->10, softmax, argmax: one column tile (column = utterance), wave 0 */
-		if (wave == 0)
+		/* ---- dense 96->10: one column tile, column = utterance (4 live). Lane (utt, h) holds logits 4h..4h+3 in
+		 *      registers 0-3 and 8+4h.. in registers 4-7 (only rows 8, 9 exist): parked as 10 int8 per utterance */
 		{
-			const unsigned char *c4 = acts + col * EDM_UTT + 16 * h;
+			const int uu = col < EDM_G ? col : EDM_G - 1;
+			const unsigned char *c4 = acts + uu * EDM_UTT + 16 * h;
 			v16i acc = {0};
 #pragma unroll
 			for (int s = 0; s < 3; s++)
 				acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(edm_ld16(afrag + afc_off + s * 1024), edm_ld16(c4 + 32 * s), acc, 0, 0, 0);
-			/* lane (utt, h) holds rows 4h..4h+3 in regs 0-3 and rows 8+4h.. in regs 4-7 (only rows 8, 9 exist) */
-			int lg[10];
-			int mine[4], hi2[2];
-#pragma unroll
-			for (int i = 0; i < 4; i++)
+			if (col < EDM_G)
 			{
-				const int v = (acc[i] + M.bfc[4 * h + i]) >> M.rsfc;
-				mine[i] = edm_med3(v, -128, 127);
-			}
+				uint32_t w = 0;
 #pragma unroll
-			for (int i = 0; i < 2; i++) hi2[i] = edm_med3((acc[4 + i] + M.bfc[8 + i]) >> M.rsfc, -128, 127);
-#pragma unroll
-			for (int i = 0; i < 4; i++)
-			{
-				const int other = __shfl(mine[i], col + 32); /* rows 4..7 live in the upper half-wave */
-				lg[i] = mine[i];
-				lg[4 + i] = other;
-			}
-			lg[8] = hi2[0]; lg[9] = hi2[1];
-			if (h == 0 && col < nb)
-			{
-				/* arm_softmax_q7 (portable branch) and nnom_predict's first-maximum rule */
-				int mx = -128;
-#pragma unroll
-				for (int i = 0; i < 10; i++) mx = lg[i] > mx ? lg[i] : mx;
-				const int sbase = mx - 8;
-				int sum = 0;
-#pragma unroll
-				for (int i = 0; i < 10; i++) sum += 1 << edm_med3(lg[i] - sbase, 0, 7);
-				const int output_base = (1 << 20) / sum;
-				int best = 0, bv = -129;
-				uint32_t lw[3] = {0, 0, 0}, sw[3] = {0, 0, 0};
-#pragma unroll
-				for (int i = 0; i < 10; i++)
+				for (int i = 0; i < 4; i++)
+					w |= (uint32_t)(uint8_t)edm_med3((acc[i] + M.bfc[4 * h + i]) >> rsfc, -128, 127) << (8 * i);
+				unsigned char *slot = park + (parked * EDM_G + col) * 16;
+				*reinterpret_cast<uint32_t *>(slot + 4 * h) = w;          /* logits 0-3 (h = 0) / 4-7 (h = 1) */
+				if (h == 0)
 				{
-					const int v = edm_med3(output_base >> edm_med3(13 + sbase - lg[i], 0, 31), -128, 127);
-					if (v > bv) { bv = v; best = i; }
-					lw[i >> 2] |= (uint32_t)(uint8_t)lg[i] << (8 * (i & 3));
-					sw[i >> 2] |= (uint32_t)(uint8_t)v << (8 * (i & 3));
+					uint32_t w2 = 0;
+#pragma unroll
+					for (int i = 0; i < 2; i++)
+						w2 |= (uint32_t)(uint8_t)edm_med3((acc[4 + i] + M.bfc[8 + i]) >> rsfc, -128, 127) << (8 * i);
+					*reinterpret_cast<uint32_t *>(slot + 8) = w2;         /* logits 8, 9 */
 				}
-				const int64_t uo = (base + col) * ED_FC_O; /* 10-byte records: 2-byte aligned */
-				if (logits)
-				{
-					uint16_t *p = reinterpret_cast<uint16_t *>(logits + uo);
-					p[0] = (uint16_t)lw[0]; p[1] = (uint16_t)(lw[0] >> 16); p[2] = (uint16_t)lw[1];
-					p[3] = (uint16_t)(lw[1] >> 16); p[4] = (uint16_t)lw[2];
-				}
-				if (softmax)
-				{
-					uint16_t *p = reinterpret_cast<uint16_t *>(softmax + uo);
-					p[0] = (uint16_t)sw[0]; p[1] = (uint16_t)(sw[0] >> 16); p[2] = (uint16_t)sw[1];
-					p[3] = (uint16_t)(sw[1] >> 16); p[4] = (uint16_t)sw[2];
-				}
-				if (argmax) argmax[base + col] = best;
 			}
+			if (lane == 0) park_group[parked] = (int)idx;
+			parked++;
 		}
+		edm_wave_sync();
+
+		/* ---- softmax + argmax + stores for the parked utterances: every EDM_PARK groups, and after the wave's last */
+		if (parked == EDM_PARK || next >= cnt)
+		{
+			const int slot = lane >> 2, u = lane & 3; /* lanes 0..31 */
+			if (lane < EDM_PARK * EDM_G && slot < parked)
+			{
+				const int64_t utt = (g_lo + park_group[slot]) * EDM_G + u;
+				if (utt < n_utt)
+				{
+					const uint4 raw = *reinterpret_cast<const uint4 *>(park + (slot * EDM_G + u) * 16);
+					const uint32_t lw[3] = {raw.x, raw.y, raw.z};
+					int lg[10];
+#pragma unroll
+					for (int i = 0; i < 10; i++) lg[i] = (int)(int8_t)(lw[i >> 2] >> (8 * (i & 3)));
+					/* arm_softmax_q7 (portable branch) and nnom_predict's first-maximum rule */
+					int mx = -128;
+#pragma unroll
+					for (int i = 0; i < 10; i++) mx = lg[i] > mx ? lg[i] : mx;
+					const int sbase = mx - 8;
+					int sum = 0;
+#pragma unroll
+					for (int i = 0; i < 10; i++) sum += 1 << edm_med3(lg[i] - sbase, 0, 7);
+					const int output_base = (1 << 20) / sum;
+					int best = 0, bv = -129;
+					uint32_t sw[3] = {0, 0, 0};
+#pragma unroll
+					for (int i = 0; i < 10; i++)
+					{
+						const int v = edm_med3(output_base >> edm_med3(13 + sbase - lg[i], 0, 31), -128, 127);
+						if (v > bv) { bv = v; best = i; }
+						sw[i >> 2] |= (uint32_t)(uint8_t)v << (8 * (i & 3));
+					}
+					const int64_t uo = utt * ED_FC_O; /* 10-byte records: 2-byte aligned */
+					if (logits)
+					{
+						uint16_t *p = reinterpret_cast<uint16_t *>(logits + uo);
+						p[0] = (uint16_t)lw[0]; p[1] = (uint16_t)(lw[0] >> 16); p[2] = (uint16_t)lw[1];
+						p[3] = (uint16_t)(lw[1] >> 16); p[4] = (uint16_t)lw[2];
+					}
+					if (softmax)
+					{
+						uint16_t *p = reinterpret_cast<uint16_t *>(softmax + uo);
+						p[0] = (uint16_t)sw[0]; p[1] = (uint16_t)(sw[0] >> 16); p[2] = (uint16_t)sw[1];
+						p[3] = (uint16_t)(sw[1] >> 16); p[4] = (uint16_t)sw[2];
+					}
+					if (argmax) argmax[utt] = best;
+				}
+			}
+			parked = 0;
+			edm_wave_sync();
+		}
+		idx = next;
 	}
 }
 
@@ -298,7 +520,7 @@ extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const in
                                   hipStream_t stream)
 {
 	if (n_utt <= 0) return 0;
-	const size_t lds = sizeof(ed_cnn_mfma_model_t) + (size_t)EDM_U * EDM_UTT;
+	const size_t lds = sizeof(ed_cnn_mfma_model_t) + (size_t)EDM_WAVES * EDM_WAVE_LDS + 16 /* queue */;
 	if (!g_cnn_mfma_ready)
 	{
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ed_cnn_mfma_kernel),
@@ -306,7 +528,8 @@ extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const in
 		if (e != hipSuccess) return (int)e;
 		g_cnn_mfma_ready = 1;
 	}
-	int64_t blocks = (n_utt + EDM_U - 1) / EDM_U;
+	const int64_t n_groups = (n_utt + EDM_G - 1) / EDM_G;
+	int64_t blocks = (n_groups + EDM_WAVES - 1) / EDM_WAVES;
 	if (blocks > n_cu) blocks = n_cu; /* 157 KB of LDS: one workgroup per CU */
 	hipLaunchKernelGGL(ed_cnn_mfma_kernel, dim3((unsigned)blocks), dim3(EDM_THREADS), lds, stream, dev_model, feat, n_utt,
 	                   feat_stride, logits, softmax, argmax);
