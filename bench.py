@@ -342,9 +342,39 @@ def main():
         soft = torch.empty((nu, 10), dtype=torch.int8, device=dev)
         am = torch.empty((nu,), dtype=torch.int32, device=dev)
         feat = torch.empty((nu, 403), dtype=torch.int8, device=dev)
-        gather = parallel.LogitsGatherer(nu, 10, device=dev) if world > 1 else None
+        # N > 1: the collective runs behind the C-ABI (edison_kws_batch_sharded_dev -> ncclAllGather on the context's
+        # stream); torch.distributed only carries the 128-byte communicator id. The result of the first step is checked
+        # against torch's own all_gather_into_tensor; if the C path cannot be set up on every rank the bench falls back
+        # to the torch collective and says so in config.collective.
+        gather, logits_all, collective = None, None, "none"
+        if world > 1:
+            gather = parallel.LogitsGatherer(nu, 10, device=dev)
+            collective = "all_gather int8 logits (RCCL via torch.distributed)"
+            ok = torch.ones(1, dtype=torch.int32, device=dev)
+            try:
+                parallel.dist_unique_id()              # local probe: can this rank bind RCCL at all?
+            except Exception:
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                parallel.init_context_comm(ctx, rank, world, dev)
+                logits_all = torch.empty((world * nu, 10), dtype=torch.int8, device=dev)
+                ctx.kws_sharded_t(audio, nu, 31 * 1024, logits_all, feat=feat, logits=logits, softmax=soft, argmax=am)
+                ref_all = gather(logits).clone()
+                torch.cuda.synchronize()
+                same = torch.tensor([1 if torch.equal(ref_all, logits_all) else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                if int(same.item()) == 1:
+                    collective = "all_gather int8 logits: ncclAllGather behind the C-ABI (edison_kws_batch_sharded_dev), verified against torch.distributed"
+                else:
+                    logits_all = None
+                    collective += " [C-ABI gather disagreed with torch's on the first step: not used]"
+                del ref_all
 
         def kws_step(i):
+            if logits_all is not None:
+                ctx.kws_sharded_t(audio, nu, 31 * 1024, logits_all, feat=feat, logits=logits, softmax=soft, argmax=am)
+                return
             ctx.kws_t(audio, nu, 31 * 1024, feat=feat, logits=logits, softmax=soft, argmax=am)
             if gather is not None:
                 gather(logits)
@@ -357,7 +387,7 @@ def main():
         kws = dict(metric="KWS inferences/sec (whole node)", value=round(inf_per_s, 1), unit="inferences/s",
                    mfcc_frames_per_s=round(inf_per_s * 31, 1), ms_per_step=round(kw_ms, 4),
                    config=dict(workload="kws_full_%d_utt_per_gpu_x31_frames_mfccB_int8cnn" % nu, global_batch=world * nu,
-                               collective="all_gather int8 logits (RCCL)" if world > 1 else "none"),
+                               collective=collective),
                    roofline=dict(bound="hbm", kernel="ed_mfcc2_kernel<true, 2, 5> + ed_cnn_mfma_kernel", achieved=round(kach, 1),
                                  peak=HBM_PEAK_GBS, unit="GB/s", frac=round(kach / HBM_PEAK_GBS, 4), traffic=None,
                                  bytes_per_unit=KWS_BYTES_PER_UTT, units_per_launch=nu, kernel_ms=round(kev_ms, 4)),
@@ -366,7 +396,9 @@ def main():
             # the same utterances with the firmware's own features (variant C): what the board would answer, at GPU speed
             def kws_q15_step(i):
                 ctx.kws_t(audio, nu, 31 * 1024, feat=feat, logits=logits, softmax=soft, argmax=am, q15=True)
-                if gather is not None:
+                if logits_all is not None:
+                    ctx.allgather_logits_t(logits, nu, logits_all)
+                elif gather is not None:
                     gather(logits)
             qsteps = max(5, args.steps // 5)
             kq_ms, _ = timed_region(kws_q15_step, qsteps, min(args.warmup, 3), world)

@@ -16,6 +16,7 @@ E_RUNTIME, E_NO_IMPL, E_NO_DEVICE, E_NO_MODEL = -16, -17, -18, -19
 MFCC_A, MFCC_B, MFCC_C, MFCC_USE_LOG = 0, 1, 2, 0x100
 
 FS, FRAME_LEN, NUM_MEL, NUM_MFCC, UTT_FRAMES, NET_IN, NET_OUT = 16000, 1024, 32, 13, 31, 403, 10
+DIST_ID_BYTES = 128
 CNN_ACT_BYTES = 10420
 
 c_void_p, c_int, c_int64, c_size_t, c_float, c_double, c_char_p = (
@@ -63,6 +64,13 @@ SIGNATURES = {
     "edison_net_layers_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "edison_net_batch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "edison_net_layers": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "edison_dist_unique_id": (c_int, [c_void_p]),
+    "edison_dist_init": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "edison_dist_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "edison_dist_shutdown": (c_int, [c_void_p]),
+    "edison_dist_shard_range": (c_int, [c_int64, c_int, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
+    "edison_dist_allgather_logits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "edison_kws_batch_sharded_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "edison_dev_alloc": (c_int, [c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
     "edison_dev_free": (c_int, [c_void_p, c_void_p]),
     "edison_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),

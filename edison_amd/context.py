@@ -254,6 +254,26 @@ class Context:
         self._check(fn(self._h, _t_ptr(audio), int(n_utt), int(utt_stride), _t_ptr(feat), _t_ptr(logits),
                        _t_ptr(softmax), _t_ptr(argmax)))
 
+    # ------------------------------------------------------------------ multi-GPU (edison_dist_*: RCCL behind the C-ABI)
+    def dist_init(self, id_bytes, rank, world_size):
+        buf = ctypes.create_string_buffer(bytes(id_bytes), _lib.DIST_ID_BYTES)
+        self._check(self._L.edison_dist_init(self._h, ctypes.cast(buf, ctypes.c_void_p), int(rank), int(world_size)))
+
+    def dist_info(self):
+        r, w = ctypes.c_int(), ctypes.c_int()
+        self._check(self._L.edison_dist_info(self._h, ctypes.byref(r), ctypes.byref(w)))
+        return r.value, w.value
+
+    def dist_shutdown(self):
+        self._check(self._L.edison_dist_shutdown(self._h))
+
+    def allgather_logits_t(self, local_logits, n_local, out):
+        self._check(self._L.edison_dist_allgather_logits(self._h, _t_ptr(local_logits), int(n_local), _t_ptr(out)))
+
+    def kws_sharded_t(self, audio, n_local, utt_stride, logits_all, feat=None, logits=None, softmax=None, argmax=None):
+        self._check(self._L.edison_kws_batch_sharded_dev(self._h, _t_ptr(audio), int(n_local), int(utt_stride), _t_ptr(feat),
+                                                         _t_ptr(logits), _t_ptr(softmax), _t_ptr(argmax), _t_ptr(logits_all)))
+
     def mfcc_q15_t(self, audio, n_frames, frame_step=FRAME_LEN, n_coef=NUM_MFCC, out=None, feat=None):
         """audio: int16 CUDA tensor; out: int16 [n_frames, n_coef] CUDA tensor or None; feat: int8 or None."""
         self._check(self._L.edison_mfcc_q15_batch_dev(self._h, _t_ptr(audio), int(n_frames), int(frame_step), int(n_coef),

@@ -53,6 +53,9 @@ struct edison_ctx
 	/* growable device scratch for the host-pointer entry points and the fused KWS path */
 	void *scratch;
 	size_t scratch_bytes;
+	/* multi-GPU (edison_dist.hip): the RCCL communicator this context belongs to, NULL for a single-GPU context */
+	void *dist_comm;
+	int dist_rank, dist_world;
 	char err[512];
 };
 

@@ -123,6 +123,7 @@ extern "C" void edison_shutdown(edison_ctx *ctx)
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	(void)hipDeviceSynchronize();
+	(void)edison_dist_shutdown(ctx);
 	for (int v = 0; v < 2; v++) if (ctx->d_tab[v]) (void)hipFree(ctx->d_tab[v]);
 	if (ctx->d_q15) (void)hipFree(ctx->d_q15);
 	if (ctx->d_model) (void)hipFree(ctx->d_model);

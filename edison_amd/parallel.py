@@ -43,6 +43,41 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+def dist_unique_id():
+    """128 opaque bytes from rank 0's RCCL (edison_dist_unique_id); every rank needs the same ones for dist_init."""
+    import ctypes
+    from . import _lib
+    buf = ctypes.create_string_buffer(_lib.DIST_ID_BYTES)
+    r = _lib.lib().edison_dist_unique_id(ctypes.cast(buf, ctypes.c_void_p))
+    if r != _lib.OK:
+        raise _lib.EdisonError(r, "edison_dist_unique_id failed (is RCCL installed? EDISON_RCCL_LIB)")
+    return buf.raw
+
+
+def init_context_comm(ctx, rank, world, device):
+    """Join `ctx` to a communicator of its own behind the C-ABI: rank 0 creates the id, torch.distributed (whatever
+    backend is up: gloo or nccl) carries the 128 bytes to the other ranks -- that is all torch does for this path."""
+    if world == 1:
+        return
+    payload = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        payload = torch.frombuffer(bytearray(dist_unique_id()), dtype=torch.uint8).clone()
+    payload = payload.to(device) if dist.get_backend() == "nccl" else payload
+    dist.broadcast(payload, src=0)
+    ctx.dist_init(bytes(payload.cpu().numpy().tobytes()), rank, world)
+
+
+def shard_range_c(n_items, rank, world_size):
+    """edison_dist_shard_range: the C-ABI's copy of shard_range (the two must agree: tests/test_distributed_cpu.py)."""
+    import ctypes
+    from . import _lib
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    r = _lib.lib().edison_dist_shard_range(int(n_items), int(rank), int(world_size), ctypes.byref(lo), ctypes.byref(hi))
+    if r != _lib.OK:
+        raise ValueError("bad shard request")
+    return lo.value, hi.value
+
+
 class LogitsGatherer:
     """Pre-allocated all-gather of equal-sized logit shards ([n_local, 10] int8 -> [world*n_local, 10])."""
 

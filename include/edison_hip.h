@@ -134,6 +134,26 @@ int edison_dev_free(edison_ctx *ctx, void *dptr);
 int edison_dev_upload(edison_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int edison_dev_download(edison_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 
+/* ---- multi-GPU: one process (one context) per GPU, one RCCL all-gather of the logits ---------------------------
+ * The reference has no counterpart (single MCU, UART host link: hostinterface.c:96-112). Utterances are
+ * sharded contiguously over the ranks (edison_dist_shard_range); frames and utterances are independent, so the data
+ * path has no collective; the only exchange is the all-gather of the per-class int8 logits (10 B per utterance) over
+ * xGMI. Protocol: rank 0 calls edison_dist_unique_id and hands the 128 bytes to every rank by whatever means the host
+ * program has (MPI, a file, a socket, torch.distributed); every rank then calls edison_dist_init on its context.
+ * RCCL is bound at run time (librccl.so.1, or EDISON_RCCL_LIB); EDISON_E_NO_IMPL when it cannot be found. */
+#define EDISON_DIST_ID_BYTES 128
+int edison_dist_unique_id(void *id128);
+int edison_dist_init(edison_ctx *ctx, const void *id128, int rank, int world_size);
+int edison_dist_info(const edison_ctx *ctx, int *rank, int *world_size);
+int edison_dist_shutdown(edison_ctx *ctx); /* also done by edison_shutdown */
+int edison_dist_shard_range(int64_t n_items, int rank, int world_size, int64_t *lo, int64_t *hi);
+/* device pointers; every rank passes the same n_local_utt; rank r's rows land at all_logits + r * n_local_utt * 10.
+ * Asynchronous on the context's stream. A context outside any communicator is a world of one (plain copy). */
+int edison_dist_allgather_logits(edison_ctx *ctx, const int8_t *local_logits, int64_t n_local_utt, int8_t *all_logits);
+/* edison_kws_batch_dev on this rank's shard followed by the all-gather: BASELINE config 4 in one call per rank */
+int edison_kws_batch_sharded_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_local_utt, int64_t utt_stride,
+                                 int8_t *feat, int8_t *logits_local, int8_t *softmax, int32_t *argmax, int8_t *logits_all);
+
 /* ---- the hot path, batched, device pointers ----------------------------------------------------------- */
 
 /*

@@ -67,3 +67,55 @@ def test_single_process_gather_is_identity():
     assert torch.equal(parallel.all_gather_logits(x), x)
     g = parallel.LogitsGatherer(4)
     assert torch.equal(g(x), x)
+
+
+def test_c_abi_shard_range_equals_the_python_one():
+    """edison_dist_shard_range (what a C host uses) and parallel.shard_range must cut the batch identically, and the
+    shards must tile [0, n) in rank order (the layout the all-gather assumes)."""
+    sys.path.insert(0, ROOT)
+    from edison_amd import parallel
+    for n in (0, 1, 7, 10, 403, 262144, 2097152, 2097153):
+        for w in (1, 2, 3, 4, 8):
+            edge = 0
+            for r in range(w):
+                lo, hi = parallel.shard_range_c(n, r, w)
+                assert (lo, hi) == parallel.shard_range(n, r, w)
+                assert lo == edge
+                edge = hi
+            assert edge == n
+    with pytest.raises(ValueError):
+        parallel.shard_range_c(10, 2, 2)
+
+
+def _id_worker(rank, world, port, q):
+    """The C-ABI communicator bootstrap over gloo: rank 0's RCCL unique id reaches every rank unchanged (the
+    ncclCommInitRank that follows needs GPUs and is exercised by tests/test_gpu_dist.py and bench.py --gpus N)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from edison_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    payload = torch.zeros(128, dtype=torch.uint8)
+    mine = None
+    if rank == 0:
+        mine = parallel.dist_unique_id()
+        payload = torch.frombuffer(bytearray(mine), dtype=torch.uint8).clone()
+    dist.broadcast(payload, src=0)
+    got = bytes(payload.numpy().tobytes())
+    gathered = [None] * world
+    dist.all_gather_object(gathered, got)
+    q.put((rank, len(got) == 128 and all(g == gathered[0] for g in gathered) and (mine is None or mine == got) and any(got)))
+    dist.destroy_process_group()
+
+
+def test_unique_id_reaches_every_rank():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_id_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
