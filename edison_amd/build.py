@@ -14,10 +14,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libedison_hip.so")
-C_SOURCES = ["tables.c", "tables_q15.c", "tables_f32.c", "model.c", "model_net.c", "legacy.c"]
+C_SOURCES = ["tables.c", "tables_q15.c", "tables_f32.c", "model.c", "model_net.c", "model_net_mm.c", "legacy.c"]
 HIP_SOURCES = ["edison_hip.hip", "edison_q15.hip", "edison_f32.hip", "edison_net.hip", "edison_stream.hip", "edison_dist.hip", "mfcc_kernels.hip",
                "mfcc_q15_kernels.hip", "mfcc_f32_kernels.hip", "cnn_kernels.hip", "cnn_mfma_kernels.hip",
-               "cnn_net_kernels.hip"]
+               "cnn_net_kernels.hip", "cnn_net_mfma_kernels.hip"]
 HEADERS = ["edison_internal.h", "edison_ctx.h", os.path.join("..", "..", "include", "edison_hip.h")]
 ARCH = "gfx950"
 

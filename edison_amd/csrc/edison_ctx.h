@@ -23,6 +23,10 @@ extern "C" int ed_launch_net(const ed_net_plan_t *dev_plan, const int8_t *dev_w,
                              const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax,
                              int8_t *acts, int n_cu, hipStream_t stream);
 
+extern "C" int ed_launch_net_mfma(const ed_net_plan_t *dev_plan, const ed_mm_plan_t *dev_mm, const int8_t *dev_frag,
+                                  const int32_t *dev_seeds, int lds_bytes, int batch, const int8_t *in, int64_t n, int64_t in_stride,
+                                  int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu, hipStream_t stream);
+
 extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int mel_nlo, int mel_nhi,
                                   int stages, int n_cu, hipStream_t stream);
 
@@ -50,6 +54,11 @@ struct edison_ctx
 	ed_net_plan_t *d_net_plan;
 	int8_t *d_net_w;
 	int32_t *d_net_seeds;
+	/* ... and its matrix-core plan (cnn_net_mfma_kernels.hip), when the graph has one */
+	int mm_ok, mm_lds, mm_batch;
+	ed_mm_plan_t *d_mm_plan;
+	int8_t *d_mm_frag;
+	int32_t *d_mm_seeds;
 	/* growable device scratch for the host-pointer entry points and the fused KWS path */
 	void *scratch;
 	size_t scratch_bytes;
@@ -80,6 +89,9 @@ static inline int ed_set_err(edison_ctx *ctx, int code, const char *msg)
  * the kws_conv graph, the general kernel for any other graph of that shape. feat_stride = bytes between utterances. */
 int ed_ctx_kws_cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int64_t feat_stride, int8_t *logits,
                           int8_t *softmax, int32_t *argmax);
+
+/* Any loaded graph, no per-layer dumps: matrix-core kernel if the graph has a plan for it, else the layer-by-layer one. */
+int ed_ctx_net_launch(edison_ctx *ctx, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax);
 
 /* Fill the launch arguments of the MFCC kernel for `variant` and enqueue it on the context's stream. */
 int ed_ctx_mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,

@@ -131,6 +131,9 @@ extern "C" void edison_shutdown(edison_ctx *ctx)
 	if (ctx->d_net_plan) (void)hipFree(ctx->d_net_plan);
 	if (ctx->d_net_w) (void)hipFree(ctx->d_net_w);
 	if (ctx->d_net_seeds) (void)hipFree(ctx->d_net_seeds);
+	if (ctx->d_mm_plan) (void)hipFree(ctx->d_mm_plan);
+	if (ctx->d_mm_frag) (void)hipFree(ctx->d_mm_frag);
+	if (ctx->d_mm_seeds) (void)hipFree(ctx->d_mm_seeds);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	free(ctx);
@@ -217,6 +220,28 @@ extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t b
 		if (e == hipSuccess) e = hipMemcpy(ctx->d_net_plan, plan, sizeof(ed_net_plan_t), hipMemcpyHostToDevice);
 		if (e == hipSuccess) e = hipMemcpy(ctx->d_net_w, w, (size_t)plan->weights_bytes, hipMemcpyHostToDevice);
 		if (e == hipSuccess) e = hipMemcpy(ctx->d_net_seeds, seeds, (size_t)plan->n_seeds * sizeof(int32_t), hipMemcpyHostToDevice);
+		/* the matrix-core plan of the same graph (any graph: model_net_mm.c); without one the graph stays on the
+		 * layer-by-layer kernel */
+		ctx->mm_ok = 0;
+		if (ctx->d_mm_frag) { (void)hipFree(ctx->d_mm_frag); ctx->d_mm_frag = NULL; }
+		if (ctx->d_mm_seeds) { (void)hipFree(ctx->d_mm_seeds); ctx->d_mm_seeds = NULL; }
+		if (e == hipSuccess)
+		{
+			ed_mm_plan_t *mm = (ed_mm_plan_t *)malloc(sizeof(ed_mm_plan_t));
+			int8_t *frag = NULL;
+			int32_t *mseeds = NULL;
+			if (mm && ed_plan_net_mm(blob, blob_bytes, plan, mm, &frag, &mseeds) == EDISON_OK && mm->ok)
+			{
+				if (!ctx->d_mm_plan) e = hipMalloc((void **)&ctx->d_mm_plan, sizeof(ed_mm_plan_t));
+				if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mm_frag, (size_t)mm->frag_bytes + 16);
+				if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_mm_seeds, ((size_t)mm->n_seeds + 4) * sizeof(int32_t));
+				if (e == hipSuccess) e = hipMemcpy(ctx->d_mm_plan, mm, sizeof(ed_mm_plan_t), hipMemcpyHostToDevice);
+				if (e == hipSuccess) e = hipMemcpy(ctx->d_mm_frag, frag, (size_t)mm->frag_bytes, hipMemcpyHostToDevice);
+				if (e == hipSuccess) e = hipMemcpy(ctx->d_mm_seeds, mseeds, (size_t)mm->n_seeds * sizeof(int32_t), hipMemcpyHostToDevice);
+				if (e == hipSuccess) { ctx->mm_ok = 1; ctx->mm_lds = mm->lds_bytes; ctx->mm_batch = mm->batch; }
+			}
+			free(mm); free(frag); free(mseeds);
+		}
 		if (e == hipSuccess)
 		{
 			ctx->net = *plan;
@@ -377,6 +402,18 @@ static int kws_shaped(const ed_net_plan_t *p)
 	return p->in_h == EDISON_UTT_FRAMES && p->in_w == EDISON_NUM_MFCC && p->in_c == 1 && p->out_n == EDISON_NET_OUT && p->has_softmax;
 }
 
+/* any loaded graph without per-layer dumps: the matrix-core kernel when the graph has a plan for it (EDISON_NET_NO_MFMA=1
+ * keeps the layer-by-layer kernel, for A/B measurements), else the layer-by-layer kernel */
+int ed_ctx_net_launch(edison_ctx *ctx, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax)
+{
+	static const int no_mfma = getenv("EDISON_NET_NO_MFMA") ? atoi(getenv("EDISON_NET_NO_MFMA")) : 0;
+	if (ctx->mm_ok && !no_mfma)
+		return ed_launch_net_mfma(ctx->d_net_plan, ctx->d_mm_plan, ctx->d_mm_frag, ctx->d_mm_seeds, ctx->mm_lds, ctx->mm_batch, in, n,
+		                          in_stride, logits, softmax, argmax, ctx->n_cu, ctx->stream);
+	return ed_launch_net(ctx->d_net_plan, ctx->d_net_w, ctx->d_net_seeds, ctx->net.lds_bytes, in, n, in_stride, logits, softmax, argmax,
+	                     NULL, ctx->n_cu, ctx->stream);
+}
+
 int ed_ctx_kws_cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int64_t feat_stride, int8_t *logits,
                           int8_t *softmax, int32_t *argmax)
 {
@@ -385,8 +422,7 @@ int ed_ctx_kws_cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, in
 		return set_err(ctx, EDISON_E_SIZE, "the loaded model is not a 31x13x1 -> 10 softmax classifier; use edison_net_batch");
 	int e = ctx->fast_model
 	            ? ed_launch_cnn_mfma(ctx->d_model_mfma, feat, n_utt, feat_stride, logits, softmax, argmax, ctx->n_cu, ctx->stream)
-	            : ed_launch_net(ctx->d_net_plan, ctx->d_net_w, ctx->d_net_seeds, ctx->net.lds_bytes, feat, n_utt, feat_stride,
-	                            logits, softmax, argmax, NULL, ctx->n_cu, ctx->stream);
+	            : ed_ctx_net_launch(ctx, feat, n_utt, feat_stride, logits, softmax, argmax);
 	if (e != 0)
 	{
 		snprintf(ctx->err, sizeof(ctx->err), "CNN kernel launch failed: %s", hipGetErrorString((hipError_t)e));

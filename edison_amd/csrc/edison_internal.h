@@ -229,6 +229,48 @@ typedef struct {
 int ed_plan_net(const void *blob, size_t blob_bytes, ed_net_plan_t *plan, int8_t **weights, int32_t **seeds, char *err,
                 size_t err_cap);
 
+/* ------------------------------------------------------------------ the same graphs on the matrix cores (cnn_net_mfma_kernels.hip)
+ * Every Conv2D / Dense layer as the implicit GEMM  D[out_channel][pixel] = sum_k A[out_channel][k] * B[k][pixel]  on
+ * v_mfma_i32_32x32x32_i8. k runs over (kernel row ky, 16-byte chunk j of that row's CONTIGUOUS input segment): in HWC
+ * memory the kw * C_in bytes under one kernel row are adjacent, so a B fragment is one aligned ds_read_b128
+ *   - straight from the (zero-padded) input image when C_in % 16 == 0, or
+ *   - from an expanded copy with one 16-byte-aligned record per (input row, output x) otherwise (first layers, RGB).
+ * A = the layer's weights, packed by the planner as ready operand fragments ([row tile][k-step][64 lanes][16 B], zeros
+ * beyond kw * C_in, beyond the last chunk and beyond C_out); C = the accumulator seeds. MaxPool, Softmax and the argmax
+ * stay on the VALU. A workgroup takes `batch` inputs at a time so that small late layers still fill 32-column tiles. */
+#define ED_MM_MAX_KOFF 1024
+typedef struct {
+	int32_t mm;                 /* 1: Conv2D / Dense on the matrix cores                                              */
+	int32_t in_hp, in_wp;       /* the input image as this layer wants it in LDS: padded height / width ...          */
+	int32_t in_py, in_px;       /* ... and where the unpadded image starts inside it                                  */
+	int32_t in_img;             /* bytes per input image in that layout (multiple of 16, + 16 bytes of slack)         */
+	int32_t expand;             /* 1: B comes from the expanded copy                                                  */
+	int32_t x_img;              /* bytes per expanded image (0 when direct)                                           */
+	int32_t cpr, n_ks, n_rt;    /* 16-byte chunks per kernel row, k-steps = ceil(kh * cpr / 2), row tiles             */
+	int32_t pitch_x, pitch_y;   /* B addressing in bytes: per output x, per input row                                 */
+	int32_t frag_off;           /* byte offset of the fragments in the fragment buffer                                */
+	int32_t seed_off;           /* index of the 32 * n_rt padded seeds                                                */
+	int32_t koff_off;           /* index into koff[]: byte offset of chunk c = 2 s + h inside the image (ky * pitch_y + 16 j) */
+} ed_mm_layer_t;
+
+typedef struct {
+	int32_t ok;                 /* 0: this graph stays on the layer-by-layer kernel (why: the loader's error text)     */
+	int32_t batch;              /* inputs per workgroup iteration                                                     */
+	int32_t buf_bytes;          /* each of the two ping-pong activation buffers                                       */
+	int32_t x_bytes;            /* expansion buffer                                                                   */
+	int32_t lds_bytes;
+	int32_t frag_lds;           /* bytes of LDS reserved for weight fragments                                         */
+	int32_t frag_mode;          /* 2: all layers resident in LDS, 1: one layer at a time, 0: streamed from L2          */
+	int32_t tbl_bytes;          /* LDS copy of the small tables: koff | seeds | layer records (read once per workgroup) */
+	int32_t frag_bytes, n_seeds, n_koff;
+	ed_mm_layer_t L[ED_NET_MAX_LAYERS];
+	int32_t koff[ED_MM_MAX_KOFF];
+} ed_mm_plan_t;
+
+/* Adds the matrix-core plan to a graph ed_plan_net accepted. *frag / *seeds are malloc'd when mm->ok. */
+int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *plan, ed_mm_plan_t *mm, int8_t **frag,
+                   int32_t **seeds);
+
 /* ------------------------------------------------------------------ kernel launchers (HIP side)           */
 typedef struct {
 	const int16_t *audio;

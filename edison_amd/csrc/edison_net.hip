@@ -17,7 +17,7 @@ extern "C" int edison_net_get_info(edison_ctx *ctx, edison_net_info *out)
 	const ed_net_plan_t *p = &ctx->net;
 	out->in_h = p->in_h; out->in_w = p->in_w; out->in_c = p->in_c;
 	out->n_out = p->out_n; out->n_layers = p->n_layers; out->acts_bytes = p->acts_bytes;
-	out->has_softmax = p->has_softmax; out->accelerated = ctx->fast_model;
+	out->has_softmax = p->has_softmax; out->accelerated = ctx->fast_model ? 1 : (ctx->mm_ok ? 2 : 0);
 	return EDISON_OK;
 }
 
@@ -41,10 +41,12 @@ static int net_launch(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *logi
 	if (softmax && !ctx->net.has_softmax) return ed_set_err(ctx, EDISON_E_ARGUMENT, "the loaded model has no Softmax layer; pass softmax = NULL");
 	if (n >= ((int64_t)1 << 31)) return ed_set_err(ctx, EDISON_E_ARGUMENT, "too many inputs per call");
 	/* the shipped graph keeps its matrix-core kernel; per-layer dumps always come from the general kernel */
-	if (allow_fast && ctx->fast_model && !acts)
+	static const int force_general = getenv("EDISON_NET_FORCE_GENERAL") ? atoi(getenv("EDISON_NET_FORCE_GENERAL")) : 0; /* A/B knob */
+	if (allow_fast && ctx->fast_model && !acts && !force_general)
 		return ed_ctx_kws_cnn_launch(ctx, in, n, ctx->net.in_n, logits, softmax, argmax);
-	int e = ed_launch_net(ctx->d_net_plan, ctx->d_net_w, ctx->d_net_seeds, ctx->net.lds_bytes, in, n, ctx->net.in_n, logits, softmax,
-	                      argmax, acts, ctx->n_cu, ctx->stream);
+	int e = acts ? ed_launch_net(ctx->d_net_plan, ctx->d_net_w, ctx->d_net_seeds, ctx->net.lds_bytes, in, n, ctx->net.in_n, logits, softmax,
+	                             argmax, acts, ctx->n_cu, ctx->stream)
+	             : ed_ctx_net_launch(ctx, in, n, ctx->net.in_n, logits, softmax, argmax);
 	if (e != 0)
 	{
 		snprintf(ctx->err, sizeof(ctx->err), "network kernel launch failed: %s", hipGetErrorString((hipError_t)e));

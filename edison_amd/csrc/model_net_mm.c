@@ -1,0 +1,188 @@
+/*
+ * model_net_mm.c -- host-side planner of the matrix-core path for ANY sequential NNoM int8 graph (the layer list
+ * ed_plan_net built): operand-fragment packing of every Conv2D / Dense layer, the padded activation layouts and the
+ * LDS budget. The arithmetic it feeds is the reference's (arm_convolve_HWC_q7_basic_nonsquare.c:188-221,
+ * arm_fully_connected_q7_opt.c:374-473: out = sat8((sum x*w + (bias << BL) + NN_ROUND(RS)) >> RS)); only the order of
+ * the exact integer sums differs. See edison_internal.h (ed_mm_plan_t) for the scheme.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/edison_hip.h"
+#include "edison_internal.h"
+
+typedef struct { int32_t v[12]; } rec_t;
+
+static int imax(int a, int b) { return a > b ? a : b; }
+static int up16(int v) { return (v + 15) & ~15; }
+
+int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *plan, ed_mm_plan_t *mm, int8_t **frag, int32_t **seeds)
+{
+	const unsigned char *p = (const unsigned char *)blob;
+	memset(mm, 0, sizeof(*mm));
+	*frag = NULL;
+	*seeds = NULL;
+	if (blob_bytes < 40) return EDISON_E_SIZE;
+	const int n_layers = plan->n_layers;
+	const int8_t *payload = (const int8_t *)(p + 40 + (size_t)n_layers * 48);
+
+	/* pass 1: shapes, counts */
+	size_t frag_bytes = 0;
+	int n_seeds = 0, n_koff = 0;
+	for (int i = 0; i < n_layers; i++)
+	{
+		const ed_net_layer_t *L = &plan->L[i];
+		ed_mm_layer_t *M = &mm->L[i];
+		/* default: the layer reads a compact (unpadded) image */
+		M->in_hp = L->in_h; M->in_wp = L->in_w; M->in_py = 0; M->in_px = 0;
+		/* (a dense layer reads the same compact HWC image: it is a 1x1 convolution over ONE row of in_n bytes) */
+		if (L->type != ED_NET_CONV && L->type != ED_NET_DENSE)
+		{
+			M->in_img = up16(L->in_n) + 16;
+			continue;
+		}
+		const int dense = L->type == ED_NET_DENSE;
+		const int in_c = dense ? L->in_n : L->in_c, kh = dense ? 1 : L->kh, kw = dense ? 1 : L->kw;
+		const int sh = dense ? 1 : L->sh, out_w = dense ? 1 : L->out_w, out_h = dense ? 1 : L->out_h;
+		if (!dense)
+		{
+			/* zero border so that every window lies inside the stored image: pad rows / columns in front
+			 * (nnom_conv2d.c:66-71) and whatever the last windows overhang behind */
+			M->in_py = L->pad_h; M->in_px = L->pad_w;
+			M->in_hp = imax(L->in_h + L->pad_h, (out_h - 1) * L->sh + kh);
+			M->in_wp = imax(L->in_w + L->pad_w, (out_w - 1) * L->sw + kw);
+		}
+		const int seg = kw * in_c;                 /* contiguous bytes under one kernel row */
+		M->mm = 1;
+		M->cpr = (seg + 15) / 16;
+		M->n_ks = (kh * M->cpr + 1) / 2;
+		M->n_rt = (L->out_c + 31) / 32;
+		M->expand = (in_c % 16) != 0;
+		M->in_img = (dense ? up16(L->in_n) : up16(M->in_hp * M->in_wp * in_c)) + 16; /* dense: the compact image, C_in = its whole length */
+		if (M->expand)
+		{
+			M->pitch_x = 16 * M->cpr;
+			M->pitch_y = out_w * 16 * M->cpr;
+			M->x_img = (dense ? 1 : M->in_hp) * M->pitch_y + 16;
+		}
+		else
+		{
+			M->pitch_x = (dense ? 1 : L->sw) * in_c;
+			M->pitch_y = M->in_wp * in_c;
+			M->x_img = 0;
+		}
+		(void)sh;
+		M->frag_off = (int32_t)frag_bytes;
+		frag_bytes += (size_t)M->n_rt * M->n_ks * 1024;
+		M->seed_off = n_seeds;
+		n_seeds += 32 * M->n_rt;
+		M->koff_off = n_koff;
+		n_koff += 2 * M->n_ks;
+		if (n_koff > ED_MM_MAX_KOFF || 2 * M->n_ks > 256 || frag_bytes > ((size_t)64 << 20)) return EDISON_OK; /* mm->ok stays 0 */
+	}
+
+	/* LDS budget: two ping-pong buffers of batch x the largest image layout, the expansion buffer, the koff table */
+	int max_img = up16(plan->in_n) + 16, max_x = 0;
+	for (int i = 0; i < n_layers; i++)
+	{
+		if (mm->L[i].in_img > max_img) max_img = mm->L[i].in_img;
+		if (mm->L[i].x_img > max_x) max_x = mm->L[i].x_img;
+		const int out_img = up16(plan->L[i].out_n) + 16; /* the last layer's compact output */
+		if (out_img > max_img) max_img = out_img;
+	}
+	/* Where the weight fragments live while a workgroup runs, best first: (2) ALL layers resident in LDS for the whole
+	 * launch (one L2 read per workgroup), (1) one layer at a time, re-staged per batch, (0) streamed from L2 per MFMA.
+	 * With the fragments placed, the batch is the largest power of two whose activations still fit. */
+	int max_frag = 0;
+	for (int i = 0; i < n_layers; i++)
+		if (mm->L[i].mm && mm->L[i].n_rt * mm->L[i].n_ks * 1024 > max_frag) max_frag = mm->L[i].n_rt * mm->L[i].n_ks * 1024;
+	const int lds_cap = 150 * 1024;
+	const int tbl = up16(4 * n_koff) + up16(4 * n_seeds) + up16(n_layers * (int)sizeof(ed_net_layer_t)) + up16(n_layers * (int)sizeof(ed_mm_layer_t));
+	if (tbl > 24 * 1024) return EDISON_OK;
+	int batch = 0, frag_lds = 0, frag_mode = 0;
+	for (int mode = 2; mode >= 0 && !batch; mode--)
+	{
+		const int64_t fl = mode == 2 ? (int64_t)frag_bytes : mode == 1 ? max_frag : 0;
+		if (fl > 96 * 1024) continue;
+		for (int b = 16; b >= (mode == 2 ? 4 : 1); b >>= 1)
+			if (2 * (int64_t)b * max_img + (int64_t)b * up16(max_x) + tbl + fl <= lds_cap) { batch = b; frag_lds = (int)fl; frag_mode = mode; break; }
+	}
+	if (!batch) return EDISON_OK;
+	mm->batch = batch;
+	mm->buf_bytes = batch * max_img;
+	mm->x_bytes = batch * up16(max_x);
+	mm->frag_lds = frag_lds;
+	mm->frag_mode = frag_mode;
+	mm->tbl_bytes = tbl;
+	mm->lds_bytes = 2 * mm->buf_bytes + mm->x_bytes + tbl + frag_lds;
+	mm->frag_bytes = (int32_t)frag_bytes;
+	mm->n_seeds = n_seeds;
+	mm->n_koff = n_koff;
+
+	/* pass 2: fragments, seeds, chunk offsets */
+	int8_t *fb = (int8_t *)calloc(frag_bytes + 16, 1);
+	int32_t *sb = (int32_t *)calloc((size_t)n_seeds + 4, sizeof(int32_t));
+	if (!fb || !sb) { free(fb); free(sb); return EDISON_E_NO_MEMORY; }
+	for (int i = 0; i < n_layers; i++)
+	{
+		const ed_net_layer_t *L = &plan->L[i];
+		const ed_mm_layer_t *M = &mm->L[i];
+		if (!M->mm) continue;
+		rec_t r;
+		memcpy(&r, p + 40 + (size_t)i * 48, sizeof(r));
+		const int dense = L->type == ED_NET_DENSE;
+		const int in_c = dense ? L->in_n : L->in_c, kh = dense ? 1 : L->kh, kw = dense ? 1 : L->kw;
+		const int seg = kw * in_c;
+		const int8_t *w = payload + r.v[9], *bias = payload + r.v[10]; /* OHWI / [out][in]: row o = kh segments of seg bytes */
+		for (int rt = 0; rt < M->n_rt; rt++)
+			for (int s = 0; s < M->n_ks; s++)
+			{
+				int8_t *f = fb + M->frag_off + ((size_t)rt * M->n_ks + s) * 1024;
+				for (int l = 0; l < 64; l++)
+				{
+					const int row = 32 * rt + (l & 31), c = 2 * s + (l >> 5);
+					const int ky = c / M->cpr, jc = c - ky * M->cpr;
+					for (int j = 0; j < 16; j++)
+					{
+						const int q = 16 * jc + j;
+						f[l * 16 + j] = (row < L->out_c && ky < kh && q < seg) ? w[((size_t)row * kh + ky) * seg + q] : 0;
+					}
+				}
+			}
+		for (int o = 0; o < L->out_c; o++)
+			sb[M->seed_off + o] = (int32_t)((uint32_t)(int32_t)bias[o] << r.v[6]) + (int32_t)((1u << r.v[7]) >> 1);
+		for (int c = 0; c < 2 * M->n_ks; c++)
+		{
+			const int ky = c / M->cpr, jc = c - ky * M->cpr;
+			mm->koff[M->koff_off + c] = ky < kh ? ky * M->pitch_y + 16 * jc : 0; /* chunks past the end meet zero weights */
+		}
+	}
+	/* bounds of everything the kernel will address in LDS, checked here on the host (a plan that fails stays off the
+	 * matrix-core path instead of reaching the device): B fragment reads and epilogue stores of every layer */
+	for (int i = 0; i < n_layers; i++)
+	{
+		const ed_net_layer_t *L = &plan->L[i];
+		const ed_mm_layer_t *M = &mm->L[i];
+		int ohp, owp, opy, opx, oimg; /* the consumer's layout = where this layer's epilogue stores */
+		if (i + 1 < n_layers) { ohp = mm->L[i + 1].in_hp; owp = mm->L[i + 1].in_wp; opy = mm->L[i + 1].in_py; opx = mm->L[i + 1].in_px; oimg = mm->L[i + 1].in_img; }
+		else { ohp = L->out_h; owp = L->out_w; opy = 0; opx = 0; oimg = up16(L->out_n) + 16; }
+		const int64_t last_store = ((int64_t)(L->out_h - 1 + opy) * owp + (L->out_w - 1 + opx)) * L->out_c + L->out_c;
+		int bad = last_store > oimg || ohp < L->out_h + opy || owp < L->out_w + opx || oimg > mm->buf_bytes / batch;
+		if (M->mm)
+		{
+			const int dense = L->type == ED_NET_DENSE;
+			const int out_h = dense ? 1 : L->out_h, out_w = dense ? 1 : L->out_w, sh = dense ? 1 : L->sh;
+			const int img = M->expand ? M->x_img : M->in_img;
+			int max_koff = 0;
+			for (int c = 0; c < 2 * M->n_ks; c++) if (mm->koff[M->koff_off + c] > max_koff) max_koff = mm->koff[M->koff_off + c];
+			const int64_t last_read = (int64_t)(out_h - 1) * sh * M->pitch_y + (int64_t)(out_w - 1) * M->pitch_x + max_koff + 16;
+			bad |= last_read > img || (M->pitch_x & 15) || (M->pitch_y & 15) || (M->in_img & 15) || (M->x_img & 15);
+			bad |= M->expand ? (batch * up16(M->x_img) > mm->x_bytes + 0) : 0;
+		}
+		if (bad) { free(fb); free(sb); return EDISON_OK; } /* mm->ok stays 0 */
+	}
+	*frag = fb;
+	*seeds = sb;
+	mm->ok = 1;
+	return EDISON_OK;
+}

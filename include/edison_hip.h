@@ -113,7 +113,8 @@ typedef struct edison_net_info {
 	int32_t n_layers;         /* compute layers (Input/Output/Flatten are not counted)                          */
 	int32_t acts_bytes;       /* bytes per input of edison_net_layers                                           */
 	int32_t has_softmax;
-	int32_t accelerated;      /* 1: the kws_conv graph, served by the matrix-core kernel                        */
+	int32_t accelerated;      /* 1: the kws_conv graph, served by its specialised matrix-core kernel; 2: another graph,
+	                           * served by the general matrix-core kernel; 0: layer-by-layer VALU kernel only      */
 } edison_net_info;
 typedef struct edison_net_layer_info_t {
 	int32_t type;             /* 1 Conv2D, 2 MaxPool, 3 Dense, 4 Softmax                                        */

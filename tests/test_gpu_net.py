@@ -44,7 +44,10 @@ def test_net_matches_reference_nnom(built_lib, net_golden, name):
     c = _context(built_lib, name)
     info = c.net_info()
     x, ref = net_golden["in_" + name], net_golden["acts_" + name]
-    assert info["acts_bytes"] == ref.shape[1] and not info["accelerated"]
+    assert info["acts_bytes"] == ref.shape[1]
+    # every fixture graph runs its Conv2D / Dense layers on the matrix cores (2); edison_net_layers (per-layer dumps)
+    # always comes from the layer-by-layer kernel
+    assert info["accelerated"] == 2
     assert np.array_equal(c.net_layers(x), ref)
     out = c.net(x)
     last = info["layers"][-1]

@@ -50,5 +50,5 @@ def timed(fn, tag):
 
 L = ctx._L
 timed(lambda: ctx._check(L.edison_net_batch_dev(ctx._h, _t_ptr(x), a.n, _t_ptr(logits), None, _t_ptr(am))),
-      "edison_net_batch_dev (%s)" % ("matrix cores" if info["accelerated"] else "general kernel"))
+      "edison_net_batch_dev (%s)" % {0: "layer-by-layer VALU kernel", 1: "kws_conv matrix-core kernel", 2: "general matrix-core kernel"}[2 if os.environ.get("EDISON_NET_FORCE_GENERAL") == "1" and info["accelerated"] == 1 else info["accelerated"]])
 timed(lambda: ctx._check(L.edison_net_layers_dev(ctx._h, _t_ptr(x), a.n, _t_ptr(acts))), "edison_net_layers_dev (general + dumps)")
