@@ -133,6 +133,12 @@ SIGNATURES = {
     "edison_mfcc_f32_n_out": (c_int, [c_void_p]),
     "edison_mfcc_f32_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "edison_mfcc_f32_batch": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "edison_f32_stream_create": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "edison_f32_stream_destroy": (None, [c_void_p]),
+    "edison_f32_stream_reset": (c_int, [c_void_p]),
+    "edison_f32_stream_events_seen": (c_int64, [c_void_p]),
+    "edison_f32_stream_push_dev": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "edison_f32_stream_push": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "edison_mfcc_frame": (c_int, [c_void_p, c_int, c_void_p]),
     "edison_global_ctx": (c_void_p, []),
 }

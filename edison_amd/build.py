@@ -18,7 +18,7 @@ C_SOURCES = ["tables.c", "tables_q15.c", "tables_f32.c", "model.c", "model_net.c
 HIP_SOURCES = ["edison_hip.hip", "edison_q15.hip", "edison_f32.hip", "edison_net.hip", "edison_stream.hip", "edison_dist.hip", "mfcc_kernels.hip",
                "mfcc_q15_kernels.hip", "mfcc_f32_kernels.hip", "cnn_kernels.hip", "cnn_mfma_kernels.hip",
                "cnn_net_kernels.hip", "cnn_net_mfma_kernels.hip"]
-HEADERS = ["edison_internal.h", "edison_ctx.h", os.path.join("..", "..", "include", "edison_hip.h")]
+HEADERS = ["edison_internal.h", "edison_ctx.h", "mfcc_fft.h", os.path.join("..", "..", "include", "edison_hip.h")]
 ARCH = "gfx950"
 
 

@@ -141,3 +141,217 @@ extern "C" int ed_launch_mfcc_f32(const ed_mfcc_f32_args_t *args, const ed_f32_t
 	hipLaunchKernelGGL(ed_mfcc_f32_kernel, dim3((unsigned)blocks), dim3(64 * EF_WPB), lds, stream, *args, dev_tab);
 	return (int)hipGetLastError();
 }
+
+/* ================================================================================================================
+ * Fast path for frames padded to 512 points (the firmware's configuration: frame 512, hop 256, app.c:497,583).
+ *
+ * The 512-point real transform of a frame is taken as a 512-point COMPLEX transform with a zero imaginary part on the
+ * register-level radix-8 machinery of the variant A / B kernel (mfcc_fft.h): three radix-8 passes, the first digit
+ * transpose on the VALU (v_permlane swaps + DPP), the second through a wave-private LDS buffer; no real-FFT split is
+ * needed, lane l ends with X[l + 64 r] in register r and bins 0..256 are registers 0..3 (+ register 4 of lane 0).
+ * Two frames ride in the two halves of packed fp32 registers (v_pk_*_f32): independent lanes of arithmetic, so a silent
+ * frame next to a loud one stays exactly silent (which pairing two real frames into ONE complex transform would not
+ * give). Frames are handed to the 12 waves of a CU-wide workgroup through a counter in LDS, as in ed_mfcc2_kernel.
+ * Mel: two lanes per band (first / second half of the band's taps), log, DCT row per lane, scale, round half away,
+ * saturate -- float32 like the firmware; the order of the partial sums differs from its serial loops, inside the bars
+ * tests/test_gpu_f32.py states. Parity unpinned, as for the whole variant.
+ */
+#include "mfcc_fft.h"
+
+#define EF2_WPB 12
+#define EF2_S_OFF 1088     /* float offset of the interleaved spectra S2[k] = (|X_A[k]|, |X_B[k]|), k = 0..256 */
+#define EF2_L_OFF 1664     /* log-mel energies of both frames, float2[32] */
+#define EF2_XBUF_FLOATS 2208
+#define EF2_TAB_FLOATS (2 * 7 * 64 * 2 + ED_F32_MAX_W + ED_F32_NUM_FBANK * ED_F32_NUM_FBANK + 4) /* twiddles | mel_w | dct */
+
+__global__ __launch_bounds__(64 * EF2_WPB) void ed_mfcc_f32_fast_kernel(ed_mfcc_f32_args_t a, const ed_f32_tables_t *__restrict__ T,
+                                                                      const ed_mfcc_tables_t *__restrict__ F)
+{
+	extern __shared__ __attribute__((aligned(16))) float ef_smem[];
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	float2 *twl = reinterpret_cast<float2 *>(ef_smem);                /* [2][7][64]: pass-1 / pass-2 twiddles per lane */
+	float *melw = ef_smem + 2 * 7 * 64 * 2;
+	float *dctl = melw + ED_F32_MAX_W;
+	float *xbuf = ef_smem + EF2_TAB_FLOATS + wave * EF2_XBUF_FLOATS;  /* wave-private */
+	unsigned *queue = reinterpret_cast<unsigned *>(ef_smem + EF2_TAB_FLOATS + EF2_WPB * EF2_XBUF_FLOATS);
+
+	const int N = T->frame_len, n_out = T->n_features - T->offset;
+	const float preempha = T->preempha, scale = T->scale;
+	const uint32_t n_frames = (uint32_t)a.n_frames, n_pairs = (n_frames + 1) >> 1;
+	const uint32_t s0 = (uint32_t)(((uint64_t)blockIdx.x * n_pairs) / gridDim.x);
+	const uint32_t cnt = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_pairs) / gridDim.x) - s0;
+
+	/* per-lane constants of the 8 samples n = lane + 64 a this lane feeds: window / 2^15 (the firmware scales before it
+	 * windows; the power of two commutes exactly), the pre-emphasis factor (0 for n = 0, which the firmware passes
+	 * through unscaled: mfcc.c:178-181), and the sample offsets clamped into the frame */
+	float ws[8], pe[8];
+	int off0[8], off1[8];
+#pragma unroll
+	for (int q = 0; q < 8; q++)
+	{
+		const int n = lane + 64 * q;
+		const bool in = n < N;
+		ws[q] = !in ? 0.0f : (n == 0 ? T->window[0] : T->window[n] * (1.0f / 32768.0f));
+		pe[q] = (in && n > 0) ? preempha : 0.0f;
+		off0[q] = in ? n : 0;
+		off1[q] = (in && n > 0) ? n - 1 : 0;
+	}
+	for (int t = threadIdx.x; t < 7 * 64; t += 64 * EF2_WPB)
+	{
+		twl[t] = *reinterpret_cast<const float2 *>(&F->tw1[1 + t / 64][t & 63][0]);
+		twl[7 * 64 + t] = *reinterpret_cast<const float2 *>(&F->tw2[1 + t / 64][t & 63][0]);
+	}
+	for (int t = threadIdx.x; t < ED_F32_MAX_W; t += 64 * EF2_WPB) melw[t] = T->mel_w[t];
+	for (int t = threadIdx.x; t < ED_F32_NUM_FBANK * ED_F32_NUM_FBANK; t += 64 * EF2_WPB) dctl[t] = T->dct[t];
+	if (threadIdx.x == 0) *queue = 2 * EF2_WPB;
+	/* mel: lane (band = lane & 31, part = lane >> 5) sums one half of its band's taps */
+	const int band = lane & 31, part = lane >> 5;
+	int t_first = 0, t_cnt = 0, t_woff = 0;
+	if (band < ED_F32_NUM_FBANK && T->mel_first[band] >= 0)
+	{
+		const int first = T->mel_first[band], last = T->mel_last[band], n_t = last - first + 1, h0 = (n_t + 1) >> 1;
+		t_first = part ? first + h0 : first;
+		t_cnt = part ? n_t - h0 : h0;
+		t_woff = T->mel_off[band] + (part ? h0 : 0);
+	}
+	const int dct_row = (T->offset + (lane < n_out ? lane : 0)) * ED_F32_NUM_FBANK;
+	__syncthreads();
+	const float2 *tw1l = twl + lane, *tw2l = twl + 7 * 64 + lane;
+	const int hi3 = lane >> 3, lo3 = lane & 7;
+	float4 *xc4 = reinterpret_cast<float4 *>(xbuf);
+	ed_f2 *S2 = reinterpret_cast<ed_f2 *>(xbuf + EF2_S_OFF);
+	ed_f2 *LM = reinterpret_cast<ed_f2 *>(xbuf + EF2_L_OFF);
+
+	auto load_pair = [&](uint32_t pr, int (&xa)[8], int (&ya)[8], int (&xb)[8], int (&yb)[8]) {
+		const uint32_t fA = 2 * pr, fB = fA + 1 < n_frames ? fA + 1 : fA;
+		const int16_t *pa = a.audio + (int64_t)fA * a.frame_step, *pb = a.audio + (int64_t)fB * a.frame_step;
+#pragma unroll
+		for (int q = 0; q < 8; q++) { xa[q] = pa[off0[q]]; ya[q] = pa[off1[q]]; xb[q] = pb[off0[q]]; yb[q] = pb[off1[q]]; }
+	};
+
+	uint32_t i_cur = wave, i_next = wave + EF2_WPB;
+	int xa[8], ya[8], xb[8], yb[8];
+	if (i_cur < cnt) load_pair(s0 + i_cur, xa, ya, xb, yb);
+	while (i_cur < cnt)
+	{
+		const uint32_t fA = 2 * (s0 + i_cur);
+		const bool haveB = fA + 1 < n_frames;
+		/* ---- 1. pre-emphasis, scale, window; the imaginary parts start as zero */
+		ed_f2 re[8], im[8];
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+		{
+			const float va = __fsub_rn((float)xa[q], __fmul_rn((float)ya[q], pe[q])), vb = __fsub_rn((float)xb[q], __fmul_rn((float)yb[q], pe[q]));
+			re[q] = ed_mk2(va * ws[q], vb * ws[q]);
+			im[q] = ed_splat(0.0f);
+		}
+		load_pair(s0 + (i_next < cnt ? i_next : cnt - 1), xa, ya, xb, yb); /* unconditional, see ed_mfcc2_kernel */
+		uint32_t drawn = 0;
+		if (lane == 0) drawn = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+		/* ---- 2. 512-point complex FFT: pass 1 + twiddles, transpose 1 (VALU), pass 2 + twiddles, transpose 2 (LDS), pass 3 */
+		ed_radix8_2(re, im);
+#pragma unroll
+		for (int q = 1; q < 8; q++)
+		{
+			const float2 w_ = tw1l[64 * (q - 1)];
+			const ed_f2 wr = ed_splat(w_.x), wi = ed_splat(w_.y), xr = re[q], xi = im[q];
+			re[q] = xr * wr - xi * wi;
+			im[q] = xr * wi + xi * wr;
+		}
+		ed_transpose8_2<3, 4, 5>(re, lane);
+		ed_transpose8_2<3, 4, 5>(im, lane);
+		ed_radix8_2(re, im);
+#pragma unroll
+		for (int q = 1; q < 8; q++)
+		{
+			const float2 w_ = tw2l[64 * (q - 1)];
+			const ed_f2 wr = ed_splat(w_.x), wi = ed_splat(w_.y), xr = re[q], xi = im[q];
+			re[q] = xr * wr - xi * wi;
+			im[q] = xr * wi + xi * wr;
+		}
+#pragma unroll
+		for (int q = 0; q < 8; q++) xc4[66 * lo3 + hi3 + 8 * q] = make_float4(re[q].x, re[q].y, im[q].x, im[q].y);
+		ed_wave_sync();
+#pragma unroll
+		for (int c = 0; c < 8; c++)
+		{
+			const float4 v = xc4[66 * c + lane];
+			re[c] = ed_mk2(v.x, v.y); im[c] = ed_mk2(v.z, v.w);
+		}
+		ed_wave_sync();
+		ed_radix8_2(re, im);
+
+		/* ---- 3. |X[k]|, k = lane + 64 r (r < 4), and k = 256 (lane 0, r = 4): sqrtf(re^2 + im^2) (mfcc.c:196-206) */
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+		{
+			const ed_f2 e = re[r] * re[r] + im[r] * im[r];
+			S2[lane + 64 * r] = ed_mk2(__fsqrt_rn(e.x), __fsqrt_rn(e.y));
+		}
+		if (lane == 0)
+		{
+			const ed_f2 e = re[4] * re[4] + im[4] * im[4];
+			S2[256] = ed_mk2(__fsqrt_rn(e.x), __fsqrt_rn(e.y));
+		}
+		ed_wave_sync();
+
+		/* ---- 4. mel bands: two lanes per band, each over half of the taps; FLT_MIN for an exactly empty band, logf */
+		ed_f2 acc = ed_splat(0.0f);
+		for (int i = 0; i < t_cnt; i++) acc = ed_fma2(S2[t_first + i], ed_splat(melw[t_woff + i]), acc);
+		ed_f2 e = ed_mk2(ed_sum_halves(acc.x), ed_sum_halves(acc.y));
+		if (e.x == 0.0f) e.x = FLT_MIN;
+		if (e.y == 0.0f) e.y = FLT_MIN;
+		const ed_f2 lg = ed_mk2(logf(e.x), logf(e.y));
+		if (lane < ED_F32_NUM_FBANK)
+		{
+			LM[lane] = lg;
+			if (a.logmel)
+			{
+				a.logmel[(int64_t)fA * ED_F32_NUM_FBANK + lane] = lg.x;
+				if (haveB) a.logmel[(int64_t)(fA + 1) * ED_F32_NUM_FBANK + lane] = lg.y;
+			}
+		}
+		ed_wave_sync();
+
+		/* ---- 5. DCT rows, scale, round half away from zero, saturate to q7 (mfcc.c:234-254) */
+		if (lane < n_out)
+		{
+			ed_f2 sum = ed_splat(0.0f);
+#pragma unroll
+			for (int j = 0; j < ED_F32_NUM_FBANK; j++) sum = ed_fma2(ed_splat(dctl[dct_row + j]), LM[j], sum);
+			sum = sum * ed_splat(scale);
+			const float ra = roundf(sum.x), rb = roundf(sum.y);
+			const int64_t oa = (int64_t)fA * n_out + lane;
+			a.out[oa] = (int8_t)(ra >= 127.0f ? 127 : (ra <= -128.0f ? -128 : (int)ra));
+			if (a.out_f32) a.out_f32[oa] = sum.x;
+			if (haveB)
+			{
+				a.out[oa + n_out] = (int8_t)(rb >= 127.0f ? 127 : (rb <= -128.0f ? -128 : (int)rb));
+				if (a.out_f32) a.out_f32[oa + n_out] = sum.y;
+			}
+		}
+		ed_wave_sync(); /* S2 / LM are rewritten by the next pair */
+		i_cur = i_next; i_next = __builtin_amdgcn_readfirstlane(drawn);
+	}
+}
+
+extern "C" int ed_launch_mfcc_f32_fast(const ed_mfcc_f32_args_t *args, const ed_f32_tables_t *dev_tab, const ed_mfcc_tables_t *dev_fft_tab,
+                                       int n_cu, hipStream_t stream)
+{
+	if (args->n_frames <= 0) return 0;
+	const size_t lds = sizeof(float) * (EF2_TAB_FLOATS + EF2_WPB * EF2_XBUF_FLOATS) + 16;
+	static int ready = 0;
+	if (!ready)
+	{
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ed_mfcc_f32_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return (int)e;
+		ready = 1;
+	}
+	const int64_t n_pairs = (args->n_frames + 1) / 2;
+	int64_t blocks = (n_pairs + EF2_WPB - 1) / EF2_WPB;
+	if (blocks > n_cu) blocks = n_cu;
+	hipLaunchKernelGGL(ed_mfcc_f32_fast_kernel, dim3((unsigned)blocks), dim3(64 * EF2_WPB), lds, stream, *args, dev_tab, dev_fft_tab);
+	return (int)hipGetLastError();
+}

@@ -56,3 +56,48 @@ class MfccF32:
         q = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         self.ctx._check(self._L.edison_mfcc_f32_batch_dev(self._h, q(audio), int(n_frames), int(frame_step), q(out),
                                                           q(out_f32), q(logmel)))
+
+
+class NnomKwsFrontEnd:
+    """The audio front end of the firmware's NNoM keyword-spotting example (appNnomKwsRun, app.c:545-623) on the GPU:
+    push 512 new samples per event, get the 63 x 12 int8 network input (oldest feature row first) after every event.
+    ``dma_to_int16`` is the firmware's conversion of the microphone's 32-bit DMA words (app.c:572-575)."""
+
+    AUDIO_FRAME_LEN, MFCC_LEN = 512, 63            # app.c:497,499
+
+    def __init__(self, ctx=None, window_rows=63, max_events=64, **mfcc_params):
+        self.mfcc = MfccF32(ctx=ctx, **mfcc_params)  # defaults = mfcc_create(13, 1, 512, 8, 0.97f), app.c:540
+        self.ctx, self._L = self.mfcc.ctx, self.mfcc._L
+        h = ctypes.c_void_p()
+        self.ctx._check(self._L.edison_f32_stream_create(self.ctx._h, self.mfcc._h, int(window_rows), int(max_events), ctypes.byref(h)))
+        self._h, self.rows, self.max_events = h, int(window_rows), int(max_events)
+
+    @staticmethod
+    def dma_to_int16(raw32):
+        return np.clip(np.asarray(raw32, dtype=np.int32) >> 8, -32768, 32767).astype(np.int16)
+
+    def push(self, samples):
+        """samples: k * 512 new int16 samples -> int8 [k, window_rows, n_out]: mfcc_features_seq after each event."""
+        x = np.ascontiguousarray(samples, dtype=np.int16).ravel()
+        if x.size % self.AUDIO_FRAME_LEN:
+            raise ValueError("an audio event is %d samples" % self.AUDIO_FRAME_LEN)
+        k = x.size // self.AUDIO_FRAME_LEN
+        out = np.zeros((k, self.rows, self.mfcc.n_out), np.int8)
+        for lo in range(0, k, self.max_events):
+            n = min(self.max_events, k - lo)
+            self.ctx._check(self._L.edison_f32_stream_push(self._h, x[lo * 512:].ctypes.data_as(ctypes.c_void_p), n,
+                                                           out[lo:].ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    @property
+    def events_seen(self):
+        return int(self._L.edison_f32_stream_events_seen(self._h))
+
+    def reset(self):
+        self.ctx._check(self._L.edison_f32_stream_reset(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.edison_f32_stream_destroy(self._h)
+            self._h = None
+        self.mfcc.close()

@@ -353,6 +353,20 @@ int edison_mfcc_f32_batch_dev(mfcc_t *mfcc, const int16_t *audio, int64_t n_fram
                               float *out_f32, float *logmel);
 int edison_mfcc_f32_batch(mfcc_t *mfcc, const int16_t *audio, int64_t n_frames, int64_t frame_step, int8_t *out,
                           float *out_f32, float *logmel);
+
+/* The front end of the firmware's NNoM keyword-spotting example around mfcc_compute (appNnomKwsRun, app.c:545-623): every
+ * audio event delivers 512 new samples behind the last 256 old ones (app.c:567-575), two frames are extracted at offsets 0
+ * and 256 (app.c:583) into a ring of window_rows (MFCC_LEN = 63) feature rows, and the network input is that ring oldest
+ * row first (mfcc_features_seq, app.c:600-604). A push takes n_events <= max_events events (one kernel launch for all
+ * their frames) and returns the window after every event: windows [n_events][window_rows][n_out] int8. State (samples and
+ * rows) starts as zeros, like the firmware's static buffers. The extractor must be a 512-sample one on the same context. */
+typedef struct edison_f32_stream edison_f32_stream;
+int edison_f32_stream_create(edison_ctx *ctx, mfcc_t *mfcc, int window_rows, int max_events, edison_f32_stream **out);
+void edison_f32_stream_destroy(edison_f32_stream *s);
+int edison_f32_stream_reset(edison_f32_stream *s);
+int64_t edison_f32_stream_events_seen(const edison_f32_stream *s);
+int edison_f32_stream_push_dev(edison_f32_stream *s, const int16_t *samples, int n_events, int8_t *windows);
+int edison_f32_stream_push(edison_f32_stream *s, const int16_t *samples, int n_events, int8_t *windows);
 /* One 1024-sample frame through the GPU MFCC, any variant; out32 fp32. */
 int edison_mfcc_frame(const int16_t *frame1024, int variant, float *out32);
 edison_ctx *edison_global_ctx(void);

@@ -91,3 +91,35 @@ def test_f32_firmware_names(built_lib, ctx, oracle_mod, mfcc_golden):
         d = np.abs(out.astype(int) - ri[f].astype(int))
         assert d.max() <= 1 and (d != 0).sum() <= 1
     L.mfcc_delete(h)
+
+
+def test_nnom_example_front_end(ctx, oracle_mod):
+    """edison_f32_stream_* against a literal replay of appNnomKwsRun's buffers (app.c:545-623) on the host: 768-sample
+    audio buffer (256 old + 512 new), two mfcc_compute calls per event, a 63-row ring unrolled oldest row first. The
+    features themselves come from the batch path (pinned against the oracle above), so the windows must be equal bit for
+    bit -- for one event per push and for many."""
+    from edison_amd.mfcc.mfcc_f32 import MfccF32, NnomKwsFrontEnd
+    rng = np.random.default_rng(63)
+    n_ev = 70                                                        # more than 63 / 2 events: the ring wraps
+    raw = (rng.normal(0, 900000, n_ev * 512)).astype(np.int32)       # 32-bit DMA words, volume as in app.c:572-575
+    x = NnomKwsFrontEnd.dma_to_int16(raw)
+    assert x.dtype == np.int16 and np.array_equal(x, np.clip(raw >> 8, -32768, 32767))
+    m = MfccF32(ctx=ctx)
+    audio = np.zeros(768, np.int16)
+    ring = np.zeros((63, 12), np.int8)
+    idx, want = 0, []
+    for e in range(n_ev):
+        audio[:256] = audio[512:768]                                 # memcpy(audio_buffer_16bit, &audio_buffer_16bit[512], 256 * 2)
+        audio[256:] = x[e * 512:(e + 1) * 512]
+        for i in range(2):
+            ring[idx] = m.compute(audio[i * 256:i * 256 + 512], n_frames=1)[0]
+            idx = (idx + 1) % 63
+        want.append(np.concatenate([ring[idx:], ring[:idx]]))        # mfcc_features_seq
+    want = np.stack(want)
+    fe = NnomKwsFrontEnd(ctx=ctx, max_events=16)
+    got = np.concatenate([fe.push(x[:512]), fe.push(x[512:512 * 40]), fe.push(x[512 * 40:])])
+    assert fe.events_seen == n_ev and got.shape == (n_ev, 63, 12)
+    assert np.array_equal(got, want)
+    fe.reset()
+    assert np.array_equal(fe.push(x[:1024]), want[:2])
+    fe.close(); m.close()
