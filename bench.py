@@ -34,6 +34,11 @@ import torch        # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# dense int8 MFMA peak: v_mfma_i32_32x32x32_i8 = 32 768 MAC in 32 cycles per SIMD (guide: I8 = 2 x BF16 per clock; measured
+# 32.0 cycles, profiles/r02_ubench_mfma_valu_coexec.txt) x 1024 SIMDs x 2.4 GHz x 2 op/MAC
+MFMA_I8_PEAK_TOPS = 1024 * 1024 * 2.4e9 * 2 / 1e12
+CNN_MACS_PER_UTT = 784752         # NNoM compile log / SURVEY.md A.2
+CNN_MFMA_PER_UTT = 167 / 4.0      # v_mfma_i32_32x32x32_i8 issued per utterance (cnn_mfma_kernels.hip; counter: profiles/r02_cnn_counters.txt)
 MFCC_BYTES_PER_FRAME = 2048 + 52  # 1024 int16 in + 13 fp32 out
 KWS_BYTES_PER_UTT = 63488 + 10 + 10 + 4  # 31*1024 int16 in + logits + softmax + argmax out
 
@@ -84,6 +89,20 @@ def hbm_traffic_from_profiles(key):
         h = json.load(open(files[-1]))["hbm"][key]
         return (round(h["FETCH_SIZE_bytes_corrected"] + h["WRITE_SIZE_bytes_corrected"]), os.path.relpath(files[-1], ROOT))
     except (KeyError, ValueError):
+        return None
+
+
+def cnn_counters_from_profiles():
+    """Matrix-core counters of ed_cnn_mfma_kernel from the newest committed counter pass (tools/profile_cnn.sh), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cnn_counters.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        d["source"] = os.path.relpath(files[-1], ROOT)
+        return d
+    except ValueError:
         return None
 
 
@@ -183,6 +202,21 @@ def _synth_frames_np(n_frames, seed):
     return np.clip(x, -32768, 32767).astype(np.int16).reshape(-1)
 
 
+def _cgroup_cpu_quota():
+    """CPU quota of this container in cores (cgroup v2 cpu.max, v1 cfs_quota_us / cfs_period_us), or None."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / p if q > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def _median_rate(fn, units, passes=3):
     """one warm-up pass, then >= 3 timed passes, the median."""
     fn()
@@ -201,10 +235,16 @@ def cpu_baseline():
     from oracle import oracle
     oracle.use_native_build()
     nproc = os.cpu_count()
-    n_all = len(os.sched_getaffinity(0))
-    print("cpu_baseline: nproc=%d, usable cores (affinity)=%d; legs: 1 thread and %d threads" % (nproc, n_all, n_all),
-          file=sys.stderr, flush=True)
-    host = dict(nproc=nproc, usable_cores=n_all, build="gcc -O3 -march=native -fopenmp (oracle/Makefile native)", passes=3)
+    n_aff = len(os.sched_getaffinity(0))
+    quota = _cgroup_cpu_quota()
+    # "all host cores" = the cores this process may actually run on at once: its affinity mask, cut by the container's CPU
+    # quota when there is one (a GPU box hands a 1-GPU job a 16-core share of a 256-thread host: 256 OpenMP threads on
+    # it measure the scheduler, not the code)
+    n_all = max(1, min(n_aff, int(quota + 0.999))) if quota else n_aff
+    print("cpu_baseline: nproc=%d, affinity=%d cores, cgroup CPU quota=%s; legs: 1 thread and %d threads" % (
+        nproc, n_aff, "%.1f cores" % quota if quota else "none", n_all), file=sys.stderr, flush=True)
+    host = dict(nproc=nproc, affinity_cores=n_aff, cgroup_quota_cores=quota, threads_all_cores_leg=n_all,
+                build="gcc -O3 -march=native -fopenmp (oracle/Makefile native)", passes=3)
     res = {}
     x = _synth_frames_np(65536, 20)                                   # seed 20: SURVEY.md 8(d) config 2
     n1 = 4096                                                         # 1-thread sample: ~0.1-0.2 s per pass
@@ -290,7 +330,7 @@ def main():
     wall_ms, ev_ms = timed_region(mfcc_step, args.steps, args.warmup, world, args.settle_ms)
     frames_per_s = world * nf / (wall_ms * 1e-3)
     ach = MFCC_BYTES_PER_FRAME * nf / (ev_ms * 1e-3) / 1e9
-    roofline = dict(bound="hbm", kernel="ed_mfcc2_kernel<true, 2, 5>", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+    roofline = dict(bound="hbm", kernel="ed_mfcc2_kernel<true, true, 2, 5>", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, bytes_per_unit=MFCC_BYTES_PER_FRAME,
                     units_per_launch=nf, kernel_ms=round(ev_ms, 4))
     checksum = float(out.double().sum().item())
@@ -325,10 +365,28 @@ def main():
         if qtr is not None:
             q15["roofline"]["traffic"] = qtr[0]
             q15["roofline"]["traffic_source"] = qtr[1]
+    # ------------------------------------------------------------------ variant D: the firmware's float32 extractor, 512-sample frames at hop 256
+    variant_d = None
+    try:
+        from edison_amd.mfcc.mfcc_f32 import MfccF32
+        md = MfccF32(ctx=ctx)
+        flat = bufs[0].reshape(-1)
+        nfd = (flat.numel() - 512) // 256 + 1
+        outd = torch.empty((nfd, md.n_out), dtype=torch.int8, device=dev)
+
+        def d_step(i):
+            md.compute_t(bufs[i % len(bufs)].reshape(-1), nfd, 256, outd)
+        d_ms, dev_ms = timed_region(d_step, max(20, args.steps // 4), min(args.warmup, 50), world)
+        variant_d = dict(metric="MFCC frames/sec, variant D (firmware float32 ML-KWS extractor, 512-sample frames, hop 256)", unit="frames/s",
+                         value=round(world * nfd / (d_ms * 1e-3), 1), ms_per_step=round(d_ms, 4), kernel_ms=round(dev_ms, 4),
+                         frames_per_step=nfd, parity="unpinned (no reference vectors; checker oracle/mfcc_f32_ref.c)")
+        md.close()
+    except Exception as e:  # an extra workload must never cost the headline numbers
+        variant_d = dict(error=repr(e))
     del bufs
     # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
     # this command, FETCH_SIZE doubled as the gfx950 guide prescribes); only valid for the default batch size
-    tr = hbm_traffic_from_profiles("ed_mfcc2_kernel<true, 2, 5>:short") if nf == 65536 else None
+    tr = hbm_traffic_from_profiles("ed_mfcc2_kernel<true, true, 2, 5>:short") if nf == 65536 else None
     if tr is not None:
         roofline["traffic"] = tr[0]
         roofline["traffic_source"] = tr[1]
@@ -388,10 +446,33 @@ def main():
                    mfcc_frames_per_s=round(inf_per_s * 31, 1), ms_per_step=round(kw_ms, 4),
                    config=dict(workload="kws_full_%d_utt_per_gpu_x31_frames_mfccB_int8cnn" % nu, global_batch=world * nu,
                                collective=collective),
-                   roofline=dict(bound="hbm", kernel="ed_mfcc2_kernel<true, 2, 5> + ed_cnn_mfma_kernel", achieved=round(kach, 1),
+                   roofline=dict(bound="hbm", kernel="ed_mfcc2_kernel<true, false, 2, 5> + ed_cnn_mfma_kernel", achieved=round(kach, 1),
                                  peak=HBM_PEAK_GBS, unit="GB/s", frac=round(kach / HBM_PEAK_GBS, 4), traffic=None,
                                  bytes_per_unit=KWS_BYTES_PER_UTT, units_per_launch=nu, kernel_ms=round(kev_ms, 4)),
                    class_histogram=hist)
+        # ---- the CNN alone on the features of the last step: the matrix-core figure north_star asks for
+        def cnn_step(i):
+            ctx.cnn_t(feat, nu, logits=logits, softmax=soft, argmax=am)
+        c_ms, cev_ms = timed_region(cnn_step, max(20, min(args.steps, 200)), 10, 1 if world == 1 else world)
+        useful = nu * CNN_MACS_PER_UTT * 2 / (cev_ms * 1e-3) / 1e12
+        issued = nu * CNN_MFMA_PER_UTT * 32768 * 2 / (cev_ms * 1e-3) / 1e12
+        kws["cnn"] = dict(metric="int8 CNN alone (ed_cnn_mfma_kernel)", value=round(world * nu / (c_ms * 1e-3), 1), unit="inferences/s",
+                          ms_per_step=round(c_ms, 4),
+                          roofline=dict(bound="mfma_i8", kernel="ed_cnn_mfma_kernel", achieved=round(useful, 1), peak=round(MFMA_I8_PEAK_TOPS, 1),
+                                        unit="TOP/s", frac=round(useful / MFMA_I8_PEAK_TOPS, 4), kernel_ms=round(cev_ms, 4),
+                                        what="achieved = real network MACs (784 752 per utterance) x 2; issued = MFMA instructions x 32 768 MAC x 2",
+                                        issued=round(issued, 1), issued_frac=round(issued / MFMA_I8_PEAK_TOPS, 4),
+                                        counters=cnn_counters_from_profiles()))
+        # ---- the same graph through the GENERAL matrix-core kernel (what any other retrained graph runs on)
+        os.environ["EDISON_NET_FORCE_GENERAL"] = "1"
+        try:
+            def net_step(i):
+                ctx.net_t(feat, nu, logits=logits, argmax=am)
+            g_ms, _ = timed_region(net_step, 10, 2, 1 if world == 1 else world)
+            kws["general_net_kernel"] = dict(value=round(world * nu / (g_ms * 1e-3), 1), unit="inputs/s", ms_per_step=round(g_ms, 4),
+                                             what="kws_conv graph forced onto ed_net_mfma_kernel (edison_net_batch_dev, EDISON_NET_FORCE_GENERAL=1)")
+        finally:
+            del os.environ["EDISON_NET_FORCE_GENERAL"]
         if not args.skip_q15:
             # the same utterances with the firmware's own features (variant C): what the board would answer, at GPU speed
             def kws_q15_step(i):
@@ -429,6 +510,8 @@ def main():
                                 frame_len=1024, parallelism="dp%d" % world, rotate_buffers=args.rotate, settle_ms=args.settle_ms),
                     roofline=roofline, device=info["name"], checksum=checksum)
         line["mfcc_variant_a"] = variant_a
+        if variant_d is not None:
+            line["mfcc_variant_d"] = variant_d
         if q15 is not None:
             line["mfcc_q15"] = q15
             if cpu is not None and "q15" in cpu:

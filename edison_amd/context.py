@@ -249,6 +249,10 @@ class Context:
         self._check(self._L.edison_cnn_batch_dev(self._h, _t_ptr(feat), int(n_utt), _t_ptr(logits), _t_ptr(softmax),
                                                  _t_ptr(argmax)))
 
+    def net_t(self, x, n, logits=None, softmax=None, argmax=None):
+        """Any loaded graph on device tensors (edison_net_batch_dev)."""
+        self._check(self._L.edison_net_batch_dev(self._h, _t_ptr(x), int(n), _t_ptr(logits), _t_ptr(softmax), _t_ptr(argmax)))
+
     def kws_t(self, audio, n_utt, utt_stride, feat=None, logits=None, softmax=None, argmax=None, q15=False):
         fn = self._L.edison_kws_batch_q15_dev if q15 else self._L.edison_kws_batch_dev
         self._check(fn(self._h, _t_ptr(audio), int(n_utt), int(utt_stride), _t_ptr(feat), _t_ptr(logits),

@@ -41,7 +41,8 @@ static int net_launch(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *logi
 	if (softmax && !ctx->net.has_softmax) return ed_set_err(ctx, EDISON_E_ARGUMENT, "the loaded model has no Softmax layer; pass softmax = NULL");
 	if (n >= ((int64_t)1 << 31)) return ed_set_err(ctx, EDISON_E_ARGUMENT, "too many inputs per call");
 	/* the shipped graph keeps its matrix-core kernel; per-layer dumps always come from the general kernel */
-	static const int force_general = getenv("EDISON_NET_FORCE_GENERAL") ? atoi(getenv("EDISON_NET_FORCE_GENERAL")) : 0; /* A/B knob */
+	const char *fg_ = getenv("EDISON_NET_FORCE_GENERAL"); /* A/B knob, read per call: keep the shipped graph off its specialised kernel */
+	const int force_general = fg_ ? atoi(fg_) : 0;
 	if (allow_fast && ctx->fast_model && !acts && !force_general)
 		return ed_ctx_kws_cnn_launch(ctx, in, n, ctx->net.in_n, logits, softmax, argmax);
 	int e = acts ? ed_launch_net(ctx->d_net_plan, ctx->d_net_w, ctx->d_net_seeds, ctx->net.lds_bytes, in, n, ctx->net.in_n, logits, softmax,

@@ -43,4 +43,13 @@ if dur:
         n_mfma * 32768 * 2 / (d * 1e-9) / 1e15, 100 * n_mfma * 32768 * 2 / (d * 1e-9) / 5.03e15))
     print("useful int8 MAC rate (784 752 MAC per utterance): %.2f POP/s = %.1f %% of peak" % (
         262144 * 784752 * 2 / (d * 1e-9) / 1e15, 100 * 262144 * 784752 * 2 / (d * 1e-9) / 5.03e15))
+    import json
+    clk = c.get("GRBM_GUI_ACTIVE", 0) / 8 / (d * 1e-9) / 1e9 if d else 0
+    json.dump(dict(utterances_per_launch=262144, kernel_us_unprofiled=d / 1e3, mfma_instructions=n_mfma, mfma_per_utterance=n_mfma / 262144,
+                   SQ_VALU_MFMA_BUSY_CYCLES=busy, mfma_busy_cycles_per_simd=busy / 1024,
+                   mfma_pipe_busy_frac_at_2p4GHz=busy / 1024 / (d * 2.4), SQ_VALU_MFMA_COEXEC_CYCLES=c.get("SQ_VALU_MFMA_COEXEC_CYCLES"),
+                   SQ_ACTIVE_INST_VALU_quadcycles=c.get("SQ_ACTIVE_INST_VALU"), SQ_LDS_IDX_ACTIVE=c.get("SQ_LDS_IDX_ACTIVE"),
+                   SQ_LDS_BANK_CONFLICT=c.get("SQ_LDS_BANK_CONFLICT"), clock_GHz_from_GRBM_GUI_ACTIVE_profiled_pass=clk,
+                   note="counters: mean per launch over separate rocprofv3 --pmc passes; duration: kernel trace pass without counters"),
+              open(sys.argv[1] + "/cnn_counters.json", "w"), indent=1)
 PY
