@@ -32,8 +32,10 @@ extern "C" void ed_set_net_debug_buffer(void *p) { (void)hipMemcpyToSymbol(HIP_S
 #else
 #define EMM_ST(i)
 #endif
-#define EMM_THREADS 512
-#define EMM_WAVES 8
+#ifndef EMM_THREADS
+#define EMM_THREADS 1024 /* 16 waves: the phases between barriers are short and latency-bound (+12 % over 8 waves) */
+#endif
+#define EMM_WAVES (EMM_THREADS / 64)
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -153,17 +155,22 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 			__syncthreads();
 		}
 		EMM_ST(0)
+		int cur = 0;
 		for (int li = 0; li < n_layers; li++)
 		{
 			const ed_net_layer_t L = PL[li];
 			const ed_mm_layer_t ML = MLs[li];
-			const emm_layout lin = emm_in_layout(MLs, PL, n_layers, li), lo = emm_in_layout(MLs, PL, n_layers, li + 1);
-			const int8_t *a = bufs[li & 1];
-			int8_t *o = bufs[(li + 1) & 1];
+			if (ML.skip) continue; /* a MaxPool taken in the epilogue of the layer in front of it */
+			const int fused = ML.pool_h > 0, lnx = fused ? li + 2 : li + 1; /* the layer that consumes what this one stores */
+			const emm_layout lin = emm_in_layout(MLs, PL, n_layers, li), lo = emm_in_layout(MLs, PL, n_layers, lnx);
+			const int st_h = fused ? PL[li + 1].out_h : L.out_h, st_w = fused ? PL[li + 1].out_w : L.out_w; /* stored tensor */
+			const int8_t *a = bufs[cur];
+			int8_t *o = bufs[cur ^ 1];
+			cur ^= 1;
 			const int oc_pitch = L.out_c;                           /* bytes per output pixel */
 			const int o_origin = (lo.py * lo.wp + lo.px) * oc_pitch; /* where pixel (0, 0) goes */
 			const int o_row = lo.wp * oc_pitch;
-			if (lo.hp != L.out_h || lo.wp != L.out_w) /* uniform: the consumer wants a zero border */
+			if (lo.hp != st_h || lo.wp != st_w) /* uniform: the consumer wants a zero border */
 			{
 				emm_zero(o, batch * lo.img);
 				__syncthreads();
@@ -172,6 +179,8 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 			{
 				const int dense = L.type == ED_NET_DENSE;
 				const int out_h = dense ? 1 : L.out_h, out_w = dense ? 1 : L.out_w, sh = dense ? 1 : L.sh;
+				const int ph = fused ? ML.pool_h : 1, pw = fused ? ML.pool_w : 1, nwin = ph * pw; /* accumulator tiles per column */
+				const int col_h = dense ? 1 : st_h, col_w = dense ? 1 : st_w;                       /* columns = stored pixels */
 				const int8_t *bsrc = a;
 				int img = lin.img;
 				if (ML.expand)
@@ -184,11 +193,21 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 					{
 						int b, e, r, e2, xo, j;
 						emm_divmod(i, rec_per_img, inv_rec, b, e); emm_divmod(e, out_w * ML.cpr, inv_row, r, e2); emm_divmod(e2, ML.cpr, inv_cpr, xo, j);
-						const int8_t *src = a + b * lin.img + (r * lin.wp + xo * sw) * in_c + 16 * j;
-						uint32_t d[4] = {0, 0, 0, 0};
+						/* 16 bytes from an arbitrary byte offset: five aligned dwords around them, funnel-shifted (v_alignbit), the
+						 * bytes past the end of the kernel-row segment zeroed (the image buffers carry 16 bytes of slack) */
+						const int soff = b * lin.img + (r * lin.wp + xo * sw) * in_c + 16 * j;
+						const uint32_t *s4 = reinterpret_cast<const uint32_t *>(a + (soff & ~3));
+						const uint32_t sh = (uint32_t)(soff & 3) * 8;
+						const uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2], w3 = s4[3], w4 = s4[4];
+						uint32_t d[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),
+						                 __builtin_amdgcn_alignbit(w3, w2, sh), __builtin_amdgcn_alignbit(w4, w3, sh)};
+						const int keep = seg - 16 * j; /* bytes of this chunk that belong to the segment (>= 1) */
 #pragma unroll
-						for (int t = 0; t < 16; t++)
-							if (16 * j + t < seg) d[t >> 2] |= (uint32_t)(uint8_t)src[t] << (8 * (t & 3));
+						for (int t = 0; t < 4; t++)
+						{
+							const int kb = keep - 4 * t;
+							d[t] = kb >= 4 ? d[t] : (kb <= 0 ? 0u : d[t] & (0xffffffffu >> (8 * (4 - kb))));
+						}
 						*reinterpret_cast<uint4 *>(xbuf + b * ML.x_img + r * ML.pitch_y + xo * ML.pitch_x + 16 * j) = make_uint4(d[0], d[1], d[2], d[3]);
 					}
 					bsrc = xbuf;
@@ -203,9 +222,9 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 					for (int i = threadIdx.x; i < ML.n_rt * ML.n_ks * 64; i += EMM_THREADS) dst[i] = src[i];
 				}
 				__syncthreads();
-				const int pix_per_img = out_h * out_w, n_cols = nb * pix_per_img, n_ct = (n_cols + 31) / 32;
+				const int pix_per_img = col_h * col_w, n_cols = nb * pix_per_img, n_ct = (n_cols + 31) / 32;
 				const int rs = L.rs, lo_clamp = L.relu ? 0 : -128;
-				const float inv_rt = 1.0f / (float)ML.n_rt, inv_ppi = 1.0f / (float)pix_per_img, inv_ow = 1.0f / (float)out_w;
+				const float inv_rt = 1.0f / (float)ML.n_rt, inv_ppi = 1.0f / (float)pix_per_img, inv_ow = 1.0f / (float)col_w;
 				for (int t = wave; t < n_ct * ML.n_rt; t += EMM_WAVES)
 				{
 					int ct, rt;
@@ -214,29 +233,45 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 					const bool live = q < n_cols;
 					const int qq = live ? q : n_cols - 1;
 					int b, pp, y, x;
-					emm_divmod(qq, pix_per_img, inv_ppi, b, pp); emm_divmod(pp, out_w, inv_ow, y, x);
-					const int8_t *bp = bsrc + b * img + (y * sh) * ML.pitch_y + x * ML.pitch_x;
+					emm_divmod(qq, pix_per_img, inv_ppi, b, pp); emm_divmod(pp, col_w, inv_ow, y, x);
 					const int8_t *fp = (frag_mode == 2 ? fragl + ML.frag_off : frag_mode == 1 ? fragl : frag + ML.frag_off) +
 					                   (size_t)rt * ML.n_ks * 1024 + lane * 16;
-					v16i acc;
+					v16i seedv;
 					{
 						const int32_t *sp = seeds_l + ML.seed_off + 32 * rt + 4 * h;
 #pragma unroll
 						for (int g = 0; g < 4; g++)
 						{
 							const v4i s4 = *reinterpret_cast<const v4i *>(sp + 8 * g);
-							acc[4 * g] = s4.x; acc[4 * g + 1] = s4.y; acc[4 * g + 2] = s4.z; acc[4 * g + 3] = s4.w;
+							seedv[4 * g] = s4.x; seedv[4 * g + 1] = s4.y; seedv[4 * g + 2] = s4.z; seedv[4 * g + 3] = s4.w;
 						}
 					}
-					/* operands of k-step s + 1 are fetched before the MFMA of k-step s */
-					v4i av = *reinterpret_cast<const v4i *>(fp), bv = *reinterpret_cast<const v4i *>(bp + koff[h]);
-					for (int s = 0; s < ML.n_ks; s++)
+					/* one accumulator tile per position of the pooling window (one in all when nothing is fused); the
+					 * window's conv pixels are (y * ph + wy, x * pw + wx) */
+					v16i acc = seedv;
+#pragma unroll
+					for (int w = 0; w < 4; w++)
 					{
-						const int sn = s + 1 < ML.n_ks ? s + 1 : s;
-						const v4i an = *reinterpret_cast<const v4i *>(fp + (size_t)sn * 1024);
-						const v4i bn = *reinterpret_cast<const v4i *>(bp + koff[2 * sn + h]);
-						acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, acc, 0, 0, 0);
-						av = an; bv = bn;
+						if (w >= nwin) break;
+						const int wy = w / pw, wx = w - wy * pw;
+						const int8_t *bp = bsrc + b * img + ((y * ph + wy) * sh) * ML.pitch_y + (x * pw + wx) * ML.pitch_x;
+						v16i aw = seedv;
+						/* operands of k-step s + 1 are fetched before the MFMA of k-step s */
+						v4i av = *reinterpret_cast<const v4i *>(fp), bv = *reinterpret_cast<const v4i *>(bp + koff[h]);
+						for (int s = 0; s < ML.n_ks; s++)
+						{
+							const int sn = s + 1 < ML.n_ks ? s + 1 : s;
+							const v4i an = *reinterpret_cast<const v4i *>(fp + (size_t)sn * 1024);
+							const v4i bn = *reinterpret_cast<const v4i *>(bp + koff[2 * sn + h]);
+							aw = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, aw, 0, 0, 0);
+							av = an; bv = bn;
+						}
+						if (w == 0) acc = aw;
+						else
+						{
+#pragma unroll
+							for (int i = 0; i < 16; i++) acc[i] = aw[i] > acc[i] ? aw[i] : acc[i];
+						}
 					}
 					/* lane (column, h) holds rows 32 rt + 8 g + 4 h .. +3 in registers 4g..4g+3 */
 					int8_t *op = o + b * lo.img + o_origin + y * o_row + x * oc_pitch;

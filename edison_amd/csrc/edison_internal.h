@@ -251,6 +251,11 @@ typedef struct {
 	int32_t frag_off;           /* byte offset of the fragments in the fragment buffer                                */
 	int32_t seed_off;           /* index of the 32 * n_rt padded seeds                                                */
 	int32_t koff_off;           /* index into koff[]: byte offset of chunk c = 2 s + h inside the image (ky * pitch_y + 16 j) */
+	int32_t pool_h, pool_w;     /* > 0: the MaxPool that follows (window = stride, no padding) is taken in this layer's
+	                             * epilogue -- maximum of the accumulator tiles of the window, then ONE requantisation
+	                             * (exact: the requantisation is monotone) -- and the pool layer itself is skipped       */
+	int32_t skip;               /* 1: this MaxPool is fused into the layer in front of it                              */
+	int32_t pad_;
 } ed_mm_layer_t;
 
 typedef struct {

@@ -81,14 +81,29 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		if (n_koff > ED_MM_MAX_KOFF || 2 * M->n_ks > 256 || frag_bytes > ((size_t)64 << 20)) return EDISON_OK; /* mm->ok stays 0 */
 	}
 
+	/* MaxPool right behind a matrix-core layer, window = stride, no padding, at most 4 positions: fused into that layer */
+	for (int i = 0; i + 1 < n_layers; i++)
+	{
+		const ed_net_layer_t *C = &plan->L[i], *Q = &plan->L[i + 1];
+		if (!mm->L[i].mm || C->type != ED_NET_CONV || Q->type != ED_NET_POOL) continue;
+		if (Q->pad_h || Q->pad_w || Q->check_taps || Q->kh != Q->sh || Q->kw != Q->sw || Q->kh * Q->kw < 2 || Q->kh * Q->kw > 4) continue;
+		if (Q->out_h * Q->kh > C->out_h || Q->out_w * Q->kw > C->out_w) continue;
+		mm->L[i].pool_h = Q->kh; mm->L[i].pool_w = Q->kw;
+		mm->L[i + 1].skip = 1;
+		mm->L[i + 1].in_img = 0; /* the unpooled tensor never exists */
+	}
+
 	/* LDS budget: two ping-pong buffers of batch x the largest image layout, the expansion buffer, the koff table */
 	int max_img = up16(plan->in_n) + 16, max_x = 0;
 	for (int i = 0; i < n_layers; i++)
 	{
 		if (mm->L[i].in_img > max_img) max_img = mm->L[i].in_img;
 		if (mm->L[i].x_img > max_x) max_x = mm->L[i].x_img;
-		const int out_img = up16(plan->L[i].out_n) + 16; /* the last layer's compact output */
-		if (out_img > max_img) max_img = out_img;
+		if (i == n_layers - 1)
+		{
+			const int out_img = up16(plan->L[i].out_n) + 16; /* the last layer's compact output */
+			if (out_img > max_img) max_img = out_img;
+		}
 	}
 	/* Where the weight fragments live while a workgroup runs, best first: (2) ALL layers resident in LDS for the whole
 	 * launch (one L2 read per workgroup), (1) one layer at a time, re-staged per batch, (0) streamed from L2 per MFMA.
@@ -163,11 +178,14 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 	{
 		const ed_net_layer_t *L = &plan->L[i];
 		const ed_mm_layer_t *M = &mm->L[i];
+		if (M->skip) continue; /* fused MaxPool: nothing runs for it */
 		int ohp, owp, opy, opx, oimg; /* the consumer's layout = where this layer's epilogue stores */
-		if (i + 1 < n_layers) { ohp = mm->L[i + 1].in_hp; owp = mm->L[i + 1].in_wp; opy = mm->L[i + 1].in_py; opx = mm->L[i + 1].in_px; oimg = mm->L[i + 1].in_img; }
-		else { ohp = L->out_h; owp = L->out_w; opy = 0; opx = 0; oimg = up16(L->out_n) + 16; }
-		const int64_t last_store = ((int64_t)(L->out_h - 1 + opy) * owp + (L->out_w - 1 + opx)) * L->out_c + L->out_c;
-		int bad = last_store > oimg || ohp < L->out_h + opy || owp < L->out_w + opx || oimg > mm->buf_bytes / batch;
+		const int fused = M->pool_h > 0, nx = fused ? i + 2 : i + 1;          /* the consumer */
+		const int st_h = fused ? plan->L[i + 1].out_h : L->out_h, st_w = fused ? plan->L[i + 1].out_w : L->out_w; /* what is stored */
+		if (nx < n_layers) { ohp = mm->L[nx].in_hp; owp = mm->L[nx].in_wp; opy = mm->L[nx].in_py; opx = mm->L[nx].in_px; oimg = mm->L[nx].in_img; }
+		else { ohp = st_h; owp = st_w; opy = 0; opx = 0; oimg = up16(st_h * st_w * L->out_c) + 16; }
+		const int64_t last_store = ((int64_t)(st_h - 1 + opy) * owp + (st_w - 1 + opx)) * L->out_c + L->out_c;
+		int bad = last_store > oimg || ohp < st_h + opy || owp < st_w + opx || oimg > mm->buf_bytes / batch;
 		if (M->mm)
 		{
 			const int dense = L->type == ED_NET_DENSE;
