@@ -10,10 +10,11 @@
  * Scheme (ed_mm_plan_t, model_net_mm.c): implicit GEMM D[out_channel][pixel] with k = (kernel row, 16-byte chunk of the
  * row's contiguous kw * C_in input bytes). The consumer layer dictates how its input lies in LDS: zero-padded so that no
  * tap test is needed; the producing layer's epilogue writes straight into that layout. Layers whose C_in is not a
- * multiple of 16 read from an expanded copy with one aligned record per (input row, output x). A workgroup of 8 waves
- * takes `batch` inputs through the layer list; column tiles (32 pixels) x row tiles (32 channels) are dealt to the waves.
- * The weight fragments stay in LDS for the whole launch when they fit beside the activations (mode 2), else one layer
- * at a time (1), else they stream from L2 (0).
+ * multiple of 16 read from an expanded copy with one aligned record per (input row, output x). A WAVEFRONT takes `batch`
+ * inputs through the whole layer list by itself in its own slice of LDS -- no workgroup barrier in the loop (a wave's DS
+ * instructions are serviced in order); the first version ran the workgroup in lockstep phases and spent a third of its
+ * time in barriers. The weight fragments stay in LDS for the whole launch, shared by the waves, when they fit beside the
+ * activation slices (mode 2), else they stream from L2 (0).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,14 +29,11 @@
 #if EMM_STAMP
 __device__ unsigned long long *g_emm_dbg = nullptr;
 extern "C" void ed_set_net_debug_buffer(void *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_emm_dbg), &p, sizeof(p)); }
-#define EMM_ST(i) { __syncthreads(); unsigned long long n_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n_) :: "memory"); ph[i] += n_ - tl_; tl_ = n_; }
+#define EMM_ST(i) { unsigned long long n_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n_) :: "memory"); stamp_[i] += n_ - tl_; tl_ = n_; }
 #else
 #define EMM_ST(i)
 #endif
-#ifndef EMM_THREADS
-#define EMM_THREADS 1024 /* 16 waves: the phases between barriers are short and latency-bound (+12 % over 8 waves) */
-#endif
-#define EMM_WAVES (EMM_THREADS / 64)
+#define EMM_MAX_THREADS 1024
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -69,12 +67,16 @@ __device__ __forceinline__ emm_layout emm_in_layout(const ed_mm_layer_t *ML, con
 	return l;
 }
 
-__device__ __forceinline__ void emm_zero(int8_t *buf, int bytes)
+__device__ __forceinline__ void emm_zero(int8_t *buf, int bytes, int lane)
 {
-	for (int i = threadIdx.x * 16; i < bytes; i += EMM_THREADS * 16) *reinterpret_cast<uint4 *>(buf + i) = make_uint4(0, 0, 0, 0);
+	for (int i = lane * 16; i < bytes; i += 64 * 16) *reinterpret_cast<uint4 *>(buf + i) = make_uint4(0, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_plan_t *__restrict__ P, const ed_mm_plan_t *__restrict__ M,
+/* Order this wave's LDS writes before its following LDS reads: DS instructions of a wave are issued and serviced in
+ * order; the (code-less) wave barrier keeps the compiler from moving memory operations across. */
+__device__ __forceinline__ void emm_sync() { __builtin_amdgcn_wave_barrier(); }
+
+__global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_net_plan_t *__restrict__ P, const ed_mm_plan_t *__restrict__ M,
                                                                  const int8_t *__restrict__ frag, const int32_t *__restrict__ seeds,
                                                                  const int8_t *__restrict__ in, int64_t n, int64_t in_stride,
                                                                  int8_t *__restrict__ logits, int8_t *__restrict__ softmax,
@@ -82,44 +84,46 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 {
 	extern __shared__ __attribute__((aligned(16))) int8_t emm_lds[];
 	const int n_layers = P->n_layers, batch = M->batch, buf_bytes = M->buf_bytes;
-	int8_t *bufs[2] = {emm_lds, emm_lds + buf_bytes};
-	int8_t *xbuf = emm_lds + 2 * buf_bytes;
-	/* small tables, copied once per workgroup: chunk offsets of every layer | seeds | layer records */
-	int8_t *tbl = emm_lds + 2 * buf_bytes + M->x_bytes;
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, h = lane >> 5;
+	const int n_threads = blockDim.x, n_waves = n_threads >> 6;
+	/* small tables, copied once per workgroup: chunk offsets of every layer | seeds | layer records; then the weight
+	 * fragments (mode 2); then one slice per wave: two ping-pong activation buffers and the expansion buffer */
+	int8_t *tbl = emm_lds;
 	const int n_koff = M->n_koff, n_seeds = M->n_seeds;
 	int *koff_all = reinterpret_cast<int *>(tbl);
 	int32_t *seeds_l = reinterpret_cast<int32_t *>(tbl + ((4 * n_koff + 15) & ~15));
 	ed_net_layer_t *PL = reinterpret_cast<ed_net_layer_t *>(reinterpret_cast<int8_t *>(seeds_l) + ((4 * n_seeds + 15) & ~15));
 	ed_mm_layer_t *MLs = reinterpret_cast<ed_mm_layer_t *>(reinterpret_cast<int8_t *>(PL) + ((n_layers * (int)sizeof(ed_net_layer_t) + 15) & ~15));
-	int8_t *fragl = tbl + M->tbl_bytes; /* weight fragments: all layers (mode 2) or the running layer (mode 1) */
+	int8_t *fragl = tbl + M->tbl_bytes;
 	const int frag_mode = M->frag_mode;
+	int8_t *slice = fragl + M->frag_lds + wave * (2 * buf_bytes + M->x_bytes);
+	int8_t *bufs[2] = {slice, slice + buf_bytes};
+	int8_t *xbuf = slice + 2 * buf_bytes;
 	{
-		for (int i = threadIdx.x; i < n_koff; i += EMM_THREADS) koff_all[i] = M->koff[i];
-		for (int i = threadIdx.x; i < n_seeds; i += EMM_THREADS) seeds_l[i] = seeds[i];
+		for (int i = threadIdx.x; i < n_koff; i += n_threads) koff_all[i] = M->koff[i];
+		for (int i = threadIdx.x; i < n_seeds; i += n_threads) seeds_l[i] = seeds[i];
 		const int *s1 = reinterpret_cast<const int *>(&P->L[0]);
 		int *d1 = reinterpret_cast<int *>(PL);
-		for (int i = threadIdx.x; i < n_layers * (int)(sizeof(ed_net_layer_t) / 4); i += EMM_THREADS) d1[i] = s1[i];
+		for (int i = threadIdx.x; i < n_layers * (int)(sizeof(ed_net_layer_t) / 4); i += n_threads) d1[i] = s1[i];
 		const int *s2 = reinterpret_cast<const int *>(&M->L[0]);
 		int *d2 = reinterpret_cast<int *>(MLs);
-		for (int i = threadIdx.x; i < n_layers * (int)(sizeof(ed_mm_layer_t) / 4); i += EMM_THREADS) d2[i] = s2[i];
+		for (int i = threadIdx.x; i < n_layers * (int)(sizeof(ed_mm_layer_t) / 4); i += n_threads) d2[i] = s2[i];
 		if (frag_mode == 2)
 		{
-			/* every layer's fragments, once per workgroup */
 			const uint4 *src = reinterpret_cast<const uint4 *>(frag);
 			uint4 *dst = reinterpret_cast<uint4 *>(fragl);
-			for (int i = threadIdx.x; i < M->frag_bytes / 16; i += EMM_THREADS) dst[i] = src[i];
+			for (int i = threadIdx.x; i < M->frag_bytes / 16; i += n_threads) dst[i] = src[i];
 		}
 	}
-	__syncthreads();
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+	__syncthreads(); /* the only workgroup barrier: from here on every wave is on its own */
 	const int out_n = P->out_n, logits_layer = P->logits_layer, has_softmax = P->has_softmax;
 
 #if EMM_STAMP
-	unsigned long long ph[48], tl_;
-	for (int i = 0; i < 48; i++) ph[i] = 0;
+	unsigned long long stamp_[48], tl_;
+	for (int i = 0; i < 48; i++) stamp_[i] = 0;
 	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_) :: "memory");
 #endif
-	for (int64_t u0 = (int64_t)blockIdx.x * batch; u0 < n; u0 += (int64_t)gridDim.x * batch)
+	for (int64_t u0 = ((int64_t)blockIdx.x * n_waves + wave) * batch; u0 < n; u0 += (int64_t)gridDim.x * n_waves * batch)
 	{
 		const int nb = (int)((n - u0) < batch ? (n - u0) : batch);
 		EMM_ST(47)
@@ -128,15 +132,15 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 			const emm_layout l0 = emm_in_layout(MLs, PL, n_layers, 0);
 			const int in_h = P->in_h, in_w = P->in_w, in_c = P->in_c, in_n = P->in_n;
 			const float inv_n = 1.0f / (float)in_n, inv_c = 1.0f / (float)in_c, inv_w = 1.0f / (float)in_w;
-			emm_zero(bufs[0], batch * l0.img);
-			__syncthreads();
-			for (int i0 = 0; i0 < nb * in_n; i0 += 8 * EMM_THREADS)
+			emm_zero(bufs[0], batch * l0.img, lane);
+			emm_sync();
+			for (int i0 = 0; i0 < nb * in_n; i0 += 8 * 64)
 			{
 				int8_t v[8];
 #pragma unroll
 				for (int k = 0; k < 8; k++)
 				{
-					const int i = i0 + k * EMM_THREADS + threadIdx.x;
+					const int i = i0 + k * 64 + lane;
 					int b, e;
 					emm_divmod(i, in_n, inv_n, b, e);
 					v[k] = i < nb * in_n ? in[(u0 + b) * in_stride + e] : 0;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 #pragma unroll
 				for (int k = 0; k < 8; k++)
 				{
-					const int i = i0 + k * EMM_THREADS + threadIdx.x;
+					const int i = i0 + k * 64 + lane;
 					if (i >= nb * in_n) continue;
 					int b, e, pix, c, y, x;
 					emm_divmod(i, in_n, inv_n, b, e); emm_divmod(e, in_c, inv_c, pix, c); emm_divmod(pix, in_w, inv_w, y, x);
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 				}
 			}
 			(void)in_h;
-			__syncthreads();
+			emm_sync();
 		}
 		EMM_ST(0)
 		int cur = 0;
@@ -172,13 +176,13 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 			const int o_row = lo.wp * oc_pitch;
 			if (lo.hp != st_h || lo.wp != st_w) /* uniform: the consumer wants a zero border */
 			{
-				emm_zero(o, batch * lo.img);
-				__syncthreads();
+				emm_zero(o, batch * lo.img, lane);
+				emm_sync();
 			}
 			if (ML.mm)
 			{
 				const int dense = L.type == ED_NET_DENSE;
-				const int out_h = dense ? 1 : L.out_h, out_w = dense ? 1 : L.out_w, sh = dense ? 1 : L.sh;
+				const int out_w = dense ? 1 : L.out_w, sh = dense ? 1 : L.sh;
 				const int ph = fused ? ML.pool_h : 1, pw = fused ? ML.pool_w : 1, nwin = ph * pw; /* accumulator tiles per column */
 				const int col_h = dense ? 1 : st_h, col_w = dense ? 1 : st_w;                       /* columns = stored pixels */
 				const int8_t *bsrc = a;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 					const int in_c = dense ? L.in_n : L.in_c, seg = (dense ? 1 : L.kw) * in_c, sw = dense ? 1 : L.sw;
 					const int rec_per_img = (dense ? 1 : lin.hp) * out_w * ML.cpr;
 					const float inv_rec = 1.0f / (float)rec_per_img, inv_row = 1.0f / (float)(out_w * ML.cpr), inv_cpr = 1.0f / (float)ML.cpr;
-					for (int i = threadIdx.x; i < nb * rec_per_img; i += EMM_THREADS)
+					for (int i = lane; i < nb * rec_per_img; i += 64)
 					{
 						int b, e, r, e2, xo, j;
 						emm_divmod(i, rec_per_img, inv_rec, b, e); emm_divmod(e, out_w * ML.cpr, inv_row, r, e2); emm_divmod(e2, ML.cpr, inv_cpr, xo, j);
@@ -215,17 +219,11 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 				}
 				EMM_ST(1 + 5 * li)
 				const int *koff = koff_all + ML.koff_off;
-				if (frag_mode == 1)
-				{
-					const uint4 *src = reinterpret_cast<const uint4 *>(frag + ML.frag_off);
-					uint4 *dst = reinterpret_cast<uint4 *>(fragl);
-					for (int i = threadIdx.x; i < ML.n_rt * ML.n_ks * 64; i += EMM_THREADS) dst[i] = src[i];
-				}
-				__syncthreads();
+				emm_sync();
 				const int pix_per_img = col_h * col_w, n_cols = nb * pix_per_img, n_ct = (n_cols + 31) / 32;
 				const int rs = L.rs, lo_clamp = L.relu ? 0 : -128;
 				const float inv_rt = 1.0f / (float)ML.n_rt, inv_ppi = 1.0f / (float)pix_per_img, inv_ow = 1.0f / (float)col_w;
-				for (int t = wave; t < n_ct * ML.n_rt; t += EMM_WAVES)
+				for (int t = 0; t < n_ct * ML.n_rt; t++)
 				{
 					int ct, rt;
 					emm_divmod(t, ML.n_rt, inv_rt, ct, rt);
@@ -234,8 +232,7 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 					const int qq = live ? q : n_cols - 1;
 					int b, pp, y, x;
 					emm_divmod(qq, pix_per_img, inv_ppi, b, pp); emm_divmod(pp, col_w, inv_ow, y, x);
-					const int8_t *fp = (frag_mode == 2 ? fragl + ML.frag_off : frag_mode == 1 ? fragl : frag + ML.frag_off) +
-					                   (size_t)rt * ML.n_ks * 1024 + lane * 16;
+					const int8_t *fp = (frag_mode == 2 ? fragl + ML.frag_off : frag + ML.frag_off) + (size_t)rt * ML.n_ks * 1024 + lane * 16;
 					v16i seedv;
 					{
 						const int32_t *sp = seeds_l + ML.seed_off + 32 * rt + 4 * h;
@@ -299,7 +296,7 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 				/* four channels per thread: byte-wise signed maximum of dwords */
 				const int c4n = L.in_c >> 2, per_img = L.out_h * L.out_w * c4n;
 				const float inv_img = 1.0f / (float)per_img, inv_c4 = 1.0f / (float)c4n, inv_ow = 1.0f / (float)L.out_w;
-				for (int i = threadIdx.x; i < nb * per_img; i += EMM_THREADS)
+				for (int i = lane; i < nb * per_img; i += 64)
 				{
 					int b, e, pix, c4, y, x;
 					emm_divmod(i, per_img, inv_img, b, e); emm_divmod(e, c4n, inv_c4, pix, c4); emm_divmod(pix, L.out_w, inv_ow, y, x);
@@ -324,7 +321,7 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 			else if (L.type == ED_NET_POOL)
 			{
 				const int per_img = L.out_n;
-				for (int i = threadIdx.x; i < nb * per_img; i += EMM_THREADS)
+				for (int i = lane; i < nb * per_img; i += 64)
 				{
 					const int b = i / per_img, e = i - b * per_img;
 					const int pix = e / L.in_c, c = e - pix * L.in_c, y = pix / L.out_w, x = pix - y * L.out_w;
@@ -346,10 +343,10 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 			}
 			else /* softmax: arm_softmax_q7.c:215-260, one lane per input */
 			{
-				if ((int)threadIdx.x < nb)
+				if (lane < nb)
 				{
-					const int8_t *v = a + threadIdx.x * lin.img;
-					int8_t *w = o + threadIdx.x * lo.img;
+					const int8_t *v = a + lane * lin.img;
+					int8_t *w = o + lane * lo.img;
 					if (L.in_n <= 16)
 					{
 						/* the usual classifier width: one 16-byte read, everything else in registers */
@@ -386,43 +383,45 @@ __global__ __launch_bounds__(EMM_THREADS) void ed_net_mfma_kernel(const ed_net_p
 				}
 			}
 			EMM_ST(2 + 5 * li)
-			__syncthreads();
+			emm_sync();
 			/* outputs (the layouts of the logits layer's and the last layer's outputs are compact) */
 			if (li == logits_layer && logits)
-				for (int i = threadIdx.x; i < nb * out_n; i += EMM_THREADS)
+				for (int i = lane; i < nb * out_n; i += 64)
 					logits[(u0 + i / out_n) * out_n + i % out_n] = o[(i / out_n) * lo.img + i % out_n];
 			if (li == n_layers - 1)
 			{
 				if (has_softmax && softmax)
-					for (int i = threadIdx.x; i < nb * out_n; i += EMM_THREADS)
+					for (int i = lane; i < nb * out_n; i += 64)
 						softmax[(u0 + i / out_n) * out_n + i % out_n] = o[(i / out_n) * lo.img + i % out_n];
-				if (argmax && (int)threadIdx.x < nb)
+				if (argmax && lane < nb)
 				{
-					const int8_t *v = o + threadIdx.x * lo.img;
+					const int8_t *v = o + lane * lo.img;
 					int best = 0, mx = -129;
 					for (int i = 0; i < out_n; i++)
 						if (v[i] > mx) { mx = v[i]; best = i; }
-					argmax[u0 + threadIdx.x] = best;
+					argmax[u0 + lane] = best;
 				}
 			}
 		}
 		EMM_ST(46)
-		__syncthreads(); /* the next batch overwrites both buffers */
+		emm_sync(); /* the next batch overwrites both buffers */
 	}
 #if EMM_STAMP
-	if (g_emm_dbg && threadIdx.x == 0 && blockIdx.x == 0) for (int i = 0; i < 48; i++) g_emm_dbg[i] = ph[i];
+	if (g_emm_dbg && threadIdx.x == 0 && blockIdx.x == 0) for (int i = 0; i < 48; i++) g_emm_dbg[i] = stamp_[i];
 #endif
 }
 
 extern "C" int ed_launch_net_mfma(const ed_net_plan_t *dev_plan, const ed_mm_plan_t *dev_mm, const int8_t *dev_frag,
-                                  const int32_t *dev_seeds, int lds_bytes, int batch, const int8_t *in, int64_t n, int64_t in_stride,
+                                  const int32_t *dev_seeds, int lds_bytes, int batch, int waves, const int8_t *in, int64_t n, int64_t in_stride,
                                   int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu, hipStream_t stream)
 {
 	if (n <= 0) return 0;
+	if (waves < 1 || waves > EMM_MAX_THREADS / 64) return (int)hipErrorInvalidValue;
 	int per_cu = (160 * 1024) / (lds_bytes + 256);
-	if (per_cu > 8) per_cu = 8;
+	if (per_cu > 32 / waves) per_cu = 32 / waves;
 	if (per_cu < 1) per_cu = 1;
-	int64_t blocks = (n + batch - 1) / batch;
+	const int64_t per_block = (int64_t)batch * waves;
+	int64_t blocks = (n + per_block - 1) / per_block;
 	if (blocks > (int64_t)n_cu * per_cu) blocks = (int64_t)n_cu * per_cu;
 	static int max_lds_set = 0;
 	if (lds_bytes > max_lds_set)
@@ -432,7 +431,7 @@ extern "C" int ed_launch_net_mfma(const ed_net_plan_t *dev_plan, const ed_mm_pla
 		if (e != hipSuccess) return (int)e;
 		max_lds_set = lds_bytes;
 	}
-	hipLaunchKernelGGL(ed_net_mfma_kernel, dim3((unsigned)blocks), dim3(EMM_THREADS), (size_t)lds_bytes, stream, dev_plan, dev_mm,
+	hipLaunchKernelGGL(ed_net_mfma_kernel, dim3((unsigned)blocks), dim3(64 * waves), (size_t)lds_bytes, stream, dev_plan, dev_mm,
 	                   dev_frag, dev_seeds, in, n, in_stride, logits, softmax, argmax);
 	return (int)hipGetLastError();
 }

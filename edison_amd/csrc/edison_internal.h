@@ -237,7 +237,8 @@ int ed_plan_net(const void *blob, size_t blob_bytes, ed_net_plan_t *plan, int8_t
  *   - from an expanded copy with one 16-byte-aligned record per (input row, output x) otherwise (first layers, RGB).
  * A = the layer's weights, packed by the planner as ready operand fragments ([row tile][k-step][64 lanes][16 B], zeros
  * beyond kw * C_in, beyond the last chunk and beyond C_out); C = the accumulator seeds. MaxPool, Softmax and the argmax
- * stay on the VALU. A workgroup takes `batch` inputs at a time so that small late layers still fill 32-column tiles. */
+ * stay on the VALU. A WAVEFRONT takes `batch` inputs through the whole layer list by itself, in its own slice of LDS: no
+ * workgroup barrier (the first version ran a workgroup in lockstep phases and spent a third of its time in barriers). */
 #define ED_MM_MAX_KOFF 1024
 typedef struct {
 	int32_t mm;                 /* 1: Conv2D / Dense on the matrix cores                                              */
@@ -260,12 +261,13 @@ typedef struct {
 
 typedef struct {
 	int32_t ok;                 /* 0: this graph stays on the layer-by-layer kernel (why: the loader's error text)     */
-	int32_t batch;              /* inputs per workgroup iteration                                                     */
-	int32_t buf_bytes;          /* each of the two ping-pong activation buffers                                       */
-	int32_t x_bytes;            /* expansion buffer                                                                   */
+	int32_t batch;              /* inputs a WAVEFRONT takes through the layer list at a time                          */
+	int32_t waves;              /* wavefronts per workgroup: each works alone in its own LDS slice (no workgroup barrier) */
+	int32_t buf_bytes;          /* each of a wave's two ping-pong activation buffers                                  */
+	int32_t x_bytes;            /* a wave's expansion buffer                                                          */
 	int32_t lds_bytes;
 	int32_t frag_lds;           /* bytes of LDS reserved for weight fragments                                         */
-	int32_t frag_mode;          /* 2: all layers resident in LDS, 1: one layer at a time, 0: streamed from L2          */
+	int32_t frag_mode;          /* 2: all layers resident in LDS, 0: streamed from L2                                  */
 	int32_t tbl_bytes;          /* LDS copy of the small tables: koff | seeds | layer records (read once per workgroup) */
 	int32_t frag_bytes, n_seeds, n_koff;
 	ed_mm_layer_t L[ED_NET_MAX_LAYERS];

@@ -105,31 +105,36 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 			if (out_img > max_img) max_img = out_img;
 		}
 	}
-	/* Where the weight fragments live while a workgroup runs, best first: (2) ALL layers resident in LDS for the whole
-	 * launch (one L2 read per workgroup), (1) one layer at a time, re-staged per batch, (0) streamed from L2 per MFMA.
-	 * With the fragments placed, the batch is the largest power of two whose activations still fit. */
-	int max_frag = 0;
-	for (int i = 0; i < n_layers; i++)
-		if (mm->L[i].mm && mm->L[i].n_rt * mm->L[i].n_ks * 1024 > max_frag) max_frag = mm->L[i].n_rt * mm->L[i].n_ks * 1024;
+	/* Where the weight fragments live: (2) ALL layers resident in LDS for the whole launch, shared by the waves of the
+	 * workgroup (one L2 read per workgroup), or (0) streamed from L2 per MFMA. Every wave gets its own activation slice
+	 * (two ping-pong buffers + the expansion buffer for `batch` inputs); as many waves as fit, at most 16, at least 4; the
+	 * per-wave batch grows (up to 4) only while 8 waves still fit -- independent waves hide each other's latencies, a
+	 * bigger batch only fills the 32-column tiles of small late layers better. */
 	const int lds_cap = 150 * 1024;
 	const int tbl = up16(4 * n_koff) + up16(4 * n_seeds) + up16(n_layers * (int)sizeof(ed_net_layer_t)) + up16(n_layers * (int)sizeof(ed_mm_layer_t));
 	if (tbl > 24 * 1024) return EDISON_OK;
-	int batch = 0, frag_lds = 0, frag_mode = 0;
-	for (int mode = 2; mode >= 0 && !batch; mode--)
+	int batch = 0, waves = 0, frag_lds = 0, frag_mode = 0;
+	for (int mode = 2; mode >= 0 && !batch; mode -= 2)
 	{
-		const int64_t fl = mode == 2 ? (int64_t)frag_bytes : mode == 1 ? max_frag : 0;
+		const int64_t fl = mode == 2 ? (int64_t)frag_bytes : 0;
 		if (fl > 96 * 1024) continue;
-		for (int b = 16; b >= (mode == 2 ? 4 : 1); b >>= 1)
-			if (2 * (int64_t)b * max_img + (int64_t)b * up16(max_x) + tbl + fl <= lds_cap) { batch = b; frag_lds = (int)fl; frag_mode = mode; break; }
+		for (int b = 4; b >= 1 && !batch; b >>= 1)
+		{
+			const int64_t per_wave = 2 * (int64_t)b * max_img + (int64_t)b * up16(max_x);
+			int64_t w = (lds_cap - tbl - fl) / per_wave;
+			if (w > 16) w = 16;
+			if (w >= (b > 1 ? 8 : 4)) { batch = b; waves = (int)w; frag_lds = (int)fl; frag_mode = mode; }
+		}
 	}
 	if (!batch) return EDISON_OK;
 	mm->batch = batch;
+	mm->waves = waves;
 	mm->buf_bytes = batch * max_img;
 	mm->x_bytes = batch * up16(max_x);
 	mm->frag_lds = frag_lds;
 	mm->frag_mode = frag_mode;
 	mm->tbl_bytes = tbl;
-	mm->lds_bytes = 2 * mm->buf_bytes + mm->x_bytes + tbl + frag_lds;
+	mm->lds_bytes = tbl + frag_lds + waves * (2 * mm->buf_bytes + mm->x_bytes);
 	mm->frag_bytes = (int32_t)frag_bytes;
 	mm->n_seeds = n_seeds;
 	mm->n_koff = n_koff;

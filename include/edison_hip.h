@@ -359,7 +359,8 @@ int edison_mfcc_f32_batch(mfcc_t *mfcc, const int16_t *audio, int64_t n_frames, 
  * and 256 (app.c:583) into a ring of window_rows (MFCC_LEN = 63) feature rows, and the network input is that ring oldest
  * row first (mfcc_features_seq, app.c:600-604). A push takes n_events <= max_events events (one kernel launch for all
  * their frames) and returns the window after every event: windows [n_events][window_rows][n_out] int8. State (samples and
- * rows) starts as zeros, like the firmware's static buffers. The extractor must be a 512-sample one on the same context. */
+ * rows) starts as zeros, like the firmware's static buffers. The extractor must be a 512-sample one on the same context and
+ * must outlive the stream (edison_f32_stream_destroy before mfcc_delete). */
 typedef struct edison_f32_stream edison_f32_stream;
 int edison_f32_stream_create(edison_ctx *ctx, mfcc_t *mfcc, int window_rows, int max_events, edison_f32_stream **out);
 void edison_f32_stream_destroy(edison_f32_stream *s);
