@@ -53,8 +53,10 @@ def build(force=False, verbose=False):
         objs.append(obj)
     for src in HIP_SOURCES:
         obj = os.path.join(bdir, src + ".o")
-        # -fno-slp-vectorize: on gfx950 v_pk_{add,mul,fma}_f32 issue at half the rate of their scalar forms, so
-        # SLP-packing adjacent fp32 ops buys nothing and costs the v_mov's that build the register pairs
+        # -fno-slp-vectorize: measured (tools/ubench/rates, profiles/r02_ubench_rates.txt) a v_pk_{add,mul,fma}_f32 costs 4.3-4.7
+        # cycles of vector issue against 2.3-2.6 for a back-to-back VOP2 add / mul / fmac and 3.7-4.0 for a VOP3 v_fma_f32: packing
+        # pays when whole register PAIRS stay pairs (the two-frame MFCC kernel is written that way by hand), not when the
+        # compiler's SLP pass packs adjacent scalar ops and pays v_mov's to build the pairs (-15 % on the one-frame kernel)
         cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-fno-slp-vectorize"] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

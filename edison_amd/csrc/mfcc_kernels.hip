@@ -383,6 +383,9 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 #define ED2_TW_LDS 0      /* 1: pass-1/2 twiddles read from LDS (14 ds_read_b64 per pair) instead of 28 registers */
 #endif
 #define ED2_TWTAB_FLOATS (ED2_TW_LDS ? 2 * 7 * 64 * 2 : 0)
+#ifndef ED2_TABLES_FIRST
+#define ED2_TABLES_FIRST 0 /* 1: prologue issues the table loads before the first pair's sample loads */
+#endif
 #ifndef ED2_UNPACK_SB
 #define ED2_UNPACK_SB 0   /* 1: scheduling barrier between the unpack and the next pair's loads */
 #endif
@@ -470,6 +473,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 	const uint32_t cnt = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_pairs) / gridDim.x) - s0;
 	uint32_t i_cur = wave, i_next = wave + ED2_WPB;
 	uint32_t rawA[8], rawB[8];
+#if !ED2_TABLES_FIRST
 	if (i_cur < cnt)
 	{
 		const int16_t *pa, *pb;
@@ -477,6 +481,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		ed_load_frame<ALIGNED>(pa, lane, rawA);
 		ed_load_frame<ALIGNED>(pb, lane, rawB);
 	}
+#endif
 	/* every table load of the prologue goes in flight before the first wait */
 #if ED2_TW_LDS
 	/* per-lane twiddle tables [q - 1][lane] as float2, conflict-free ds_read_b64 */
@@ -513,12 +518,40 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		 * stage), so their weight quads are stored (z, w, x, y); quad t belongs to lane t & 63 (ED_FIXTAB_FLOATS / 4 is
 		 * a multiple of 64) and threadIdx.x + k * blockDim.x keeps that lane: the flag is this thread's own mel_half */
 		static_assert((64 * ED2_WPB) % 64 == 0 && (ED_FIXTAB_FLOATS / 4) % 64 == 0, "weight quad <-> lane mapping");
+#if ED2_TABLES_FIRST
+		/* table loads first (L2 hits, needed before the barrier), the first pair's samples behind them (HBM, needed
+		 * after it): vector-memory results return in issue order, so the other order makes the barrier wait for HBM */
+		constexpr int NT = (n4 + 64 * ED2_WPB - 1) / (64 * ED2_WPB);
+		float4 tv[NT];
+#pragma unroll
+		for (int k = 0; k < NT; k++)
+		{
+			const int t = threadIdx.x + k * 64 * ED2_WPB;
+			tv[k] = src[t < n4 ? t : 0];
+		}
+		if (i_cur < cnt)
+		{
+			const int16_t *pa, *pb;
+			ed_pair_ptrs<PLAIN>(args, s0 + i_cur, pa, pb);
+			ed_load_frame<ALIGNED>(pa, lane, rawA);
+			ed_load_frame<ALIGNED>(pb, lane, rawB);
+		}
+#pragma unroll
+		for (int k = 0; k < NT; k++)
+		{
+			const int t = threadIdx.x + k * 64 * ED2_WPB;
+			float4 v = tv[k];
+			if (ED2_MEL_SWAP && t >= ED_FIXTAB_FLOATS / 4 && mel_half) v = make_float4(v.z, v.w, v.x, v.y);
+			if (t < n4) dst[t] = v;
+		}
+#else
 		for (int t = threadIdx.x; t < n4; t += 64 * ED2_WPB)
 		{
 			float4 v = src[t];
 			if (ED2_MEL_SWAP && t >= ED_FIXTAB_FLOATS / 4 && mel_half) v = make_float4(v.z, v.w, v.x, v.y);
 			dst[t] = v;
 		}
+#endif
 		if (threadIdx.x == 0) *queue = 2 * ED2_WPB;
 	}
 	__syncthreads();
