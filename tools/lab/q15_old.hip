@@ -38,9 +38,7 @@
 #include "../../include/edison_hip.h"
 #include "edison_internal.h"
 
-#ifndef EQ_WPB
-#define EQ_WPB 12                /* wavefronts (= frames in flight) per workgroup: one workgroup per CU, 3 waves per SIMD */
-#endif
+#define EQ_WPB 4                 /* wavefronts (= frames in flight) per workgroup                     */
 #define EQ_BUF 1088              /* 1024 complex values + one pad dword per 16                        */
 #define EQ_P(p) ((p) + ((p) >> 4))
 #define EQ_NB 16                 /* frames whose DCT stage a wavefront runs together                  */
@@ -115,45 +113,6 @@ __device__ __forceinline__ void eq_bf_first(u32 &a, u32 &b, u32 &c, u32 &d, cons
 	d = eq_twiddle<false>(plus, t.w[2], t.wx[2]);
 }
 
-/*
- * The same first stage on the REAL samples of a frame, two butterflies at a time: with every imaginary part zero the
- * saturating adds and the halving run on (sample of butterfly A, sample of butterfly B) pairs -- a dword of two
- * neighbouring samples as it comes from memory. What the general routine computes with rt = (0, b-d), s = (a-c, 0):
- *   x0 = ((r + tt) >> 1, 0)          x1 = (r - tt, 0) * conj(w2)
- *   plus = (s, q)                    minus = (s, -q)                    q = b - d, in [-16383, 16383] after the >> 2
- * so x1 needs one product per part (the coefficient of butterfly A sits in the low half of its dword with a zero above
- * it, B's in the high half: v_dot2 then picks the right sample of the pair by itself) and plus / minus are two
- * v_perm_b32 each. tA / tB: coefficient sets of the two butterflies, index 1 (the 2 ic pair) in that one-sided form.
- */
-__device__ __forceinline__ void eq_bf_first_real2(u32 a0, u32 a1, u32 a2, u32 a3, const eq_tw3 &tA, const eq_tw3 &tB,
-                                                  u32 (&oA)[4], u32 (&oB)[4])
-{
-	a0 = eq_asr2(a0); a1 = eq_asr2(a1); a2 = eq_asr2(a2); a3 = eq_asr2(a3);
-	const u32 r = eq_qadd(a0, a2), s = eq_qsub(a0, a2), tt = eq_qadd(a1, a3), q = eq_qsub(a1, a3);
-	const u32 x0 = eq_hadd(r, tt), x1 = eq_qsub(r, tt);
-	const u32 nq = eq_u((s16x2)(0) - eq_s(q));
-	oA[0] = x0 & 0xffffu; oB[0] = x0 >> 16;
-	oA[1] = __builtin_amdgcn_perm((u32)eq_dot2<false>(tA.wx[1], x1), (u32)eq_dot2<false>(tA.w[1], x1), 0x07060302u);
-	oB[1] = __builtin_amdgcn_perm((u32)eq_dot2<false>(tB.wx[1], x1), (u32)eq_dot2<false>(tB.w[1], x1), 0x07060302u);
-	oA[2] = eq_twiddle<false>(__builtin_amdgcn_perm(nq, s, 0x05040100u), tA.w[0], tA.wx[0]);
-	oB[2] = eq_twiddle<false>(__builtin_amdgcn_perm(nq, s, 0x07060302u), tB.w[0], tB.wx[0]);
-	oA[3] = eq_twiddle<false>(__builtin_amdgcn_perm(q, s, 0x05040100u), tA.w[2], tA.wx[2]);
-	oB[3] = eq_twiddle<false>(__builtin_amdgcn_perm(q, s, 0x07060302u), tB.w[2], tB.wx[2]);
-}
-
-/* the samples of one frame as stage 1 wants them: x[4 v + q] = samples (2 lane + 128 v + 256 q, and the next one) */
-template <bool ALIGNED>
-__device__ __forceinline__ void eq_load_frame(const int16_t *src, int lane, u32 (&x)[8])
-{
-#pragma unroll
-	for (int i = 0; i < 8; i++)
-	{
-		const int at = 2 * lane + 128 * (i >> 2) + 256 * (i & 3);
-		if (ALIGNED) x[i] = *reinterpret_cast<const u32 *>(src + at);
-		else x[i] = (u32)(unsigned short)src[at] | ((u32)(unsigned short)src[at + 1] << 16);
-	}
-}
-
 /* middle stages (:335-455) */
 template <bool UNIFORM>
 __device__ __forceinline__ void eq_bf_mid(u32 &a, u32 &b, u32 &c, u32 &d, const eq_tw3 &t)
@@ -218,10 +177,9 @@ __device__ __forceinline__ int eq_sqrt_q31(int in_raw)
 __device__ __forceinline__ bool eq_mag_fast(u32 x, int &c)
 {
 	c = (int)__builtin_amdgcn_sqrtf((float)x * 0.5f);
-	const u32 c2 = (u32)c + (u32)c;                       /* c <= 46340: both factors fit 24 bits, the product 32 */
-	const u32 d = x - __umul24(c2, (u32)c);
+	const int d = (int)x + __mul24(c, __mul24(c, -2));
 	const u32 t = (u32)c >> 11;
-	return d + ~t <= ((c2 - t) << 1); /* t + 1 <= d <= 4c + 1 - t in one unsigned compare */
+	return (u32)d + ~t < 4u * (u32)c + 1u - 2u * t; /* t + 1 <= d <= 4c + 1 - t in one unsigned compare */
 }
 
 /* The rest: x == 2 c^2 (mag is c or c - 1: one bit per c from tables_q15.c) and the rare near-boundary inputs, the
@@ -271,15 +229,11 @@ __device__ __forceinline__ const int16_t *eq_frame_ptr(const ed_mfcc_q15_args_t 
 /*
  * dct2_q15 for nb <= 16 parked frames of this wavefront (mel rows in melb[s][32]): v[i] = mel[2i], v[31-i] = mel[2i+1];
  * z[n] = (v[2n], v[2n+1]); 16-point radix-4 transform (first + last stage); real-FFT split; real parts. Frame s of the
- * batch is frame fid[s] of the launch (the work queue hands a wave frames in no fixed pattern). The output rows
- * overwrite the mel rows.
+ * batch is frame f0 + s * fstride of the launch. The output rows overwrite the mel rows.
  */
-__device__ __forceinline__ void eq_dct_batch(const ed_mfcc_q15_args_t &a, int *melb, u32 *zb, int nb, const u32 *fid,
-                                             int lane, const ed_q15_tables_t *__restrict__ T)
+__device__ __forceinline__ void eq_dct_batch(const ed_mfcc_q15_args_t &a, int *melb, u32 *zb, int nb, uint32_t f0,
+                                             uint32_t fstride, int lane, const eq_tw3 &t16, u32 rfa_l, u32 rfb_l)
 {
-	/* once per 16 frames: the constants of this stage are fetched here (L2 hits) instead of holding 8 registers */
-	const eq_tw3 t16 = eq_load_tw(T->tw16, T->tw16x, lane & 3);
-	const u32 rfa_l = T->rfa[lane & 15], rfb_l = T->rfb[lane & 15];
 	{
 		const int s = lane >> 2, j = lane & 3;
 		const int *mel = melb + 32 * s;
@@ -345,7 +299,7 @@ __device__ __forceinline__ void eq_dct_batch(const ed_mfcc_q15_args_t &a, int *m
 			if (s < nb && c < a.n_coef)
 			{
 				const int o = melb[32 * s + c];
-				const int64_t at = (int64_t)fid[s] * a.n_coef + c;
+				const int64_t at = (int64_t)(f0 + (uint32_t)s * fstride) * a.n_coef + c;
 				if (a.mfcc_i16) a.mfcc_i16[at] = (int16_t)o;
 				if (a.mfcc_f32) a.mfcc_f32[at] = (float)o;
 				if (a.feat) a.feat[at] = (int8_t)(o > 127 ? 127 : (o < -128 ? -128 : o));
@@ -361,15 +315,15 @@ __device__ __forceinline__ void eq_dct_batch(const ed_mfcc_q15_args_t &a, int *m
 #define EQ_TW_LDS 1
 #endif
 #if EQ_TW_LDS
-#define EQ_TW12(stage, u, regs) eq_tw_from_lds(s_tw12 + ((stage) * 4 + (u)) * 6 * 64, lane)
+#define EQ_TW12(stage, u, regs) eq_tw_from_lds(s_tw12[stage][u], lane)
 #else
 #define EQ_TW12(stage, u, regs) (regs)
 #endif
-__device__ __forceinline__ eq_tw3 eq_tw_from_lds(const u32 *t, int lane)
+__device__ __forceinline__ eq_tw3 eq_tw_from_lds(const u32 (*t)[64], int lane)
 {
 	eq_tw3 r;
 #pragma unroll
-	for (int i = 0; i < 3; i++) { r.w[i] = t[64 * i + lane]; r.wx[i] = t[64 * (3 + i) + lane]; }
+	for (int i = 0; i < 3; i++) { r.w[i] = t[i][lane]; r.wx[i] = t[3 + i][lane]; }
 	return r;
 }
 
@@ -379,36 +333,26 @@ __device__ __forceinline__ eq_tw3 eq_tw_from_lds(const u32 *t, int lane)
 #define EQ_OCCUPANCY
 #endif
 
-/* LDS of one workgroup, in dwords: mel taps, the x == 2c^2 bits, the stage-1/2 coefficients, then per wave the transform
- * buffer, 16 parked mel rows, the DCT scratch and the parked frames' numbers; one dword of work queue at the end */
-#define EQ_LDS_DWORDS(nlop, nhip) (((nlop) + (nhip)) * 64 + 1024 + 2 * 4 * 6 * 64 + EQ_WPB * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB) + 4)
-
-/*
- * One workgroup per CU (EQ_WPB wavefronts, 3 per SIMD at 167 VGPRs) owns a contiguous slice of the launch's frames and
- * hands them to its wavefronts through a counter in LDS: the vector ALU arbitrates oldest-first, so with a fixed
- * frame -> wave assignment the old waves of a SIMD finish long before the young ones and the tail of the launch runs
- * at one or two waves per SIMD (SQ_WAVE_CYCLES / SQ_WAVES was 78 % of the kernel's busy time); drawn from a queue, all
- * waves of a CU finish within one frame of each other. The tables are staged once per CU instead of once per 4 waves.
- */
-template <bool STAGES, bool ALIGNED, int NLO, int NHI>
+template <bool STAGES, int NLO, int NHI>
 __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(ed_mfcc_q15_args_t a, const ed_q15_tables_t *__restrict__ T)
 {
-	extern __shared__ __align__(16) u32 eq_smem[];
+	__shared__ u32 s_buf[EQ_WPB][EQ_BUF];
 	constexpr int NLOP = ED_Q15_PAIRS(NLO), NHIP = ED_Q15_PAIRS(NHI); /* dword reads of the int16 spectrum */
-	u32 *s_tap = eq_smem;                        /* [NLOP + NHIP][64] */
-	u32 *s_sqbit = s_tap + (NLOP + NHIP) * 64;   /* [1024]            */
-	u32 *s_tw12 = s_sqbit + 1024;                /* [2][4][6][64]     */
+	__shared__ u32 s_tap[NLOP + NHIP][64];
+	__shared__ int s_melb[EQ_WPB][EQ_NB * 32];
+	__shared__ u32 s_zb[EQ_WPB][EQ_NB * 16];
+	__shared__ u32 s_sqbit[1024];
+#if EQ_TW_LDS
+	__shared__ u32 s_tw12[2][4][6][64];
+#endif
 	const int lane = threadIdx.x & 63;
 	const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	u32 *buf = s_tw12 + 2 * 4 * 6 * 64 + w * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB);
-	int *melb = reinterpret_cast<int *>(buf + EQ_BUF);
-	u32 *zb = buf + EQ_BUF + EQ_NB * 32;
-	u32 *fid = zb + EQ_NB * 16;
-	unsigned *queue = s_tw12 + 2 * 4 * 6 * 64 + EQ_WPB * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB);
+	u32 *buf = s_buf[w];
+	int *melb = s_melb[w];
+	u32 *zb = s_zb[w];
 
-	for (int i = threadIdx.x; i < (NLOP + NHIP) * 64; i += 64 * EQ_WPB) s_tap[i] = (&T->mel_tap2[0][0])[i];
+	for (int i = threadIdx.x; i < (NLOP + NHIP) * 64; i += 64 * EQ_WPB) (&s_tap[0][0])[i] = (&T->mel_tap2[0][0])[i];
 	for (int i = threadIdx.x; i < 1024; i += 64 * EQ_WPB) s_sqbit[i] = T->sqbit[i];
-	if (threadIdx.x == 0) *queue = 2 * EQ_WPB; /* the first two frames of every wave are handed out by position */
 	__syncthreads();
 
 	/* per-lane constants of the whole run */
@@ -417,10 +361,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 #pragma unroll
 	for (int u = 0; u < 4; u++)
 	{
-		/* stage 1: ic = j, lane l owns butterflies j = 2 l + (u & 1) + 128 (u >> 1); the 2 ic pair in its one-sided form */
-		t1[u] = eq_load_tw(T->tw1024, T->tw1024x, 2 * lane + (u & 1) + 128 * (u >> 1));
-		t1[u].w[1] = (u & 1) ? t1[u].w[1] << 16 : t1[u].w[1] & 0xffffu;
-		t1[u].wx[1] = (u & 1) ? t1[u].wx[1] << 16 : t1[u].wx[1] & 0xffffu;
+		t1[u] = eq_load_tw(T->tw1024, T->tw1024x, lane + 64 * u);     /* stage 1: ic = j                  */
 		t2[u] = eq_load_tw(T->tw1024, T->tw1024x, 4 * (j3 + 16 * u)); /* stage 2: ic = 4 j, j = j3 + 16a  */
 #if EQ_TW_LDS
 		/* the per-lane coefficients of stages 1 and 2 (48 registers) live in LDS instead, one conflict-free
@@ -430,8 +371,8 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 #pragma unroll
 			for (int i = 0; i < 3; i++)
 			{
-				s_tw12[((0 * 4 + u) * 6 + i) * 64 + lane] = t1[u].w[i]; s_tw12[((0 * 4 + u) * 6 + 3 + i) * 64 + lane] = t1[u].wx[i];
-				s_tw12[((1 * 4 + u) * 6 + i) * 64 + lane] = t2[u].w[i]; s_tw12[((1 * 4 + u) * 6 + 3 + i) * 64 + lane] = t2[u].wx[i];
+				s_tw12[0][u][i][lane] = t1[u].w[i]; s_tw12[0][u][3 + i][lane] = t1[u].wx[i];
+				s_tw12[1][u][i][lane] = t2[u].w[i]; s_tw12[1][u][3 + i][lane] = t2[u].wx[i];
 			}
 		}
 #endif
@@ -451,47 +392,41 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	const int mel_scale = T->mel_scale;
 	const bool need_nyquist = STAGES || T->need_nyquist != 0; /* a band that reaches bin 512 (not the shipped filterbank) */
 	const int rev6 = eq_bitrev(lane, 6);
+	const eq_tw3 t16 = eq_load_tw(T->tw16, T->tw16x, lane & 3);
+	const u32 rfa_l = T->rfa[lane & 15], rfb_l = T->rfb[lane & 15];
 
-	/* this workgroup's slice of the launch, and this wave's first two frames of it */
-	const uint32_t n_frames = (uint32_t)a.n_frames;
-	const uint32_t s0 = (uint32_t)(((uint64_t)blockIdx.x * n_frames) / gridDim.x);
-	const uint32_t cnt = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_frames) / gridDim.x) - s0;
-	uint32_t i_cur = (uint32_t)w, i_next = (uint32_t)w + EQ_WPB;
+	const uint32_t n_frames = (uint32_t)a.n_frames, fstride = gridDim.x * EQ_WPB;
+	const uint32_t f_first = blockIdx.x * EQ_WPB + (uint32_t)w;
 	int slot = 0;
-	/* software prefetch: the samples of the wave's next frame are requested while this one is being transformed */
-	u32 raw[8];
-	if (i_cur < cnt) eq_load_frame<ALIGNED>(eq_frame_ptr(a, s0 + i_cur), lane, raw);
-	while (i_cur < cnt)
+	/* software prefetch: the samples of frame f + fstride are requested while frame f is being transformed */
+	unsigned short raw[16];
+	if (f_first < n_frames)
 	{
-		const uint32_t f = s0 + i_cur;
+		const int16_t *src = eq_frame_ptr(a, f_first);
+#pragma unroll
+		for (int i = 0; i < 16; i++) raw[i] = (unsigned short)src[lane + 64 * (i >> 2) + 256 * (i & 3)];
+	}
+	for (uint32_t f = f_first; f < n_frames; f += fstride)
+	{
 		u32 e[16];
 
-		/* ---- stage 1 on sample pairs: butterflies j = 2 lane + 128 v (low halves) and j + 1 (high halves) */
+		/* ---- stage 1: real samples become (re, 0) */
+#pragma unroll
+		for (int i = 0; i < 16; i++) e[i] = (u32)raw[i];
 		{
-			u32 x[8];
+			/* unconditional (a conditional load would make raw[] a merge of two definitions: 16 copies per frame at the
+			 * loop latch); a wave's last iteration re-reads the batch's last frame, an L2 hit */
+			const uint32_t fn = (f + fstride < n_frames && f + fstride > f) ? f + fstride : n_frames - 1;
+			const int16_t *src = eq_frame_ptr(a, fn);
 #pragma unroll
-			for (int i = 0; i < 8; i++) x[i] = raw[i];
-			/* unconditional (a conditional load would make raw[] a merge of two definitions: copies at the loop latch);
-			 * a wave's last iteration re-reads the slice's last frame, an L2 hit */
-			eq_load_frame<ALIGNED>(eq_frame_ptr(a, s0 + (i_next < cnt ? i_next : cnt - 1)), lane, raw);
+			for (int i = 0; i < 16; i++) raw[i] = (unsigned short)src[lane + 64 * (i >> 2) + 256 * (i & 3)];
+		}
 #pragma unroll
-			for (int v = 0; v < 2; v++)
-			{
-				u32 oA[4], oB[4];
-				if (!(EQ_ABLATE & 16))
-					eq_bf_first_real2(x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3], EQ_TW12(0, 2 * v, t1[2 * v]), EQ_TW12(0, 2 * v + 1, t1[2 * v + 1]), oA, oB);
-				else
-				{
+		for (int u = 0; u < 4; u++)
+		{
+			if (!(EQ_ABLATE & 16)) eq_bf_first(e[4 * u], e[4 * u + 1], e[4 * u + 2], e[4 * u + 3], EQ_TW12(0, u, t1[u]));
 #pragma unroll
-					for (int q = 0; q < 4; q++) { oA[q] = x[4 * v + q] & 0xffffu; oB[q] = x[4 * v + q] >> 16; }
-				}
-#pragma unroll
-				for (int q = 0; q < 4; q++)
-				{
-					const int p = 2 * lane + 128 * v + 256 * q; /* even: p and p + 1 share their pad */
-					buf[EQ_P(p)] = oA[q]; buf[EQ_P(p) + 1] = oB[q];
-				}
-			}
+			for (int q = 0; q < 4; q++) buf[EQ_P(lane + 64 * u + 256 * q)] = e[4 * u + q];
 		}
 		eq_wave_sync();
 
@@ -573,15 +508,6 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 		}
 		eq_wave_sync();
 
-		/* the frame after the next one is drawn from the queue here, where few registers are live; the answer is needed
-		 * at the bottom of the loop, a mel stage later */
-		uint32_t drawn = 0;
-		if (lane == 0)
-		{
-			drawn = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			fid[slot] = f;
-		}
-
 		/* ---- compact mel matrix: lane (b, r) sums quarter r of band b and of band 31-b; 32-bit wrap-around like the MCU */
 		u32 acc_lo = 0, acc_hi = 0;
 		const u32 *spec2 = buf; /* the int16 spectrum, two bins per dword */
@@ -591,10 +517,10 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 			/* two taps per v_dot2_i32_i16 (no clamp: the same wrap-around sum); magnitudes and taps fit 16 bits */
 #pragma unroll
 			for (int t = 0; t < NLOP; t++)
-				acc_lo = (u32)__builtin_amdgcn_sdot2(eq_s(spec2[mel_lo_pair + t]), eq_s(s_tap[64 * t + lane]), (int)acc_lo, false);
+				acc_lo = (u32)__builtin_amdgcn_sdot2(eq_s(spec2[mel_lo_pair + t]), eq_s(s_tap[t][lane]), (int)acc_lo, false);
 #pragma unroll
 			for (int t = 0; t < NHIP; t++)
-				acc_hi = (u32)__builtin_amdgcn_sdot2(eq_s(spec2[mel_hi_pair + t]), eq_s(s_tap[64 * (NLOP + t) + lane]), (int)acc_hi, false);
+				acc_hi = (u32)__builtin_amdgcn_sdot2(eq_s(spec2[mel_hi_pair + t]), eq_s(s_tap[NLOP + t][lane]), (int)acc_hi, false);
 		}
 		/* both sums with one v_permlane32_swap (it exchanges halves of TWO registers: lanes 0..31 then hold the
 		 * narrow band's half sums, 32..63 the wide band's), then the row pairs: rows 0,1 = band b, rows 2,3 = 31-b */
@@ -609,7 +535,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 		eq_wave_sync();
 
 		/* ---- dct2_q15, deferred: run it when 16 frames are parked or the wave has no frame left */
-		const bool last = i_next >= cnt;
+		const bool last = f + fstride >= n_frames || f + fstride < f;
 		if (slot == EQ_NB - 1 || last)
 		{
 			if (EQ_ABLATE & 2)
@@ -617,43 +543,37 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 				if (lane < a.n_coef && a.mfcc_i16) a.mfcc_i16[(int64_t)f * a.n_coef + lane] = (int16_t)melb[32 * slot + lane];
 			}
 			else
-				eq_dct_batch(a, melb, zb, slot + 1, fid, lane, T);
+				eq_dct_batch(a, melb, zb, slot + 1, f - (uint32_t)slot * fstride, fstride, lane, t16, rfa_l, rfb_l);
 			slot = 0;
 		}
 		else
 			slot++;
-		i_cur = i_next; i_next = __builtin_amdgcn_readfirstlane(drawn);
 	}
 }
 
-static int g_q15_blocks_per_cu[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+static int g_q15_blocks_per_cu[2] = {-1, -1};
 
 template <int NLO, int NHI>
 static int ed_launch_q15_shape(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int stages, int n_cu,
-                               hipStream_t stream, int *blocks_per_cu /* [4]: stages x aligned */)
+                               hipStream_t stream, int *blocks_per_cu)
 {
-	/* 4-byte loads of sample pairs need every frame start 4-byte aligned */
-	const bool aligned = ((reinterpret_cast<uintptr_t>(args->audio) & 3) == 0) && (args->frame_step % 2 == 0) && (args->group_stride % 2 == 0);
-	const void *fn = stages ? (aligned ? (const void *)ed_mfcc_q15_kernel<true, true, NLO, NHI> : (const void *)ed_mfcc_q15_kernel<true, false, NLO, NHI>)
-	                        : (aligned ? (const void *)ed_mfcc_q15_kernel<false, true, NLO, NHI> : (const void *)ed_mfcc_q15_kernel<false, false, NLO, NHI>);
-	const size_t lds = sizeof(u32) * EQ_LDS_DWORDS(ED_Q15_PAIRS(NLO), ED_Q15_PAIRS(NHI));
-	int *bpc = &blocks_per_cu[(stages ? 2 : 0) + (aligned ? 1 : 0)];
-	if (*bpc < 0)
+	if (*blocks_per_cu < 0)
 	{
-		/* more than 64 KB of dynamic LDS has to be asked for, once per kernel instance */
-		if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
 		int nb = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * EQ_WPB, lds) != hipSuccess || nb < 1) nb = 1;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ed_mfcc_q15_kernel<false, NLO, NHI>, 64 * EQ_WPB, 0) != hipSuccess || nb < 1)
+			nb = 2;
 		const char *env = getenv("ED_Q15_BLOCKS_PER_CU"); /* tuning knob: cap the persistent grid */
 		if (env && atoi(env) > 0 && atoi(env) < nb) nb = atoi(env);
-		*bpc = nb;
+		*blocks_per_cu = nb;
 	}
 	int64_t blocks = (args->n_frames + EQ_WPB - 1) / EQ_WPB;
-	const int64_t cap = (int64_t)n_cu * *bpc;
+	const int64_t cap = (int64_t)n_cu * *blocks_per_cu;
 	if (blocks > cap) blocks = cap;
 	if (blocks < 1) return 0;
-	void *kargs[] = {(void *)args, (void *)&dev_tab};
-	return (int)hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(64 * EQ_WPB), kargs, lds, stream);
+	dim3 grid((unsigned)blocks), block(64 * EQ_WPB);
+	if (stages) hipLaunchKernelGGL((ed_mfcc_q15_kernel<true, NLO, NHI>), grid, block, 0, stream, *args, dev_tab);
+	else hipLaunchKernelGGL((ed_mfcc_q15_kernel<false, NLO, NHI>), grid, block, 0, stream, *args, dev_tab);
+	return (int)hipGetLastError();
 }
 
 /* mel_nlo / mel_nhi: the host's copy of the table shape (tables_q15.c picks 6+18 or 8+24) */
@@ -663,6 +583,6 @@ extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_t
 	if (mel_nlo == 6 && mel_nhi == 18)
 		return ed_launch_q15_shape<6, 18>(args, dev_tab, stages, n_cu, stream, &g_q15_blocks_per_cu[0]);
 	if (mel_nlo == ED_Q15_NLO_MAX && mel_nhi == ED_Q15_NHI_MAX)
-		return ed_launch_q15_shape<ED_Q15_NLO_MAX, ED_Q15_NHI_MAX>(args, dev_tab, stages, n_cu, stream, &g_q15_blocks_per_cu[4]);
+		return ed_launch_q15_shape<ED_Q15_NLO_MAX, ED_Q15_NHI_MAX>(args, dev_tab, stages, n_cu, stream, &g_q15_blocks_per_cu[1]);
 	return (int)hipErrorInvalidValue;
 }

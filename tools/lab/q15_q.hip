@@ -115,45 +115,6 @@ __device__ __forceinline__ void eq_bf_first(u32 &a, u32 &b, u32 &c, u32 &d, cons
 	d = eq_twiddle<false>(plus, t.w[2], t.wx[2]);
 }
 
-/*
- * The same first stage on the REAL samples of a frame, two butterflies at a time: with every imaginary part zero the
- * saturating adds and the halving run on (sample of butterfly A, sample of butterfly B) pairs -- a dword of two
- * neighbouring samples as it comes from memory. What the general routine computes with rt = (0, b-d), s = (a-c, 0):
- *   x0 = ((r + tt) >> 1, 0)          x1 = (r - tt, 0) * conj(w2)
- *   plus = (s, q)                    minus = (s, -q)                    q = b - d, in [-16383, 16383] after the >> 2
- * so x1 needs one product per part (the coefficient of butterfly A sits in the low half of its dword with a zero above
- * it, B's in the high half: v_dot2 then picks the right sample of the pair by itself) and plus / minus are two
- * v_perm_b32 each. tA / tB: coefficient sets of the two butterflies, index 1 (the 2 ic pair) in that one-sided form.
- */
-__device__ __forceinline__ void eq_bf_first_real2(u32 a0, u32 a1, u32 a2, u32 a3, const eq_tw3 &tA, const eq_tw3 &tB,
-                                                  u32 (&oA)[4], u32 (&oB)[4])
-{
-	a0 = eq_asr2(a0); a1 = eq_asr2(a1); a2 = eq_asr2(a2); a3 = eq_asr2(a3);
-	const u32 r = eq_qadd(a0, a2), s = eq_qsub(a0, a2), tt = eq_qadd(a1, a3), q = eq_qsub(a1, a3);
-	const u32 x0 = eq_hadd(r, tt), x1 = eq_qsub(r, tt);
-	const u32 nq = eq_u((s16x2)(0) - eq_s(q));
-	oA[0] = x0 & 0xffffu; oB[0] = x0 >> 16;
-	oA[1] = __builtin_amdgcn_perm((u32)eq_dot2<false>(tA.wx[1], x1), (u32)eq_dot2<false>(tA.w[1], x1), 0x07060302u);
-	oB[1] = __builtin_amdgcn_perm((u32)eq_dot2<false>(tB.wx[1], x1), (u32)eq_dot2<false>(tB.w[1], x1), 0x07060302u);
-	oA[2] = eq_twiddle<false>(__builtin_amdgcn_perm(nq, s, 0x05040100u), tA.w[0], tA.wx[0]);
-	oB[2] = eq_twiddle<false>(__builtin_amdgcn_perm(nq, s, 0x07060302u), tB.w[0], tB.wx[0]);
-	oA[3] = eq_twiddle<false>(__builtin_amdgcn_perm(q, s, 0x05040100u), tA.w[2], tA.wx[2]);
-	oB[3] = eq_twiddle<false>(__builtin_amdgcn_perm(q, s, 0x07060302u), tB.w[2], tB.wx[2]);
-}
-
-/* the samples of one frame as stage 1 wants them: x[4 v + q] = samples (2 lane + 128 v + 256 q, and the next one) */
-template <bool ALIGNED>
-__device__ __forceinline__ void eq_load_frame(const int16_t *src, int lane, u32 (&x)[8])
-{
-#pragma unroll
-	for (int i = 0; i < 8; i++)
-	{
-		const int at = 2 * lane + 128 * (i >> 2) + 256 * (i & 3);
-		if (ALIGNED) x[i] = *reinterpret_cast<const u32 *>(src + at);
-		else x[i] = (u32)(unsigned short)src[at] | ((u32)(unsigned short)src[at + 1] << 16);
-	}
-}
-
 /* middle stages (:335-455) */
 template <bool UNIFORM>
 __device__ __forceinline__ void eq_bf_mid(u32 &a, u32 &b, u32 &c, u32 &d, const eq_tw3 &t)
@@ -218,10 +179,9 @@ __device__ __forceinline__ int eq_sqrt_q31(int in_raw)
 __device__ __forceinline__ bool eq_mag_fast(u32 x, int &c)
 {
 	c = (int)__builtin_amdgcn_sqrtf((float)x * 0.5f);
-	const u32 c2 = (u32)c + (u32)c;                       /* c <= 46340: both factors fit 24 bits, the product 32 */
-	const u32 d = x - __umul24(c2, (u32)c);
+	const int d = (int)x + __mul24(c, __mul24(c, -2));
 	const u32 t = (u32)c >> 11;
-	return d + ~t <= ((c2 - t) << 1); /* t + 1 <= d <= 4c + 1 - t in one unsigned compare */
+	return (u32)d + ~t < 4u * (u32)c + 1u - 2u * t; /* t + 1 <= d <= 4c + 1 - t in one unsigned compare */
 }
 
 /* The rest: x == 2 c^2 (mag is c or c - 1: one bit per c from tables_q15.c) and the rare near-boundary inputs, the
@@ -275,11 +235,8 @@ __device__ __forceinline__ const int16_t *eq_frame_ptr(const ed_mfcc_q15_args_t 
  * overwrite the mel rows.
  */
 __device__ __forceinline__ void eq_dct_batch(const ed_mfcc_q15_args_t &a, int *melb, u32 *zb, int nb, const u32 *fid,
-                                             int lane, const ed_q15_tables_t *__restrict__ T)
+                                             int lane, const eq_tw3 &t16, u32 rfa_l, u32 rfb_l)
 {
-	/* once per 16 frames: the constants of this stage are fetched here (L2 hits) instead of holding 8 registers */
-	const eq_tw3 t16 = eq_load_tw(T->tw16, T->tw16x, lane & 3);
-	const u32 rfa_l = T->rfa[lane & 15], rfb_l = T->rfb[lane & 15];
 	{
 		const int s = lane >> 2, j = lane & 3;
 		const int *mel = melb + 32 * s;
@@ -390,7 +347,7 @@ __device__ __forceinline__ eq_tw3 eq_tw_from_lds(const u32 *t, int lane)
  * at one or two waves per SIMD (SQ_WAVE_CYCLES / SQ_WAVES was 78 % of the kernel's busy time); drawn from a queue, all
  * waves of a CU finish within one frame of each other. The tables are staged once per CU instead of once per 4 waves.
  */
-template <bool STAGES, bool ALIGNED, int NLO, int NHI>
+template <bool STAGES, int NLO, int NHI>
 __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(ed_mfcc_q15_args_t a, const ed_q15_tables_t *__restrict__ T)
 {
 	extern __shared__ __align__(16) u32 eq_smem[];
@@ -417,10 +374,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 #pragma unroll
 	for (int u = 0; u < 4; u++)
 	{
-		/* stage 1: ic = j, lane l owns butterflies j = 2 l + (u & 1) + 128 (u >> 1); the 2 ic pair in its one-sided form */
-		t1[u] = eq_load_tw(T->tw1024, T->tw1024x, 2 * lane + (u & 1) + 128 * (u >> 1));
-		t1[u].w[1] = (u & 1) ? t1[u].w[1] << 16 : t1[u].w[1] & 0xffffu;
-		t1[u].wx[1] = (u & 1) ? t1[u].wx[1] << 16 : t1[u].wx[1] & 0xffffu;
+		t1[u] = eq_load_tw(T->tw1024, T->tw1024x, lane + 64 * u);     /* stage 1: ic = j                  */
 		t2[u] = eq_load_tw(T->tw1024, T->tw1024x, 4 * (j3 + 16 * u)); /* stage 2: ic = 4 j, j = j3 + 16a  */
 #if EQ_TW_LDS
 		/* the per-lane coefficients of stages 1 and 2 (48 registers) live in LDS instead, one conflict-free
@@ -451,6 +405,8 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	const int mel_scale = T->mel_scale;
 	const bool need_nyquist = STAGES || T->need_nyquist != 0; /* a band that reaches bin 512 (not the shipped filterbank) */
 	const int rev6 = eq_bitrev(lane, 6);
+	const eq_tw3 t16 = eq_load_tw(T->tw16, T->tw16x, lane & 3);
+	const u32 rfa_l = T->rfa[lane & 15], rfb_l = T->rfb[lane & 15];
 
 	/* this workgroup's slice of the launch, and this wave's first two frames of it */
 	const uint32_t n_frames = (uint32_t)a.n_frames;
@@ -459,39 +415,34 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	uint32_t i_cur = (uint32_t)w, i_next = (uint32_t)w + EQ_WPB;
 	int slot = 0;
 	/* software prefetch: the samples of the wave's next frame are requested while this one is being transformed */
-	u32 raw[8];
-	if (i_cur < cnt) eq_load_frame<ALIGNED>(eq_frame_ptr(a, s0 + i_cur), lane, raw);
+	unsigned short raw[16];
+	if (i_cur < cnt)
+	{
+		const int16_t *src = eq_frame_ptr(a, s0 + i_cur);
+#pragma unroll
+		for (int i = 0; i < 16; i++) raw[i] = (unsigned short)src[lane + 64 * (i >> 2) + 256 * (i & 3)];
+	}
 	while (i_cur < cnt)
 	{
 		const uint32_t f = s0 + i_cur;
 		u32 e[16];
 
-		/* ---- stage 1 on sample pairs: butterflies j = 2 lane + 128 v (low halves) and j + 1 (high halves) */
+		/* ---- stage 1: real samples become (re, 0) */
+#pragma unroll
+		for (int i = 0; i < 16; i++) e[i] = (u32)raw[i];
 		{
-			u32 x[8];
+			/* unconditional (a conditional load would make raw[] a merge of two definitions: 16 copies per frame at the
+			 * loop latch); a wave's last iteration re-reads the slice's last frame, an L2 hit */
+			const int16_t *src = eq_frame_ptr(a, s0 + (i_next < cnt ? i_next : cnt - 1));
 #pragma unroll
-			for (int i = 0; i < 8; i++) x[i] = raw[i];
-			/* unconditional (a conditional load would make raw[] a merge of two definitions: copies at the loop latch);
-			 * a wave's last iteration re-reads the slice's last frame, an L2 hit */
-			eq_load_frame<ALIGNED>(eq_frame_ptr(a, s0 + (i_next < cnt ? i_next : cnt - 1)), lane, raw);
+			for (int i = 0; i < 16; i++) raw[i] = (unsigned short)src[lane + 64 * (i >> 2) + 256 * (i & 3)];
+		}
 #pragma unroll
-			for (int v = 0; v < 2; v++)
-			{
-				u32 oA[4], oB[4];
-				if (!(EQ_ABLATE & 16))
-					eq_bf_first_real2(x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3], EQ_TW12(0, 2 * v, t1[2 * v]), EQ_TW12(0, 2 * v + 1, t1[2 * v + 1]), oA, oB);
-				else
-				{
+		for (int u = 0; u < 4; u++)
+		{
+			if (!(EQ_ABLATE & 16)) eq_bf_first(e[4 * u], e[4 * u + 1], e[4 * u + 2], e[4 * u + 3], EQ_TW12(0, u, t1[u]));
 #pragma unroll
-					for (int q = 0; q < 4; q++) { oA[q] = x[4 * v + q] & 0xffffu; oB[q] = x[4 * v + q] >> 16; }
-				}
-#pragma unroll
-				for (int q = 0; q < 4; q++)
-				{
-					const int p = 2 * lane + 128 * v + 256 * q; /* even: p and p + 1 share their pad */
-					buf[EQ_P(p)] = oA[q]; buf[EQ_P(p) + 1] = oB[q];
-				}
-			}
+			for (int q = 0; q < 4; q++) buf[EQ_P(lane + 64 * u + 256 * q)] = e[4 * u + q];
 		}
 		eq_wave_sync();
 
@@ -617,7 +568,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 				if (lane < a.n_coef && a.mfcc_i16) a.mfcc_i16[(int64_t)f * a.n_coef + lane] = (int16_t)melb[32 * slot + lane];
 			}
 			else
-				eq_dct_batch(a, melb, zb, slot + 1, fid, lane, T);
+				eq_dct_batch(a, melb, zb, slot + 1, fid, lane, t16, rfa_l, rfb_l);
 			slot = 0;
 		}
 		else
@@ -626,18 +577,15 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	}
 }
 
-static int g_q15_blocks_per_cu[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+static int g_q15_blocks_per_cu[4] = {-1, -1, -1, -1};
 
 template <int NLO, int NHI>
 static int ed_launch_q15_shape(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int stages, int n_cu,
-                               hipStream_t stream, int *blocks_per_cu /* [4]: stages x aligned */)
+                               hipStream_t stream, int *blocks_per_cu /* [2]: plain, stages */)
 {
-	/* 4-byte loads of sample pairs need every frame start 4-byte aligned */
-	const bool aligned = ((reinterpret_cast<uintptr_t>(args->audio) & 3) == 0) && (args->frame_step % 2 == 0) && (args->group_stride % 2 == 0);
-	const void *fn = stages ? (aligned ? (const void *)ed_mfcc_q15_kernel<true, true, NLO, NHI> : (const void *)ed_mfcc_q15_kernel<true, false, NLO, NHI>)
-	                        : (aligned ? (const void *)ed_mfcc_q15_kernel<false, true, NLO, NHI> : (const void *)ed_mfcc_q15_kernel<false, false, NLO, NHI>);
+	const void *fn = stages ? (const void *)ed_mfcc_q15_kernel<true, NLO, NHI> : (const void *)ed_mfcc_q15_kernel<false, NLO, NHI>;
 	const size_t lds = sizeof(u32) * EQ_LDS_DWORDS(ED_Q15_PAIRS(NLO), ED_Q15_PAIRS(NHI));
-	int *bpc = &blocks_per_cu[(stages ? 2 : 0) + (aligned ? 1 : 0)];
+	int *bpc = &blocks_per_cu[stages ? 1 : 0];
 	if (*bpc < 0)
 	{
 		/* more than 64 KB of dynamic LDS has to be asked for, once per kernel instance */
@@ -663,6 +611,6 @@ extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_t
 	if (mel_nlo == 6 && mel_nhi == 18)
 		return ed_launch_q15_shape<6, 18>(args, dev_tab, stages, n_cu, stream, &g_q15_blocks_per_cu[0]);
 	if (mel_nlo == ED_Q15_NLO_MAX && mel_nhi == ED_Q15_NHI_MAX)
-		return ed_launch_q15_shape<ED_Q15_NLO_MAX, ED_Q15_NHI_MAX>(args, dev_tab, stages, n_cu, stream, &g_q15_blocks_per_cu[4]);
+		return ed_launch_q15_shape<ED_Q15_NLO_MAX, ED_Q15_NHI_MAX>(args, dev_tab, stages, n_cu, stream, &g_q15_blocks_per_cu[2]);
 	return (int)hipErrorInvalidValue;
 }
