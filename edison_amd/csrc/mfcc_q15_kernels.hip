@@ -64,6 +64,8 @@ __device__ __forceinline__ u32 eq_asr2(u32 a) { return eq_u(eq_s(a) >> (s16x2)(2
 /* floor((a+b)/2) = (a&b) + ((a^b)>>1); floor((a-b)/2) = ((a^b)>>1) - (~a&b): no 17th bit needed */
 __device__ __forceinline__ u32 eq_hadd(u32 a, u32 b) { return eq_u(eq_s(a & b) + (eq_s(a ^ b) >> (s16x2)(1))); }
 __device__ __forceinline__ u32 eq_hsub(u32 a, u32 b) { return eq_u((eq_s(a ^ b) >> (s16x2)(1)) - eq_s((a ^ b) & b)); } /* (a^b)&b == ~a&b */
+/* floor((a-b)/2) from h = floor((a+b)/2): h - b, exactly (the value fits 16 bits, so the wrap-around subtract is it) */
+__device__ __forceinline__ u32 eq_hsub_from_hadd(u32 h, u32 b) { return eq_u(eq_s(h) - eq_s(b)); }
 __device__ __forceinline__ u32 eq_swap(u32 a) { return __builtin_amdgcn_alignbit(a, a, 16); }
 __device__ __forceinline__ u32 eq_lohi(u32 lo_from, u32 hi_from) { return (lo_from & 0xffffu) | (hi_from & 0xffff0000u); }
 
@@ -159,11 +161,13 @@ template <bool UNIFORM>
 __device__ __forceinline__ void eq_bf_mid(u32 &a, u32 &b, u32 &c, u32 &d, const eq_tw3 &t)
 {
 	const u32 r = eq_qadd(a, c), s = eq_qsub(a, c), tt = eq_qadd(b, d);
-	const u32 x0 = eq_asr1(eq_hadd(r, tt));
-	const u32 x1 = eq_twiddle<UNIFORM>(eq_hsub(r, tt), t.w[1], t.wx[1]);
+	const u32 h = eq_hadd(r, tt);
+	const u32 x0 = eq_asr1(h);
+	const u32 x1 = eq_twiddle<UNIFORM>(eq_hsub_from_hadd(h, tt), t.w[1], t.wx[1]);
 	const u32 rt = eq_swap(eq_qsub(b, d));
+	const u32 hs = eq_hadd(s, rt);
 	u32 plus, minus;
-	EQ_PLUS_MINUS_I(eq_hadd(s, rt), eq_hsub(s, rt), plus, minus);
+	EQ_PLUS_MINUS_I(hs, eq_hsub_from_hadd(hs, rt), plus, minus);
 	a = x0; b = x1;
 	c = eq_twiddle<UNIFORM>(minus, t.w[0], t.wx[0]);
 	d = eq_twiddle<UNIFORM>(plus, t.w[2], t.wx[2]);
@@ -173,9 +177,10 @@ __device__ __forceinline__ void eq_bf_mid(u32 &a, u32 &b, u32 &c, u32 &d, const 
 __device__ __forceinline__ void eq_bf_last(u32 &a, u32 &b, u32 &c, u32 &d)
 {
 	const u32 r = eq_qadd(a, c), tt = eq_qadd(b, d), s = eq_qsub(a, c), ru = eq_swap(eq_qsub(b, d));
+	const u32 hs = eq_hadd(s, ru), h = eq_hadd(r, tt);
 	u32 plus, minus;
-	EQ_PLUS_MINUS_I(eq_hadd(s, ru), eq_hsub(s, ru), plus, minus);
-	a = eq_hadd(r, tt); b = eq_hsub(r, tt); c = minus; d = plus;
+	EQ_PLUS_MINUS_I(hs, eq_hsub_from_hadd(hs, ru), plus, minus);
+	a = h; b = eq_hsub_from_hadd(h, tt); c = minus; d = plus;
 }
 
 __device__ __forceinline__ u32 eq_mulhi(u32 a, u32 b)
@@ -365,6 +370,11 @@ __device__ __forceinline__ void eq_dct_batch(const ed_mfcc_q15_args_t &a, int *m
 #else
 #define EQ_TW12(stage, u, regs) (regs)
 #endif
+#if EQ_TW_LDS >= 2
+#define EQ_TW3(regs) eq_tw_from_lds(s_tw12 + 8 * 6 * 64, lane)
+#else
+#define EQ_TW3(regs) (regs)
+#endif
 __device__ __forceinline__ eq_tw3 eq_tw_from_lds(const u32 *t, int lane)
 {
 	eq_tw3 r;
@@ -381,7 +391,8 @@ __device__ __forceinline__ eq_tw3 eq_tw_from_lds(const u32 *t, int lane)
 
 /* LDS of one workgroup, in dwords: mel taps, the x == 2c^2 bits, the stage-1/2 coefficients, then per wave the transform
  * buffer, 16 parked mel rows, the DCT scratch and the parked frames' numbers; one dword of work queue at the end */
-#define EQ_LDS_DWORDS(nlop, nhip) (((nlop) + (nhip)) * 64 + 1024 + 2 * 4 * 6 * 64 + EQ_WPB * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB) + 4)
+#define EQ_TW_DWORDS ((2 * 4 + 1) * 6 * 64) /* coefficient sets of stages 1, 2 (four each) and 3 (one), 6 x 64 dwords a set */
+#define EQ_LDS_DWORDS(nlop, nhip) (((nlop) + (nhip)) * 64 + 1024 + EQ_TW_DWORDS + EQ_WPB * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB) + 4)
 
 /*
  * One workgroup per CU (EQ_WPB wavefronts, 3 per SIMD at 167 VGPRs) owns a contiguous slice of the launch's frames and
@@ -400,11 +411,11 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	u32 *s_tw12 = s_sqbit + 1024;                /* [2][4][6][64]     */
 	const int lane = threadIdx.x & 63;
 	const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	u32 *buf = s_tw12 + 2 * 4 * 6 * 64 + w * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB);
+	u32 *buf = s_tw12 + EQ_TW_DWORDS + w * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB);
 	int *melb = reinterpret_cast<int *>(buf + EQ_BUF);
 	u32 *zb = buf + EQ_BUF + EQ_NB * 32;
 	u32 *fid = zb + EQ_NB * 16;
-	unsigned *queue = s_tw12 + 2 * 4 * 6 * 64 + EQ_WPB * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB);
+	unsigned *queue = s_tw12 + EQ_TW_DWORDS + EQ_WPB * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB);
 
 	for (int i = threadIdx.x; i < (NLOP + NHIP) * 64; i += 64 * EQ_WPB) s_tap[i] = (&T->mel_tap2[0][0])[i];
 	for (int i = threadIdx.x; i < 1024; i += 64 * EQ_WPB) s_sqbit[i] = T->sqbit[i];
@@ -443,12 +454,23 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 			t4[u].wx[i] = __builtin_amdgcn_readfirstlane(t4[u].wx[i]);
 		}
 	}
-#if EQ_TW_LDS
-	__syncthreads(); /* s_tw12 was written by wave 0 */
-#endif
 	const eq_tw3 t3 = eq_load_tw(T->tw1024, T->tw1024x, 16 * j3);     /* stage 3: ic = 16 j               */
+#if EQ_TW_LDS >= 2 /* stage 3's six as well (measured: no gain, 16 waves per CU run no faster than 12) */
+	if (w == 1 % EQ_WPB)
+	{
+#pragma unroll
+		for (int i = 0; i < 3; i++) { s_tw12[(8 * 6 + i) * 64 + lane] = t3.w[i]; s_tw12[(8 * 6 + 3 + i) * 64 + lane] = t3.wx[i]; }
+	}
+#endif
+#if EQ_TW_LDS
+	__syncthreads(); /* s_tw12 was written by waves 0 and 1 */
+#endif
 	const int mel_lo_pair = T->mel_lo_pair[lane], mel_hi_pair = T->mel_hi_pair[lane];
 	const int mel_scale = T->mel_scale;
+	/* the firmware divides by MEL_MTX_SCALE = 128 (mel_constants.h:7): a power of two is an add and a shift (C's division
+	 * truncates towards zero), anything else the compiler's 30-instruction expansion */
+	const bool scale_pow2 = mel_scale > 0 && (mel_scale & (mel_scale - 1)) == 0;
+	const int scale_sh = __builtin_ctz((unsigned)mel_scale | 0x80000000u);
 	const bool need_nyquist = STAGES || T->need_nyquist != 0; /* a band that reaches bin 512 (not the shipped filterbank) */
 	const int rev6 = eq_bitrev(lane, 6);
 
@@ -505,7 +527,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 #pragma unroll
 			for (int aa = 0; aa < 4; aa++) eq_bf_mid<false>(e[4 * aa], e[4 * aa + 1], e[4 * aa + 2], e[4 * aa + 3], EQ_TW12(1, aa, t2[aa]));
 #pragma unroll
-			for (int b = 0; b < 4; b++) eq_bf_mid<false>(e[b], e[4 + b], e[8 + b], e[12 + b], t3);
+			for (int b = 0; b < 4; b++) eq_bf_mid<false>(e[b], e[4 + b], e[8 + b], e[12 + b], EQ_TW3(t3));
 #pragma unroll
 			for (int aa = 0; aa < 4; aa++)
 #pragma unroll
@@ -602,7 +624,8 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 		if (!(lane & 16))
 		{
 			const int band = lane < 32 ? lane : 63 - lane; /* row 0: band b = lane, row 2: band 31 - (lane & 15) */
-			const int melv = (int)(short)((int)acc / mel_scale);
+			const int quot = scale_pow2 ? ((int)acc + (((int)acc >> 31) & (mel_scale - 1))) >> scale_sh : (int)acc / mel_scale;
+			const int melv = (int)(short)quot;
 			melb[32 * slot + band] = melv;
 			if (STAGES && a.mel) a.mel[(int64_t)f * 32 + band] = (int16_t)melv;
 		}
