@@ -86,7 +86,12 @@ def hbm_traffic_from_profiles(key):
     if not files:
         return None
     try:
-        h = json.load(open(files[-1]))["hbm"][key]
+        hbm = json.load(open(files[-1]))["hbm"]
+        if key not in hbm:  # "name<...>:short" also matches by kernel name + size class when the template arguments changed
+            name, _, cls = key.partition(":")
+            cands = [k for k in hbm if k.split("<")[0] == name.split("<")[0] and k.endswith(":" + cls)]
+            key = cands[0] if len(cands) == 1 else key
+        h = hbm[key]
         return (round(h["FETCH_SIZE_bytes_corrected"] + h["WRITE_SIZE_bytes_corrected"]), os.path.relpath(files[-1], ROOT))
     except (KeyError, ValueError):
         return None
@@ -360,8 +365,8 @@ def main():
                                  unit="GB/s", frac=round(qach / HBM_PEAK_GBS, 4), traffic=None, bytes_per_unit=qbytes,
                                  units_per_launch=nf, kernel_ms=round(qev_ms, 4)),
                    checksum=int(out16.to(torch.int64).sum().item()))
-        q15["roofline"]["kernel"] = "ed_mfcc_q15_kernel<false, 6, 18>"
-        qtr = hbm_traffic_from_profiles("ed_mfcc_q15_kernel<false, 6, 18>:short") if nf == 65536 else None
+        q15["roofline"]["kernel"] = "ed_mfcc_q15_kernel<false, true, 6, 18>"
+        qtr = hbm_traffic_from_profiles("ed_mfcc_q15_kernel<false, true, 6, 18>:short") if nf == 65536 else None
         if qtr is not None:
             q15["roofline"]["traffic"] = qtr[0]
             q15["roofline"]["traffic_source"] = qtr[1]
