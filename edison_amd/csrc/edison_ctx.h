@@ -24,8 +24,8 @@ extern "C" int ed_launch_net(const ed_net_plan_t *dev_plan, const int8_t *dev_w,
                              int8_t *acts, int n_cu, hipStream_t stream);
 
 extern "C" int ed_launch_net_mfma(const ed_net_plan_t *dev_plan, const ed_mm_plan_t *dev_mm, const int8_t *dev_frag,
-                                  const int32_t *dev_seeds, int lds_bytes, int batch, int waves, const int8_t *in, int64_t n, int64_t in_stride,
-                                  int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu, hipStream_t stream);
+                                  const int32_t *dev_seeds, int lds_bytes, int batch, int waves, int frag_mode, const int8_t *in, int64_t n,
+                                  int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu, hipStream_t stream);
 
 extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int mel_nlo, int mel_nhi,
                                   int stages, int n_cu, hipStream_t stream);
@@ -55,7 +55,7 @@ struct edison_ctx
 	int8_t *d_net_w;
 	int32_t *d_net_seeds;
 	/* ... and its matrix-core plan (cnn_net_mfma_kernels.hip), when the graph has one */
-	int mm_ok, mm_lds, mm_batch, mm_waves;
+	int mm_ok, mm_lds, mm_batch, mm_waves, mm_frag_mode;
 	ed_mm_plan_t *d_mm_plan;
 	int8_t *d_mm_frag;
 	int32_t *d_mm_seeds;

@@ -238,7 +238,7 @@ extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t b
 				if (e == hipSuccess) e = hipMemcpy(ctx->d_mm_plan, mm, sizeof(ed_mm_plan_t), hipMemcpyHostToDevice);
 				if (e == hipSuccess) e = hipMemcpy(ctx->d_mm_frag, frag, (size_t)mm->frag_bytes, hipMemcpyHostToDevice);
 				if (e == hipSuccess) e = hipMemcpy(ctx->d_mm_seeds, mseeds, (size_t)mm->n_seeds * sizeof(int32_t), hipMemcpyHostToDevice);
-				if (e == hipSuccess) { ctx->mm_ok = 1; ctx->mm_lds = mm->lds_bytes; ctx->mm_batch = mm->batch; ctx->mm_waves = mm->waves; }
+				if (e == hipSuccess) { ctx->mm_ok = 1; ctx->mm_lds = mm->lds_bytes; ctx->mm_batch = mm->batch; ctx->mm_waves = mm->waves; ctx->mm_frag_mode = mm->frag_mode; }
 			}
 			free(mm); free(frag); free(mseeds);
 		}
@@ -408,7 +408,7 @@ int ed_ctx_net_launch(edison_ctx *ctx, const int8_t *in, int64_t n, int64_t in_s
 {
 	static const int no_mfma = getenv("EDISON_NET_NO_MFMA") ? atoi(getenv("EDISON_NET_NO_MFMA")) : 0;
 	if (ctx->mm_ok && !no_mfma)
-		return ed_launch_net_mfma(ctx->d_net_plan, ctx->d_mm_plan, ctx->d_mm_frag, ctx->d_mm_seeds, ctx->mm_lds, ctx->mm_batch, ctx->mm_waves, in, n,
+		return ed_launch_net_mfma(ctx->d_net_plan, ctx->d_mm_plan, ctx->d_mm_frag, ctx->d_mm_seeds, ctx->mm_lds, ctx->mm_batch, ctx->mm_waves, ctx->mm_frag_mode, in, n,
 		                          in_stride, logits, softmax, argmax, ctx->n_cu, ctx->stream);
 	return ed_launch_net(ctx->d_net_plan, ctx->d_net_w, ctx->d_net_seeds, ctx->net.lds_bytes, in, n, in_stride, logits, softmax, argmax,
 	                     NULL, ctx->n_cu, ctx->stream);

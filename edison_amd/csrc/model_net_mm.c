@@ -86,12 +86,38 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 	{
 		const ed_net_layer_t *C = &plan->L[i], *Q = &plan->L[i + 1];
 		if (!mm->L[i].mm || C->type != ED_NET_CONV || Q->type != ED_NET_POOL) continue;
-		if (Q->pad_h || Q->pad_w || Q->check_taps || Q->kh != Q->sh || Q->kw != Q->sw || Q->kh * Q->kw < 2 || Q->kh * Q->kw > 4) continue;
+		if (Q->pad_h || Q->pad_w || Q->check_taps || Q->kh != Q->sh || Q->kw != Q->sw || (Q->kh * Q->kw != 2 && Q->kh * Q->kw != 4)) continue;
 		if (Q->out_h * Q->kh > C->out_h || Q->out_w * Q->kw > C->out_w) continue;
 		mm->L[i].pool_h = Q->kh; mm->L[i].pool_w = Q->kw;
 		mm->L[i + 1].skip = 1;
 		mm->L[i + 1].in_img = 0; /* the unpooled tensor never exists */
 	}
+
+	/* column tables: (B offset, output offset) of every stored pixel, for the layers that fit ED_MM_MAX_COLS together */
+	int n_cols = 0;
+	for (int i = 0; i < n_layers; i++)
+	{
+		const ed_net_layer_t *L = &plan->L[i];
+		ed_mm_layer_t *M = &mm->L[i];
+		M->col_off = -1;
+		if (!M->mm) continue;
+		const int dense = L->type == ED_NET_DENSE, fused = M->pool_h > 0, nx = fused ? i + 2 : i + 1;
+		const int st_h = dense ? 1 : (fused ? plan->L[i + 1].out_h : L->out_h), st_w = dense ? 1 : (fused ? plan->L[i + 1].out_w : L->out_w);
+		if (n_cols + st_h * st_w > ED_MM_MAX_COLS) continue;
+		const int ph = fused ? M->pool_h : 1, pw = fused ? M->pool_w : 1, sh = dense ? 1 : L->sh;
+		int owp, opy, opx; /* the consumer's layout (the last layer's output is compact) */
+		if (nx < n_layers) { owp = mm->L[nx].in_wp; opy = mm->L[nx].in_py; opx = mm->L[nx].in_px; }
+		else { owp = fused ? plan->L[i + 1].out_w : L->out_w; opy = 0; opx = 0; }
+		M->col_off = n_cols;
+		for (int y = 0; y < st_h; y++)
+			for (int x = 0; x < st_w; x++)
+			{
+				mm->coltab[2 * n_cols] = (y * ph * sh) * M->pitch_y + (x * pw) * M->pitch_x;
+				mm->coltab[2 * n_cols + 1] = ((y + opy) * owp + x + opx) * L->out_c;
+				n_cols++;
+			}
+	}
+	mm->n_cols = n_cols;
 
 	/* LDS budget: two ping-pong buffers of batch x the largest image layout, the expansion buffer, the koff table */
 	int max_img = up16(plan->in_n) + 16, max_x = 0;
@@ -107,11 +133,12 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 	}
 	/* Where the weight fragments live: (2) ALL layers resident in LDS for the whole launch, shared by the waves of the
 	 * workgroup (one L2 read per workgroup), or (0) streamed from L2 per MFMA. Every wave gets its own activation slice
-	 * (two ping-pong buffers + the expansion buffer for `batch` inputs); as many waves as fit, at most 16, at least 4; the
+	 * (two ping-pong buffers + the expansion buffer for `batch` inputs); as many waves as fit, at most 12, at least 4; the
 	 * per-wave batch grows (up to 4) only while 8 waves still fit -- independent waves hide each other's latencies, a
 	 * bigger batch only fills the 32-column tiles of small late layers better. */
 	const int lds_cap = 150 * 1024;
-	const int tbl = up16(4 * n_koff) + up16(4 * n_seeds) + up16(n_layers * (int)sizeof(ed_net_layer_t)) + up16(n_layers * (int)sizeof(ed_mm_layer_t));
+	const int tbl = up16(4 * n_koff) + up16(4 * n_seeds) + up16(n_layers * (int)sizeof(ed_net_layer_t)) + up16(n_layers * (int)sizeof(ed_mm_layer_t)) +
+	                up16(8 * n_cols);
 	if (tbl > 24 * 1024) return EDISON_OK;
 	int batch = 0, waves = 0, frag_lds = 0, frag_mode = 0;
 	for (int mode = 2; mode >= 0 && !batch; mode -= 2)
@@ -122,7 +149,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		{
 			const int64_t per_wave = 2 * (int64_t)b * max_img + (int64_t)b * up16(max_x);
 			int64_t w = (lds_cap - tbl - fl) / per_wave;
-			if (w > 16) w = 16;
+			if (w > 12) w = 12; /* the kernel is built for 768 threads: 168 VGPRs a wave */
 			if (w >= (b > 1 ? 8 : 4)) { batch = b; waves = (int)w; frag_lds = (int)fl; frag_mode = mode; }
 		}
 	}

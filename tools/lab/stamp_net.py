@@ -28,4 +28,5 @@ print("input load %5.1f %%" % (100 * d[0] / tot))
 for li, l in enumerate(info["layers"]):
     print("layer %d type %d: setup (zero, expand, tables) %5.1f %%   body (tiles / pool / softmax) %5.1f %%" % (li, l["type"], 100 * d[1 + 5 * li] / tot, 100 * d[2 + 5 * li] / tot))
 print("outputs + loop %5.1f %%" % (100 * (d[46] + d[47]) / tot))
-print("cycles per batch of 8 (workgroup 0): %.0f" % (tot / (n / 8 / 256)))
+waves = 256 * info.get("mm_waves", 12)
+print("cycles per input of wave 0 of workgroup 0: %.0f (3 such waves share a SIMD)" % (tot / (n / waves)))
