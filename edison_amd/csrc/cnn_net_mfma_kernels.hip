@@ -48,10 +48,12 @@ typedef EMM_LDS int lds32;
 #define EMM_LD32(p) (*reinterpret_cast<const EMM_LDS int *>(p))
 #define EMM_ST32(p, v) (*reinterpret_cast<EMM_LDS uint32_t *>(p) = (v))
 
-__device__ __forceinline__ int emm_med3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* lo <= hi: v_min_i32 + v_max_i32 (the nested-ternary form compiles to a compare and a v_cndmask on top of the v_min) */
+__device__ __forceinline__ int emm_med3(int v, int lo, int hi) { const int t = v > hi ? hi : v; return t < lo ? lo : t; }
 
-/* i / d and i % d for 0 <= i < 2^24, 0 < d: one float multiply and a one-step correction instead of the ~20-instruction
- * integer division sequence (gfx950 has no integer divide); inv = 1.0f / d is computed once per loop. */
+/* i / d and i % d for 0 <= i < 2^21, 0 < d: one float multiply and a one-step correction instead of the ~20-instruction
+ * integer division sequence (gfx950 has no integer divide); inv ~ 1 / d (v_rcp_f32, 1 ulp) is computed once per loop. Every
+ * index here counts bytes or records of one wave's LDS slice, < 2^18. */
 __device__ __forceinline__ void emm_divmod(int i, int d, float inv, int &q, int &r)
 {
 	q = (int)((float)i * inv);
@@ -60,19 +62,46 @@ __device__ __forceinline__ void emm_divmod(int i, int d, float inv, int &q, int 
 	else if (r >= d) { q++; r -= d; }
 }
 
-/* a layer record out of LDS (the implicit struct copy does not take an address-space-3 source) */
-template <typename T>
-__device__ __forceinline__ void emm_copy_record(T *dst, const EMM_LDS T *src)
+/* wave-wide maximum / sum of one int per lane, the same (uniform) value in every lane: four DPP steps inside the rows of
+ * 16, then the four row results through v_readlane */
+#define EMM_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, true)
+__device__ __forceinline__ int emm_wave_max(int v)
 {
-	const lds32 *s = reinterpret_cast<const lds32 *>(src);
-	int *d = reinterpret_cast<int *>(dst);
+	int t;
+	t = EMM_DPP(v, 0xB1); v = t > v ? t : v;   /* quad_perm [1,0,3,2] */
+	t = EMM_DPP(v, 0x4E); v = t > v ? t : v;   /* quad_perm [2,3,0,1] */
+	t = EMM_DPP(v, 0x141); v = t > v ? t : v;  /* row_half_mirror      */
+	t = EMM_DPP(v, 0x140); v = t > v ? t : v;  /* row_mirror           */
+	const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16), r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+	const int m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
+	return m01 > m23 ? m01 : m23;
+}
+__device__ __forceinline__ int emm_wave_add(int v)
+{
+	v += EMM_DPP(v, 0xB1); v += EMM_DPP(v, 0x4E); v += EMM_DPP(v, 0x141); v += EMM_DPP(v, 0x140);
+	return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+/* 16 bytes from byte offset soff of an LDS image, the bytes from `keep` on zeroed (keep >= 1) */
+__device__ __forceinline__ v4i emm_gather16(const lds8 *a, int soff, int keep)
+{
+	const lds8 *s4 = a + (soff & ~3);
+	const uint32_t sh = (uint32_t)(soff & 3) * 8;
+	const uint32_t w0 = (uint32_t)EMM_LD32(s4), w1 = (uint32_t)EMM_LD32(s4 + 4), w2 = (uint32_t)EMM_LD32(s4 + 8), w3 = (uint32_t)EMM_LD32(s4 + 12), w4 = (uint32_t)EMM_LD32(s4 + 16);
+	uint32_t d[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),
+	                 __builtin_amdgcn_alignbit(w3, w2, sh), __builtin_amdgcn_alignbit(w4, w3, sh)};
 #pragma unroll
-	for (int i = 0; i < (int)(sizeof(T) / 4); i++) d[i] = s[i];
+	for (int t = 0; t < 4; t++)
+	{
+		const int kb = keep - 4 * t;
+		d[t] = kb >= 4 ? d[t] : (kb <= 0 ? 0u : d[t] & (0xffffffffu >> (8 * (4 - kb))));
+	}
+	return (v4i){(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
 }
 
 struct emm_layout { int hp, wp, py, px, img; }; /* how an activation tensor lies in LDS: padded dims, origin, bytes per image */
 
-__device__ __forceinline__ emm_layout emm_in_layout(const EMM_LDS ed_mm_layer_t *ML, const EMM_LDS ed_net_layer_t *PL, int n_layers, int li)
+__device__ __forceinline__ emm_layout emm_in_layout(const ed_mm_layer_t *__restrict__ ML, const ed_net_layer_t *__restrict__ PL, int n_layers, int li)
 {
 	emm_layout l;
 	if (li < n_layers)
@@ -81,7 +110,7 @@ __device__ __forceinline__ emm_layout emm_in_layout(const EMM_LDS ed_mm_layer_t 
 	}
 	else
 	{
-		const EMM_LDS ed_net_layer_t &L = PL[n_layers - 1];
+		const ed_net_layer_t &L = PL[n_layers - 1];
 		l.hp = L.out_h; l.wp = L.out_w; l.py = 0; l.px = 0; l.img = ((L.out_n + 15) & ~15) + 16;
 	}
 	return l;
@@ -104,66 +133,74 @@ __device__ __forceinline__ v4i emm_load_a(const lds8 *fl, const int8_t *fg, int 
 }
 
 /*
- * The k-loop of one 32-column tile for NW accumulator tiles at once (the positions of a fused pooling window, 1 when
- * nothing is fused): the A fragment of a k-step serves all of them, and the NW MFMA chains are independent. Software
- * pipeline in program order, so that every wait covers loads issued a whole step earlier (LDS returns in order):
- *   step s:  chunk offset of step s+2  |  A(s+1), B_w(s+1) at the offset read one step ago  |  MFMAs of step s
- * The first step is peeled: its MFMAs take the accumulator seeds as C directly (no copies). Returns the element-wise
- * maximum over the windows (max before the one requantisation is exact: the requantisation is monotone).
+ * The k-loop of U output tiles ("units": a row tile x a column tile each) with NW accumulator tiles per unit (the
+ * positions of a fused pooling window; 1 when nothing is fused) -- NW * U <= 4 independent MFMA chains at once. The A
+ * fragment of a k-step serves the NW windows of its unit. Software pipeline in program order, so that every wait covers
+ * loads issued a whole step earlier (LDS returns in order):
+ *   step s:  chunk offset of step s+2  |  A_u(s+1), B_c(s+1) at the offset read one step ago  |  MFMAs of step s
+ * The accumulators start as the seeds (read straight into them). acc[u] returns the element-wise maximum over the
+ * unit's windows (max before the one requantisation is exact: the requantisation is monotone).
  */
 /* The operands carried into the next k-step pass through an empty asm: without it the optimiser notices that "load for
  * step s+1, use one iteration later" equals "load at the top of step s+1", rotates the loop back and the pipeline is gone
  * (every MFMA then waits for two dependent LDS round trips). */
-#define EMM_KEEP(a, k, b)                                                \
-	do {                                                                 \
-		asm volatile("" : "+v"(a), "+v"(k));                             \
-		_Pragma("unroll") for (int w_ = 0; w_ < NW; w_++) asm volatile("" : "+v"(b[w_])); \
-	} while (0)
-
-template <int NW, bool FRAG_LDS>
-__device__ __forceinline__ v16i emm_chain(const lds8 *fl, const int8_t *fg, const lds8 *kp /* &koff[h] */, const lds8 *(&bw)[NW], int n_ks,
-                                          const v16i &seedv)
+template <int N>
+__device__ __forceinline__ void emm_keep(v4i (&x)[N])
 {
-	v16i aw[NW];
+#pragma unroll
+	for (int i = 0; i < N; i++) asm volatile("" : "+v"(x[i]));
+}
+
+template <int NW, int U, bool FRAG_LDS>
+__device__ __forceinline__ void emm_chain(const lds8 *(&fl)[U], const int8_t *(&fg)[U], const lds8 *kp /* &koff[h] */, const lds8 *(&bw)[NW * U],
+                                          int n_ks, const lds8 *(&sp)[U], v16i (&acc)[U])
+{
+	constexpr int NC = NW * U;
+	v16i aw[NC];
+#pragma unroll
+	for (int c = 0; c < NC; c++)
+#pragma unroll
+		for (int g = 0; g < 4; g++)
+		{
+			const v4i s4 = EMM_LD128(sp[c / NW] + 32 * g);
+			aw[c][4 * g] = s4.x; aw[c][4 * g + 1] = s4.y; aw[c][4 * g + 2] = s4.z; aw[c][4 * g + 3] = s4.w;
+		}
 	const int last = n_ks - 1;
 	int k_cur = EMM_LD32(kp), k_nxt = EMM_LD32(kp + 8 * (last < 1 ? last : 1));
-	v4i a = emm_load_a<FRAG_LDS>(fl, fg, 0), b[NW];
+	v4i a[U], b[NC];
 #pragma unroll
-	for (int w = 0; w < NW; w++) b[w] = EMM_LD128(bw[w] + k_cur);
-	{
-		const int k3 = EMM_LD32(kp + 8 * (last < 2 ? last : 2));
-		const v4i an = emm_load_a<FRAG_LDS>(fl, fg, last < 1 ? last : 1);
-		v4i bn[NW];
+	for (int u = 0; u < U; u++) a[u] = emm_load_a<FRAG_LDS>(fl[u], fg[u], 0);
 #pragma unroll
-		for (int w = 0; w < NW; w++) bn[w] = EMM_LD128(bw[w] + k_nxt);
-#pragma unroll
-		for (int w = 0; w < NW; w++) aw[w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[w], seedv, 0, 0, 0);
-		a = an; k_nxt = k3;
-#pragma unroll
-		for (int w = 0; w < NW; w++) b[w] = bn[w];
-		EMM_KEEP(a, k_nxt, b);
-	}
-	for (int s = 1; s < n_ks; s++)
+	for (int c = 0; c < NC; c++) b[c] = EMM_LD128(bw[c] + k_cur);
+	for (int s = 0; s < n_ks; s++)
 	{
 		const int s1 = s + 1 < n_ks ? s + 1 : last, s2 = s + 2 < n_ks ? s + 2 : last;
 		const int k3 = EMM_LD32(kp + 8 * s2);
-		const v4i an = emm_load_a<FRAG_LDS>(fl, fg, s1);
-		v4i bn[NW];
+		v4i an[U], bn[NC];
 #pragma unroll
-		for (int w = 0; w < NW; w++) bn[w] = EMM_LD128(bw[w] + k_nxt);
+		for (int u = 0; u < U; u++) an[u] = emm_load_a<FRAG_LDS>(fl[u], fg[u], s1);
 #pragma unroll
-		for (int w = 0; w < NW; w++) aw[w] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[w], aw[w], 0, 0, 0);
-		a = an; k_nxt = k3;
+		for (int c = 0; c < NC; c++) bn[c] = EMM_LD128(bw[c] + k_nxt);
 #pragma unroll
-		for (int w = 0; w < NW; w++) b[w] = bn[w];
-		EMM_KEEP(a, k_nxt, b);
+		for (int c = 0; c < NC; c++) aw[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[c / NW], b[c], aw[c], 0, 0, 0);
+		k_nxt = k3;
+#pragma unroll
+		for (int u = 0; u < U; u++) a[u] = an[u];
+#pragma unroll
+		for (int c = 0; c < NC; c++) b[c] = bn[c];
+		asm volatile("" : "+v"(k_nxt));
+		emm_keep(a);
+		emm_keep(b);
 	}
-	v16i acc = aw[0];
 #pragma unroll
-	for (int w = 1; w < NW; w++)
+	for (int u = 0; u < U; u++)
+	{
+		acc[u] = aw[u * NW];
 #pragma unroll
-		for (int i = 0; i < 16; i++) acc[i] = aw[w][i] > acc[i] ? aw[w][i] : acc[i];
-	return acc;
+		for (int w = 1; w < NW; w++)
+#pragma unroll
+			for (int i = 0; i < 16; i++) acc[u][i] = aw[u * NW + w][i] > acc[u][i] ? aw[u * NW + w][i] : acc[u][i];
+	}
 }
 
 /* what the tile loop of a layer needs, gathered once per layer (all wave-uniform) */
@@ -179,41 +216,48 @@ struct emm_mm_args
 	int n_ks, n_rt, n_cols, pix_per_img, col_w;
 	int pitch_x, pitch_y, sh, ph, pw;
 	int o_origin, o_row, oc_pitch, out_c, rs, lo_clamp;
+#if EMM_STAMP
+	unsigned long long *st_, *tl_p;
+#endif
 };
+#if EMM_STAMP
+#define EMM_ST_T(i) { unsigned long long n_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n_) :: "memory"); A.st_[i] += n_ - *A.tl_p; *A.tl_p = n_; }
+#else
+#define EMM_ST_T(i)
+#endif
 
-template <int NW, bool FRAG_LDS>
+template <int NW, int U, bool FRAG_LDS>
 __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 {
 	const int col = lane & 31, h = lane >> 5;
-	const int n_ct = (A.n_cols + 31) >> 5;
-	const float inv_ppi = 1.0f / (float)A.pix_per_img, inv_ow = 1.0f / (float)A.col_w;
-	/* the windows of a column start (wy * sh) input rows / wx output columns after its first one */
+	const int n_ct = (A.n_cols + 31) >> 5, n_units = A.n_rt * n_ct;
+	const float inv_ppi = __builtin_amdgcn_rcpf((float)A.pix_per_img), inv_ow = __builtin_amdgcn_rcpf((float)A.col_w);
+	/* the windows of a column start (wy * sh) input rows / wx output columns after its first one; the fused windows are
+	 * 2x1, 1x2 or 2x2 */
 	int wdelta[NW];
 #pragma unroll
 	for (int w = 0; w < NW; w++)
 	{
-		const int wy = w / A.pw, wx = w - wy * A.pw;
+		const int wy = A.pw == 2 ? w >> 1 : w, wx = A.pw == 2 ? w & 1 : 0;
 		wdelta[w] = (wy * A.sh) * A.pitch_y + wx * A.pitch_x;
 	}
-	for (int rt = 0; rt < A.n_rt; rt++)
+	/* units in (row tile, column tile) order, U at a time; a group's spare slots repeat the last unit and store nothing */
+	int rt = 0, ct = 0;
+	for (int u0 = 0; u0 < n_units; u0 += U)
 	{
-		v16i seedv;
-		{
-			const lds8 *sp = A.seeds + 4 * (32 * rt + 4 * h);
+		EMM_ST_T(43)
+		const lds8 *fl[U], *sp[U], *bw[NW * U];
+		const int8_t *fg[U];
+		lds8 *op[U];
+		bool live[U];
+		int rts[U];
 #pragma unroll
-			for (int g = 0; g < 4; g++)
-			{
-				const v4i s4 = EMM_LD128(sp + 32 * g);
-				seedv[4 * g] = s4.x; seedv[4 * g + 1] = s4.y; seedv[4 * g + 2] = s4.z; seedv[4 * g + 3] = s4.w;
-			}
-		}
-		const lds8 *fl = A.fragl + rt * A.n_ks * 1024 + lane * 16;
-		const int8_t *fg = A.fragg + (size_t)rt * A.n_ks * 1024 + lane * 16;
-		for (int ct = 0; ct < n_ct; ct++)
+		for (int k = 0; k < U; k++)
 		{
+			const bool valid = u0 + k < n_units;
 			const int q = ct * 32 + col;
-			const bool live = q < A.n_cols;
-			const int qq = live ? q : A.n_cols - 1;
+			live[k] = valid && q < A.n_cols;
+			const int qq = q < A.n_cols ? q : A.n_cols - 1;
 			int b = 0, pp = qq;
 			if (A.n_cols > A.pix_per_img) emm_divmod(qq, A.pix_per_img, inv_ppi, b, pp); /* uniform: more than one image per wave */
 			int boff, ooff;
@@ -228,31 +272,69 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 				boff = (y * A.ph * A.sh) * A.pitch_y + (x * A.pw) * A.pitch_x;
 				ooff = A.o_origin + y * A.o_row + x * A.oc_pitch;
 			}
-			const lds8 *bw[NW];
 #pragma unroll
-			for (int w = 0; w < NW; w++) bw[w] = A.bsrc + b * A.img + boff + wdelta[w];
-			const v16i acc = emm_chain<NW, FRAG_LDS>(fl, fg, A.koff + 4 * h, bw, A.n_ks, seedv);
-			/* lane (column, h) holds rows 32 rt + 8 g + 4 h .. +3 in registers 4g..4g+3 */
-			lds8 *op = A.o + b * A.o_img + ooff;
+			for (int w = 0; w < NW; w++) bw[k * NW + w] = A.bsrc + b * A.img + boff + wdelta[w];
+			fl[k] = A.fragl + rt * A.n_ks * 1024 + lane * 16;
+			fg[k] = A.fragg + (size_t)rt * A.n_ks * 1024 + lane * 16;
+			sp[k] = A.seeds + 4 * (32 * rt + 4 * h);
+			op[k] = A.o + b * A.o_img + ooff;
+			rts[k] = rt;
+			if (u0 + k + 1 < n_units) /* uniform */
+			{
+				ct++;
+				if (ct == n_ct) { ct = 0; rt++; }
+			}
+		}
+		v16i acc[U];
+		EMM_ST_T(40)
+		emm_chain<NW, U, FRAG_LDS>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc);
+		EMM_ST_T(41)
+		/* lane (column, h) holds rows 32 rt + 8 g + 4 h .. +3 in registers 4g..4g+3. Requantise, clamp, pack four rows
+		 * into a dword with three v_perm_b32; whole groups of 8 rows past C_out are skipped under a uniform branch, the
+		 * store alone is predicated. */
+#pragma unroll
+		for (int k = 0; k < U; k++)
 #pragma unroll
 			for (int g = 0; g < 4; g++)
 			{
-				const int r0 = 32 * rt + 8 * g + 4 * h;
-				if (!live || r0 >= A.out_c) continue;
-				const int v0 = emm_med3(acc[4 * g] >> A.rs, A.lo_clamp, 127), v1 = emm_med3(acc[4 * g + 1] >> A.rs, A.lo_clamp, 127);
-				const int v2 = emm_med3(acc[4 * g + 2] >> A.rs, A.lo_clamp, 127), v3 = emm_med3(acc[4 * g + 3] >> A.rs, A.lo_clamp, 127);
+				if (32 * rts[k] + 8 * g >= A.out_c) continue; /* uniform */
+				const int r0 = 32 * rts[k] + 8 * g + 4 * h;
+				const int v0 = emm_med3(acc[k][4 * g] >> A.rs, A.lo_clamp, 127), v1 = emm_med3(acc[k][4 * g + 1] >> A.rs, A.lo_clamp, 127);
+				const int v2 = emm_med3(acc[k][4 * g + 2] >> A.rs, A.lo_clamp, 127), v3 = emm_med3(acc[k][4 * g + 3] >> A.rs, A.lo_clamp, 127);
 				if ((A.out_c & 3) == 0)
-					EMM_ST32(op + r0, (uint32_t)(uint8_t)v0 | ((uint32_t)(uint8_t)v1 << 8) | ((uint32_t)(uint8_t)v2 << 16) | ((uint32_t)(uint8_t)v3 << 24));
-				else
 				{
-					op[r0] = (int8_t)v0;
-					if (r0 + 1 < A.out_c) op[r0 + 1] = (int8_t)v1;
-					if (r0 + 2 < A.out_c) op[r0 + 2] = (int8_t)v2;
-					if (r0 + 3 < A.out_c) op[r0 + 3] = (int8_t)v3;
+					const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x0c0c0400u), p23 = __builtin_amdgcn_perm((uint32_t)v3, (uint32_t)v2, 0x0c0c0400u);
+					if (live[k] && r0 < A.out_c) EMM_ST32(op[k] + r0, __builtin_amdgcn_perm(p23, p01, 0x05040100u));
+				}
+				else if (live[k])
+				{
+					if (r0 < A.out_c) op[k][r0] = (int8_t)v0;
+					if (r0 + 1 < A.out_c) op[k][r0 + 1] = (int8_t)v1;
+					if (r0 + 2 < A.out_c) op[k][r0 + 2] = (int8_t)v2;
+					if (r0 + 3 < A.out_c) op[k][r0 + 3] = (int8_t)v3;
 				}
 			}
-		}
+		EMM_ST_T(42)
 	}
+}
+
+/* NW windows per unit (1, 2 or 4); as many units at once as fit four accumulator tiles and the layer has */
+template <bool FRAG_LDS>
+__device__ __forceinline__ void emm_layer_dispatch(const emm_mm_args &A, int lane)
+{
+	const int nwin = A.ph * A.pw, n_units = A.n_rt * ((A.n_cols + 31) >> 5);
+	if (nwin == 1)
+	{
+		if (n_units >= 4) emm_layer_tiles<1, 4, FRAG_LDS>(A, lane);
+		else if (n_units >= 2) emm_layer_tiles<1, 2, FRAG_LDS>(A, lane);
+		else emm_layer_tiles<1, 1, FRAG_LDS>(A, lane);
+	}
+	else if (nwin == 2)
+	{
+		if (n_units >= 2) emm_layer_tiles<2, 2, FRAG_LDS>(A, lane);
+		else emm_layer_tiles<2, 1, FRAG_LDS>(A, lane);
+	}
+	else emm_layer_tiles<4, 1, FRAG_LDS>(A, lane);
 }
 
 template <bool FRAG_LDS>
@@ -267,16 +349,19 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 	const int n_layers = P->n_layers, batch = M->batch, buf_bytes = M->buf_bytes;
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int n_threads = blockDim.x, n_waves = n_threads >> 6;
-	/* small tables, copied once per workgroup: chunk offsets of every layer | seeds | layer records | column tables; then
+	/* small tables, copied once per workgroup: chunk offsets of every layer | seeds | column, expansion, input tables; then
 	 * the weight fragments (when resident); then one slice per wave: two ping-pong activation buffers and the expansion
 	 * buffer */
 	lds8 *tbl = emm_lds;
 	const int n_koff = M->n_koff, n_seeds = M->n_seeds, n_coltab = M->n_cols;
 	lds32 *koff_all = reinterpret_cast<lds32 *>(tbl);
 	lds32 *seeds_l = reinterpret_cast<lds32 *>(tbl + ((4 * n_koff + 15) & ~15));
-	EMM_LDS ed_net_layer_t *PL = reinterpret_cast<EMM_LDS ed_net_layer_t *>(reinterpret_cast<lds8 *>(seeds_l) + ((4 * n_seeds + 15) & ~15));
-	EMM_LDS ed_mm_layer_t *MLs = reinterpret_cast<EMM_LDS ed_mm_layer_t *>(reinterpret_cast<lds8 *>(PL) + ((n_layers * (int)sizeof(ed_net_layer_t) + 15) & ~15));
-	lds32 *coltab_l = reinterpret_cast<lds32 *>(reinterpret_cast<lds8 *>(MLs) + ((n_layers * (int)sizeof(ed_mm_layer_t) + 15) & ~15));
+	const ed_net_layer_t *__restrict__ PL = P->L;
+	const ed_mm_layer_t *__restrict__ MLs = M->L;
+	lds32 *coltab_l = reinterpret_cast<lds32 *>(reinterpret_cast<lds8 *>(seeds_l) + ((4 * n_seeds + 15) & ~15));
+	const int n_xtab = M->n_xtab, n_intab = M->n_intab;
+	lds32 *xtab_l = reinterpret_cast<lds32 *>(reinterpret_cast<lds8 *>(coltab_l) + ((8 * n_coltab + 15) & ~15));
+	EMM_LDS uint16_t *intab_l = reinterpret_cast<EMM_LDS uint16_t *>(reinterpret_cast<lds8 *>(xtab_l) + ((8 * n_xtab + 15) & ~15));
 	lds8 *fragl = tbl + M->tbl_bytes;
 	lds8 *slice = fragl + M->frag_lds + wave * (2 * buf_bytes + M->x_bytes);
 	lds8 *bufs[2] = {slice, slice + buf_bytes};
@@ -285,12 +370,8 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 		for (int i = threadIdx.x; i < n_koff; i += n_threads) koff_all[i] = M->koff[i];
 		for (int i = threadIdx.x; i < n_seeds; i += n_threads) seeds_l[i] = seeds[i];
 		for (int i = threadIdx.x; i < 2 * n_coltab; i += n_threads) coltab_l[i] = M->coltab[i];
-		const int *s1 = reinterpret_cast<const int *>(&P->L[0]);
-		lds32 *d1 = reinterpret_cast<lds32 *>(PL);
-		for (int i = threadIdx.x; i < n_layers * (int)(sizeof(ed_net_layer_t) / 4); i += n_threads) d1[i] = s1[i];
-		const int *s2 = reinterpret_cast<const int *>(&M->L[0]);
-		lds32 *d2 = reinterpret_cast<lds32 *>(MLs);
-		for (int i = threadIdx.x; i < n_layers * (int)(sizeof(ed_mm_layer_t) / 4); i += n_threads) d2[i] = s2[i];
+		for (int i = threadIdx.x; i < 2 * n_xtab; i += n_threads) xtab_l[i] = M->xtab[i];
+		for (int i = threadIdx.x; i < n_intab; i += n_threads) intab_l[i] = M->intab[i];
 		if (FRAG_LDS)
 		{
 			const v4i *src = reinterpret_cast<const v4i *>(frag);
@@ -313,41 +394,69 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 		{
 			const emm_layout l0 = emm_in_layout(MLs, PL, n_layers, 0);
 			const int in_h = P->in_h, in_w = P->in_w, in_c = P->in_c, in_n = P->in_n;
-			const float inv_n = 1.0f / (float)in_n, inv_c = 1.0f / (float)in_c, inv_w = 1.0f / (float)in_w;
-			emm_zero(bufs[0], batch * l0.img, lane);
-			emm_sync();
-			for (int i0 = 0; i0 < nb * in_n; i0 += 8 * 64)
+			if (l0.hp != in_h || l0.wp != in_w) /* uniform: a zero border to keep */
 			{
-				int8_t v[8];
-#pragma unroll
-				for (int k = 0; k < 8; k++)
+				emm_zero(bufs[0], batch * l0.img, lane);
+				emm_sync();
+			}
+			if (n_intab)
+			{
+				/* four elements per lane and step: one (unaligned) dword from HBM, their four places from the table */
+				for (int b = 0; b < nb; b++)
 				{
-					const int i = i0 + k * 64 + lane;
-					int b, e;
-					emm_divmod(i, in_n, inv_n, b, e);
-					v[k] = i < nb * in_n ? in[(u0 + b) * in_stride + e] : 0;
-				}
+					const int8_t *src = in + (u0 + b) * in_stride;
+					lds8 *dst = bufs[0] + b * l0.img;
+					for (int e = 4 * lane; e < in_n; e += 256)
+					{
+						uint32_t v;
+						if (e + 4 <= in_n) v = *reinterpret_cast<const uint32_t *>(src + e); /* the batch's last bytes are not overrun */
+						else
+						{
+							v = (uint32_t)(uint8_t)src[e];
+							if (e + 1 < in_n) v |= (uint32_t)(uint8_t)src[e + 1] << 8;
+							if (e + 2 < in_n) v |= (uint32_t)(uint8_t)src[e + 2] << 16;
+						}
 #pragma unroll
-				for (int k = 0; k < 8; k++)
-				{
-					const int i = i0 + k * 64 + lane;
-					if (i >= nb * in_n) continue;
-					int b, e, pix, c, y, x;
-					emm_divmod(i, in_n, inv_n, b, e); emm_divmod(e, in_c, inv_c, pix, c); emm_divmod(pix, in_w, inv_w, y, x);
-					bufs[0][b * l0.img + ((y + l0.py) * l0.wp + x + l0.px) * in_c + c] = v[k];
+						for (int t = 0; t < 4; t++)
+							if (e + t < in_n) dst[intab_l[e + t]] = (int8_t)(v >> (8 * t));
+					}
 				}
 			}
-			(void)in_h;
+			else
+			{
+				const float inv_n = __builtin_amdgcn_rcpf((float)in_n), inv_c = __builtin_amdgcn_rcpf((float)in_c), inv_w = __builtin_amdgcn_rcpf((float)in_w);
+				for (int i0 = 0; i0 < nb * in_n; i0 += 8 * 64)
+				{
+					int8_t v[8];
+#pragma unroll
+					for (int k = 0; k < 8; k++)
+					{
+						const int i = i0 + k * 64 + lane;
+						int b, e;
+						emm_divmod(i, in_n, inv_n, b, e);
+						v[k] = i < nb * in_n ? in[(u0 + b) * in_stride + e] : 0;
+					}
+#pragma unroll
+					for (int k = 0; k < 8; k++)
+					{
+						const int i = i0 + k * 64 + lane;
+						if (i >= nb * in_n) continue;
+						int b, e, pix, c, y, x;
+						emm_divmod(i, in_n, inv_n, b, e); emm_divmod(e, in_c, inv_c, pix, c); emm_divmod(pix, in_w, inv_w, y, x);
+						bufs[0][b * l0.img + ((y + l0.py) * l0.wp + x + l0.px) * in_c + c] = v[k];
+					}
+				}
+			}
 			emm_sync();
 		}
 		EMM_ST(0)
 		int cur = 0;
 		for (int li = 0; li < n_layers; li++)
 		{
-			ed_net_layer_t L;
-			ed_mm_layer_t ML;
-			emm_copy_record(&L, &PL[li]);
-			emm_copy_record(&ML, &MLs[li]);
+			/* wave-uniform records straight from the (read-only) plans: scalar loads into SGPRs. Copies in LDS cost a
+			 * ds_read + v_readfirstlane per field, ~1.7 k cycles per layer and wave. */
+			const ed_net_layer_t L = PL[li];
+			const ed_mm_layer_t ML = MLs[li];
 			if (ML.skip) continue; /* a MaxPool taken in the epilogue of the layer in front of it */
 			const int fused = ML.pool_h > 0, lnx = fused ? li + 2 : li + 1; /* the layer that consumes what this one stores */
 			const emm_layout lin = emm_in_layout(MLs, PL, n_layers, li), lo = emm_in_layout(MLs, PL, n_layers, lnx);
@@ -371,30 +480,35 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 				A.bsrc = a; A.img = lin.img;
 				if (ML.expand)
 				{
-					/* one aligned record of 16 * cpr bytes per (input row, output x): the kw * C_in bytes under a kernel row */
+					/* one aligned record of 16 * cpr bytes per (input row, output x): the kw * C_in bytes under a kernel row.
+					 * 16 bytes from an arbitrary byte offset: five aligned dwords around them, funnel-shifted (v_alignbit), the
+					 * bytes past the end of the kernel-row segment zeroed (the image buffers carry 16 bytes of slack) */
 					const int in_c = dense ? L.in_n : L.in_c, seg = (dense ? 1 : L.kw) * in_c, sw = dense ? 1 : L.sw;
 					const int rec_per_img = (dense ? 1 : lin.hp) * out_w * ML.cpr;
-					const float inv_rec = 1.0f / (float)rec_per_img, inv_row = 1.0f / (float)(out_w * ML.cpr), inv_cpr = 1.0f / (float)ML.cpr;
-					for (int i = lane; i < nb * rec_per_img; i += 64)
+					if (ML.xtab_off >= 0)
 					{
-						int b, e, r, e2, xo, j;
-						emm_divmod(i, rec_per_img, inv_rec, b, e); emm_divmod(e, out_w * ML.cpr, inv_row, r, e2); emm_divmod(e2, ML.cpr, inv_cpr, xo, j);
-						/* 16 bytes from an arbitrary byte offset: five aligned dwords around them, funnel-shifted (v_alignbit), the
-						 * bytes past the end of the kernel-row segment zeroed (the image buffers carry 16 bytes of slack) */
-						const int soff = b * lin.img + (r * lin.wp + xo * sw) * in_c + 16 * j;
-						const lds8 *s4 = a + (soff & ~3);
-						const uint32_t sh = (uint32_t)(soff & 3) * 8;
-						const uint32_t w0 = (uint32_t)EMM_LD32(s4), w1 = (uint32_t)EMM_LD32(s4 + 4), w2 = (uint32_t)EMM_LD32(s4 + 8), w3 = (uint32_t)EMM_LD32(s4 + 12), w4 = (uint32_t)EMM_LD32(s4 + 16);
-						uint32_t d[4] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),
-						                 __builtin_amdgcn_alignbit(w3, w2, sh), __builtin_amdgcn_alignbit(w4, w3, sh)};
-						const int keep = seg - 16 * j; /* bytes of this chunk that belong to the segment (>= 1) */
-#pragma unroll
-						for (int t = 0; t < 4; t++)
+						const lds8 *xt = reinterpret_cast<const lds8 *>(xtab_l + 2 * ML.xtab_off);
+						for (int i = lane; i < rec_per_img; i += 64)
 						{
-							const int kb = keep - 4 * t;
-							d[t] = kb >= 4 ? d[t] : (kb <= 0 ? 0u : d[t] & (0xffffffffu >> (8 * (4 - kb))));
+							const int w0_ = EMM_LD32(xt + 8 * i), doff = EMM_LD32(xt + 8 * i + 4);
+							const int soff0 = w0_ & 0xffffff, keep = w0_ >> 24;
+							for (int b = 0; b < nb; b++)
+							{
+								const int soff = b * lin.img + soff0;
+								EMM_ST128(xbuf + b * ML.x_img + doff, emm_gather16(a, soff, keep));
+							}
 						}
-						EMM_ST128(xbuf + b * ML.x_img + r * ML.pitch_y + xo * ML.pitch_x + 16 * j, ((v4i){(int)d[0], (int)d[1], (int)d[2], (int)d[3]}));
+					}
+					else
+					{
+						const float inv_rec = __builtin_amdgcn_rcpf((float)rec_per_img), inv_row = __builtin_amdgcn_rcpf((float)(out_w * ML.cpr)), inv_cpr = __builtin_amdgcn_rcpf((float)ML.cpr);
+						for (int i = lane; i < nb * rec_per_img; i += 64)
+						{
+							int b, e, r, e2, xo, j;
+							emm_divmod(i, rec_per_img, inv_rec, b, e); emm_divmod(e, out_w * ML.cpr, inv_row, r, e2); emm_divmod(e2, ML.cpr, inv_cpr, xo, j);
+							const int soff = b * lin.img + (r * lin.wp + xo * sw) * in_c + 16 * j;
+							EMM_ST128(xbuf + b * ML.x_img + r * ML.pitch_y + xo * ML.pitch_x + 16 * j, emm_gather16(a, soff, seg - 16 * j));
+						}
 					}
 					A.bsrc = xbuf;
 					A.img = ML.x_img;
@@ -413,16 +527,16 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 				A.pitch_x = ML.pitch_x; A.pitch_y = ML.pitch_y; A.sh = dense ? 1 : L.sh;
 				A.ph = fused ? ML.pool_h : 1; A.pw = fused ? ML.pool_w : 1;
 				A.o_origin = o_origin; A.o_row = o_row; A.oc_pitch = oc_pitch; A.out_c = L.out_c; A.rs = L.rs; A.lo_clamp = L.relu ? 0 : -128;
-				const int nwin = A.ph * A.pw; /* 1, 2 or 4 (model_net_mm.c fuses nothing else) */
-				if (nwin == 1) emm_layer_tiles<1, FRAG_LDS>(A, lane);
-				else if (nwin == 2) emm_layer_tiles<2, FRAG_LDS>(A, lane);
-				else emm_layer_tiles<4, FRAG_LDS>(A, lane);
+#if EMM_STAMP
+				A.st_ = stamp_; A.tl_p = &tl_;
+#endif
+				emm_layer_dispatch<FRAG_LDS>(A, lane); /* windows: 1, 2 or 4 (model_net_mm.c fuses nothing else) */
 			}
 			else if (L.type == ED_NET_POOL && (L.in_c & 3) == 0)
 			{
 				/* four channels per thread: byte-wise signed maximum of dwords */
 				const int c4n = L.in_c >> 2, per_img = L.out_h * L.out_w * c4n;
-				const float inv_img = 1.0f / (float)per_img, inv_c4 = 1.0f / (float)c4n, inv_ow = 1.0f / (float)L.out_w;
+				const float inv_img = __builtin_amdgcn_rcpf((float)per_img), inv_c4 = __builtin_amdgcn_rcpf((float)c4n), inv_ow = __builtin_amdgcn_rcpf((float)L.out_w);
 				for (int i = lane; i < nb * per_img; i += 64)
 				{
 					int b, e, pix, c4, y, x;
@@ -468,59 +582,60 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 					o[b * lo.img + o_origin + y * o_row + x * oc_pitch + c] = (int8_t)mx;
 				}
 			}
-			else /* softmax: arm_softmax_q7.c:215-260, one lane per input */
+			else /* softmax: arm_softmax_q7.c:215-260 */
 			{
-				if (lane < nb)
+				if (L.in_n <= 64)
+				{
+					/* one lane per class, one image after the other: maximum and sum are wave reductions, the division
+					 * happens once, in float with a one-step correction (2^20 < 2^24) */
+					for (int b = 0; b < nb; b++)
+					{
+						const bool in = lane < L.in_n;
+						const int x = in ? (int)a[b * lin.img + lane] : -128;
+						const int base = emm_wave_max(x) - 8;
+						const int sum = emm_wave_add(in ? 1 << emm_med3(x - base, 0, 7) : 0);
+						int output_base, rem;
+						emm_divmod(1 << 20, sum, __builtin_amdgcn_rcpf((float)sum), output_base, rem);
+						if (in) o[b * lo.img + lane] = (int8_t)emm_med3(output_base >> emm_med3(13 + base - x, 0, 31), -128, 127);
+					}
+				}
+				else if (lane < nb)
 				{
 					const lds8 *v = a + lane * lin.img;
 					lds8 *w = o + lane * lo.img;
-					if (L.in_n <= 16)
-					{
-						/* the usual classifier width: one 16-byte read, everything else in registers */
-						const v4i raw = EMM_LD128(v);
-						const uint32_t rw[4] = {(uint32_t)raw.x, (uint32_t)raw.y, (uint32_t)raw.z, (uint32_t)raw.w};
-						int base = -128;
-#pragma unroll
-						for (int i = 0; i < 16; i++) { const int x = (int)(int8_t)(rw[i >> 2] >> (8 * (i & 3))); if (i < L.in_n && x > base) base = x; }
-						base -= 8;
-						int sum = 0;
-#pragma unroll
-						for (int i = 0; i < 16; i++) { const int x = (int)(int8_t)(rw[i >> 2] >> (8 * (i & 3))); if (i < L.in_n) sum += 1 << emm_med3(x - base, 0, 7); }
-						const int output_base = (1 << 20) / sum;
-						uint32_t ow[4] = {0, 0, 0, 0};
-#pragma unroll
-						for (int i = 0; i < 16; i++)
-						{
-							const int x = (int)(int8_t)(rw[i >> 2] >> (8 * (i & 3)));
-							const int r = emm_med3(output_base >> emm_med3(13 + base - x, 0, 31), -128, 127);
-							if (i < L.in_n) ow[i >> 2] |= (uint32_t)(uint8_t)r << (8 * (i & 3));
-						}
-						EMM_ST128(w, ((v4i){(int)ow[0], (int)ow[1], (int)ow[2], (int)ow[3]}));
-					}
-					else
-					{
-						int base = -128;
-						for (int i = 0; i < L.in_n; i++) base = v[i] > base ? v[i] : base;
-						base -= 8;
-						int sum = 0;
-						for (int i = 0; i < L.in_n; i++) sum += 1 << emm_med3(v[i] - base, 0, 7);
-						const int output_base = (1 << 20) / sum;
-						for (int i = 0; i < L.in_n; i++) w[i] = (int8_t)emm_med3(output_base >> emm_med3(13 + base - v[i], 0, 31), -128, 127);
-					}
+					int base = -128;
+					for (int i = 0; i < L.in_n; i++) base = v[i] > base ? v[i] : base;
+					base -= 8;
+					int sum = 0;
+					for (int i = 0; i < L.in_n; i++) sum += 1 << emm_med3(v[i] - base, 0, 7);
+					const int output_base = (1 << 20) / sum;
+					for (int i = 0; i < L.in_n; i++) w[i] = (int8_t)emm_med3(output_base >> emm_med3(13 + base - v[i], 0, 31), -128, 127);
 				}
 			}
 			EMM_ST(2 + 5 * li)
 			emm_sync();
-			/* outputs (the layouts of the logits layer's and the last layer's outputs are compact) */
-			if (li == logits_layer && logits)
-				for (int i = lane; i < nb * out_n; i += 64)
-					logits[(u0 + i / out_n) * out_n + i % out_n] = o[(i / out_n) * lo.img + i % out_n];
-			if (li == n_layers - 1)
+			/* outputs (the layouts of the logits layer's and the last layer's outputs are compact); what this pass stored is
+			 * the output of layer li_out: the fused MaxPool's when there is one */
+			const int li_out = fused ? li + 1 : li;
+			if (li_out == logits_layer && logits)
+				for (int b = 0; b < nb; b++)
+					for (int i = lane; i < out_n; i += 64) logits[(u0 + b) * out_n + i] = o[b * lo.img + i];
+			if (li_out == n_layers - 1)
 			{
 				if (has_softmax && softmax)
-					for (int i = lane; i < nb * out_n; i += 64)
-						softmax[(u0 + i / out_n) * out_n + i % out_n] = o[(i / out_n) * lo.img + i % out_n];
-				if (argmax && lane < nb)
+					for (int b = 0; b < nb; b++)
+						for (int i = lane; i < out_n; i += 64) softmax[(u0 + b) * out_n + i] = o[b * lo.img + i];
+				if (argmax && out_n <= 64)
+				{
+					/* first maximum: the largest (value, 63 - index) pair of the wave */
+					for (int b = 0; b < nb; b++)
+					{
+						const int key = lane < out_n ? (((int)o[b * lo.img + lane] + 128) << 6) | (63 - lane) : -1;
+						const int best = 63 - (emm_wave_max(key) & 63);
+						if (lane == 0) argmax[u0 + b] = best;
+					}
+				}
+				else if (argmax && lane < nb)
 				{
 					const lds8 *v = o + lane * lo.img;
 					int best = 0, mx = -129;

@@ -241,6 +241,8 @@ int ed_plan_net(const void *blob, size_t blob_bytes, ed_net_plan_t *plan, int8_t
  * workgroup barrier (the first version ran a workgroup in lockstep phases and spent a third of its time in barriers). */
 #define ED_MM_MAX_KOFF 1024
 #define ED_MM_MAX_COLS 1024 /* column-table entries of all layers together (8 bytes each in LDS) */
+#define ED_MM_MAX_XTAB 1536 /* expansion-table entries of all layers together (8 bytes each in LDS) */
+#define ED_MM_MAX_INTAB 4096 /* input-table entries (2 bytes each in LDS) */
 typedef struct {
 	int32_t mm;                 /* 1: Conv2D / Dense on the matrix cores                                              */
 	int32_t in_hp, in_wp;       /* the input image as this layer wants it in LDS: padded height / width ...          */
@@ -258,6 +260,8 @@ typedef struct {
 	                             * (exact: the requantisation is monotone) -- and the pool layer itself is skipped       */
 	int32_t skip;               /* 1: this MaxPool is fused into the layer in front of it                              */
 	int32_t col_off;            /* >= 0: index of this layer's column table in coltab[] (pairs), -1: the kernel divides    */
+	int32_t xtab_off;           /* >= 0: index of this layer's expansion table in xtab[] (pairs), -1: the kernel divides   */
+	int32_t pad_[3];
 } ed_mm_layer_t;
 
 typedef struct {
@@ -269,15 +273,24 @@ typedef struct {
 	int32_t lds_bytes;
 	int32_t frag_lds;           /* bytes of LDS reserved for weight fragments                                         */
 	int32_t frag_mode;          /* 2: all layers resident in LDS, 0: streamed from L2                                  */
-	int32_t tbl_bytes;          /* LDS copy of the small tables: koff | seeds | layer records (read once per workgroup) */
+	int32_t tbl_bytes;          /* LDS copy of the small tables: koff | seeds | column tables (read once per workgroup) */
 	int32_t frag_bytes, n_seeds, n_koff;
 	int32_t n_cols;             /* entries of coltab[] in use                                                          */
+	int32_t n_xtab;             /* entries of xtab[] in use                                                            */
+	int32_t n_intab;            /* entries of intab[] in use: in_n, or 0 (the kernel divides)                          */
+	int32_t pad_;
 	ed_mm_layer_t L[ED_NET_MAX_LAYERS];
 	int32_t koff[ED_MM_MAX_KOFF];
 	/* per stored pixel (y, x) of a matrix-core layer, in pixel order: byte offset of its first window's first chunk in
 	 * the layer's B source, and of its output pixel in the consumer's layout (what the kernel would otherwise work out
 	 * with two divisions per 32-column tile) */
 	int32_t coltab[2 * ED_MM_MAX_COLS];
+	/* per expansion record of a layer (one per input row, output x and 16-byte chunk): source byte offset inside the
+	 * input image | bytes of the chunk that belong to the kernel-row segment << 24, and the destination byte offset
+	 * inside the expanded image */
+	int32_t xtab[2 * ED_MM_MAX_XTAB];
+	/* byte offset of input element e (HWC order) inside layer 0's LDS layout */
+	uint16_t intab[ED_MM_MAX_INTAB];
 } ed_mm_plan_t;
 
 /* Adds the matrix-core plan to a graph ed_plan_net accepted. *frag / *seeds are malloc'd when mm->ok. */

@@ -119,6 +119,42 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 	}
 	mm->n_cols = n_cols;
 
+	/* expansion tables and the input table, under the same rule (what does not fit is worked out by the kernel) */
+	int n_xtab = 0;
+	for (int i = 0; i < n_layers; i++)
+	{
+		const ed_net_layer_t *L = &plan->L[i];
+		ed_mm_layer_t *M = &mm->L[i];
+		M->xtab_off = -1;
+		if (!M->mm || !M->expand) continue;
+		const int dense = L->type == ED_NET_DENSE;
+		const int in_c = dense ? L->in_n : L->in_c, seg = (dense ? 1 : L->kw) * in_c, sw = dense ? 1 : L->sw, out_w = dense ? 1 : L->out_w;
+		const int rows = dense ? 1 : M->in_hp, rec = rows * out_w * M->cpr;
+		if (n_xtab + rec > ED_MM_MAX_XTAB || M->in_img >= (1 << 24)) continue;
+		M->xtab_off = n_xtab;
+		for (int r = 0; r < rows; r++)
+			for (int xo = 0; xo < out_w; xo++)
+				for (int j = 0; j < M->cpr; j++)
+				{
+					const int keep = seg - 16 * j < 16 ? seg - 16 * j : 16;
+					mm->xtab[2 * n_xtab] = ((r * M->in_wp + xo * sw) * in_c + 16 * j) | (keep << 24);
+					mm->xtab[2 * n_xtab + 1] = r * M->pitch_y + xo * M->pitch_x + 16 * j;
+					n_xtab++;
+				}
+	}
+	mm->n_xtab = n_xtab;
+	mm->n_intab = 0;
+	if (plan->in_n <= ED_MM_MAX_INTAB && mm->L[0].in_img <= 65536)
+	{
+		const ed_mm_layer_t *M0 = &mm->L[0];
+		for (int e = 0; e < plan->in_n; e++)
+		{
+			const int pix = e / plan->in_c, c = e - pix * plan->in_c, y = pix / plan->in_w, x = pix - y * plan->in_w;
+			mm->intab[e] = (uint16_t)(((y + M0->in_py) * M0->in_wp + x + M0->in_px) * plan->in_c + c);
+		}
+		mm->n_intab = plan->in_n;
+	}
+
 	/* LDS budget: two ping-pong buffers of batch x the largest image layout, the expansion buffer, the koff table */
 	int max_img = up16(plan->in_n) + 16, max_x = 0;
 	for (int i = 0; i < n_layers; i++)
@@ -137,8 +173,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 	 * per-wave batch grows (up to 4) only while 8 waves still fit -- independent waves hide each other's latencies, a
 	 * bigger batch only fills the 32-column tiles of small late layers better. */
 	const int lds_cap = 150 * 1024;
-	const int tbl = up16(4 * n_koff) + up16(4 * n_seeds) + up16(n_layers * (int)sizeof(ed_net_layer_t)) + up16(n_layers * (int)sizeof(ed_mm_layer_t)) +
-	                up16(8 * n_cols);
+	const int tbl = up16(4 * n_koff) + up16(4 * n_seeds) + up16(8 * n_cols) + up16(8 * n_xtab) + up16(2 * mm->n_intab);
 	if (tbl > 24 * 1024) return EDISON_OK;
 	int batch = 0, waves = 0, frag_lds = 0, frag_mode = 0;
 	for (int mode = 2; mode >= 0 && !batch; mode -= 2)

@@ -182,3 +182,41 @@ def test_planner_refusals(built_lib):
     with pytest.raises(_lib.EdisonError):
         c.load_model_bytes(blob[:-20])
     c.close()
+
+
+def test_fused_pool_as_the_last_layer_and_multi_unit_groups(built_lib):
+    """Shapes the random fuzz found or that exercise every (windows, units) instantiation of the matrix-core kernel:
+    a MaxPool fused into the convolution in front of it that is ALSO the graph's last (logits) layer (round 2: the
+    outputs were never written), with and without a Softmax behind it; row-tile pairs (C_out 64), four column tiles at
+    once, a 2x2 window. Batch path (edison_net_batch_dev) against the numpy restatement, bit for bit."""
+    from edison_amd import nnom_import
+    from edison_amd.context import Context
+    from oracle import net_ref
+    rng = np.random.default_rng(5)
+
+    def conv(oc, kh, kw, sh, sw, c, rs=8, bl=3, relu=1, same=0):
+        return dict(type=1, out_ch=oc, kh=kh, kw=kw, sh=sh, sw=sw, w=rng.integers(-100, 101, oc * kh * kw * c).astype(np.int8),
+                    b=rng.integers(-100, 101, oc).astype(np.int8), out_rshift=rs, bias_lshift=bl, relu=relu, same=same)
+
+    def pool(kh, kw):
+        return dict(type=2, kh=kh, kw=kw, sh=kh, sw=kw, same=0)
+
+    cases = {
+        "pool last": ((18, 10, 1), [conv(5, 1, 3, 1, 2, 1, 10, 5, 0, 1), conv(1, 4, 2, 2, 2, 5, 6, 4), pool(1, 2)]),
+        "pool + softmax last": ((18, 10, 1), [conv(5, 1, 3, 1, 2, 1, 10, 5, 0, 1), conv(4, 4, 2, 2, 2, 5, 6, 4), pool(1, 2), dict(type=4)]),
+        "row-tile pairs": ((9, 7, 16), [conv(64, 3, 3, 1, 1, 16, 9), conv(8, 3, 3, 1, 1, 64, 10)]),
+        "four column tiles": ((16, 12, 3), [conv(8, 3, 3, 1, 1, 3, 9, same=1), conv(4, 3, 3, 1, 1, 8, 9)]),
+        "2x2 window": ((14, 14, 2), [conv(16, 3, 3, 1, 1, 2, 9), pool(2, 2), conv(8, 3, 3, 1, 1, 16, 10)]),
+    }
+    c = Context(0, model_path=None)
+    for name, (shape, layers) in cases.items():
+        blob = nnom_import.build_blob(shape, [dict(L) for L in layers])
+        c.load_model_bytes(blob)
+        assert c.net_info()["accelerated"] == 2, name
+        x = rng.integers(-128, 128, (77, shape[0] * shape[1] * shape[2])).astype(np.int8)
+        ref, out = net_ref.run(blob, x), c.net(x)
+        assert np.array_equal(out["logits"], ref["logits"]), name
+        assert np.array_equal(out["argmax"], ref["argmax"]), name
+        if layers[-1]["type"] == 4:
+            assert np.array_equal(out["softmax"], ref["softmax"]), name
+    c.close()

@@ -80,7 +80,11 @@ def main():
             first = int(np.argwhere(got != want)[0][1])
             raise SystemExit("MISMATCH on graph %s %s at activation byte %d" % (shape, [(L["type"], {k: v for k, v in L.items() if k not in ("w", "b")}) for L in plain], first))
         out = ctx.net(x)
-        assert np.array_equal(out["argmax"], ref["argmax"]) and np.array_equal(out["logits"], ref["logits"])
+        if not (np.array_equal(out["argmax"], ref["argmax"]) and np.array_equal(out["logits"], ref["logits"])):
+            bad = np.argwhere(out["logits"] != ref["logits"])
+            raise SystemExit("MISMATCH (batch path, accelerated=%s) on graph %s %s: %d logits differ, first at %s; argmax equal: %s" % (
+                ctx.net_info().get("accelerated"), shape, [(L["type"], {k: v for k, v in L.items() if k not in ("w", "b")}) for L in plain],
+                len(bad), bad[:1].tolist(), np.array_equal(out["argmax"], ref["argmax"])))
         ran += 1
     print("general network kernel: %d random graphs bit-exact against oracle/net_ref.py, %d refused by the planner" % (ran, refused))
 

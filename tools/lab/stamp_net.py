@@ -27,6 +27,7 @@ info = ctx.net_info()
 print("input load %5.1f %%" % (100 * d[0] / tot))
 for li, l in enumerate(info["layers"]):
     print("layer %d type %d: setup (zero, expand, tables) %5.1f %%   body (tiles / pool / softmax) %5.1f %%" % (li, l["type"], 100 * d[1 + 5 * li] / tot, 100 * d[2 + 5 * li] / tot))
+print("inside the tile groups of all layers: group setup %5.1f %%, seeds + k-loop %5.1f %%, epilogue %5.1f %%, before the first group %5.1f %%" % tuple(100 * d[i] / tot for i in (40, 41, 42, 43)))
 print("outputs + loop %5.1f %%" % (100 * (d[46] + d[47]) / tot))
 waves = 256 * info.get("mm_waves", 12)
 print("cycles per input of wave 0 of workgroup 0: %.0f (3 such waves share a SIMD)" % (tot / (n / waves)))
