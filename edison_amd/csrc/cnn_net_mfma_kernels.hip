@@ -99,6 +99,27 @@ __device__ __forceinline__ v4i emm_gather16(const lds8 *a, int soff, int keep)
 	return (v4i){(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
 }
 
+/* elements 4 lane + 256 k .. +3 of one input image into x[k], k < EMM_PRE (zero past the image); the image's last bytes
+ * are not overrun (the batch may end there) */
+#define EMM_PRE 2
+__device__ __forceinline__ void emm_load_image(const int8_t *src, int in_n, int lane, uint32_t (&x)[EMM_PRE])
+{
+#pragma unroll
+	for (int k = 0; k < EMM_PRE; k++)
+	{
+		const int e = 4 * lane + 256 * k;
+		uint32_t v = 0;
+		if (e + 4 <= in_n) v = *reinterpret_cast<const uint32_t *>(src + e);
+		else if (e < in_n)
+		{
+			v = (uint32_t)(uint8_t)src[e];
+			if (e + 1 < in_n) v |= (uint32_t)(uint8_t)src[e + 1] << 8;
+			if (e + 2 < in_n) v |= (uint32_t)(uint8_t)src[e + 2] << 16;
+		}
+		x[k] = v;
+	}
+}
+
 struct emm_layout { int hp, wp, py, px, img; }; /* how an activation tensor lies in LDS: padded dims, origin, bytes per image */
 
 __device__ __forceinline__ emm_layout emm_in_layout(const ed_mm_layer_t *__restrict__ ML, const ed_net_layer_t *__restrict__ PL, int n_layers, int li)
@@ -318,15 +339,15 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 	}
 }
 
-/* NW windows per unit (1, 2 or 4); as many units at once as fit four accumulator tiles and the layer has */
+/* NW windows per unit (1, 2 or 4); two units at once when the layer has them and four accumulator tiles hold them */
 template <bool FRAG_LDS>
 __device__ __forceinline__ void emm_layer_dispatch(const emm_mm_args &A, int lane)
 {
 	const int nwin = A.ph * A.pw, n_units = A.n_rt * ((A.n_cols + 31) >> 5);
 	if (nwin == 1)
 	{
-		if (n_units >= 4) emm_layer_tiles<1, 4, FRAG_LDS>(A, lane);
-		else if (n_units >= 2) emm_layer_tiles<1, 2, FRAG_LDS>(A, lane);
+		/* (four units of one window each would hold 8 A fragments beside 8 B fragments and 4 accumulators: it spills) */
+		if (n_units >= 2) emm_layer_tiles<1, 2, FRAG_LDS>(A, lane);
 		else emm_layer_tiles<1, 1, FRAG_LDS>(A, lane);
 	}
 	else if (nwin == 2)
@@ -386,7 +407,13 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 	for (int i = 0; i < 48; i++) stamp_[i] = 0;
 	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_) :: "memory");
 #endif
-	for (int64_t u0 = ((int64_t)blockIdx.x * n_waves + wave) * batch; u0 < n; u0 += (int64_t)gridDim.x * n_waves * batch)
+	/* One image per wave and at most 512 bytes of it: the next image's dwords are requested from HBM before this one's layers
+	 * run (two registers; more would spill), so that the wave never waits a memory latency per input. */
+	const int64_t u_first = ((int64_t)blockIdx.x * n_waves + wave) * batch, u_step = (int64_t)gridDim.x * n_waves * batch;
+	const bool prefetch = n_intab && batch == 1 && P->in_n <= EMM_PRE * 256;
+	uint32_t pre[EMM_PRE];
+	if (prefetch && u_first < n) emm_load_image(in + u_first * in_stride, P->in_n, lane, pre);
+	for (int64_t u0 = u_first; u0 < n; u0 += u_step)
 	{
 		const int nb = (int)((n - u0) < batch ? (n - u0) : batch);
 		EMM_ST(47)
@@ -399,7 +426,23 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 				emm_zero(bufs[0], batch * l0.img, lane);
 				emm_sync();
 			}
-			if (n_intab)
+			if (prefetch)
+			{
+				uint32_t v[EMM_PRE];
+#pragma unroll
+				for (int k = 0; k < EMM_PRE; k++) v[k] = pre[k];
+				/* unconditional, like the MFCC kernels' prefetch: a wave's last pass re-reads its own image (an L2 hit) */
+				emm_load_image(in + (u0 + u_step < n ? u0 + u_step : u0) * in_stride, in_n, lane, pre);
+#pragma unroll
+				for (int k = 0; k < EMM_PRE; k++)
+				{
+					const int e = 4 * lane + 256 * k;
+#pragma unroll
+					for (int t = 0; t < 4; t++)
+						if (e + t < in_n) bufs[0][intab_l[e + t]] = (int8_t)(v[k] >> (8 * t));
+				}
+			}
+			else if (n_intab)
 			{
 				/* four elements per lane and step: one (unaligned) dword from HBM, their four places from the table */
 				for (int b = 0; b < nb; b++)
