@@ -496,87 +496,80 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 		int cur = 0;
 		for (int li = 0; li < n_layers; li++)
 		{
-			/* wave-uniform records straight from the (read-only) plans: scalar loads into SGPRs. Copies in LDS cost a
-			 * ds_read + v_readfirstlane per field, ~1.7 k cycles per layer and wave. */
-			const ed_net_layer_t L = PL[li];
-			const ed_mm_layer_t ML = MLs[li];
-			if (ML.skip) continue; /* a MaxPool taken in the epilogue of the layer in front of it */
-			const int fused = ML.pool_h > 0, lnx = fused ? li + 2 : li + 1; /* the layer that consumes what this one stores */
-			const emm_layout lin = emm_in_layout(MLs, PL, n_layers, li), lo = emm_in_layout(MLs, PL, n_layers, lnx);
-			const int st_h = fused ? PL[li + 1].out_h : L.out_h, st_w = fused ? PL[li + 1].out_w : L.out_w; /* stored tensor */
+			/* one wave-uniform run record per layer, worked out by the planner: two scalar loads (copies in LDS cost a
+			 * ds_read + v_readfirstlane per field; deriving it here from the layer records took a chain of dependent
+			 * scalar loads and ~100 scalar instructions per layer and input) */
+			const ed_mm_run_t R = M->R[li];
+			if (R.kind == ED_RUN_SKIP) continue; /* a MaxPool taken in the epilogue of the layer in front of it */
 			const lds8 *a = bufs[cur];
 			lds8 *o = bufs[cur ^ 1];
 			cur ^= 1;
-			const int oc_pitch = L.out_c;                           /* bytes per output pixel */
-			const int o_origin = (lo.py * lo.wp + lo.px) * oc_pitch; /* where pixel (0, 0) goes */
-			const int o_row = lo.wp * oc_pitch;
-			if (lo.hp != st_h || lo.wp != st_w) /* uniform: the consumer wants a zero border */
+			if (R.zero_border) /* uniform: the consumer wants a zero border */
 			{
-				emm_zero(o, batch * lo.img, lane);
+				emm_zero(o, batch * R.o_img, lane);
 				emm_sync();
 			}
-			if (ML.mm)
+			if (R.kind == ED_RUN_MM)
 			{
-				const int dense = L.type == ED_NET_DENSE;
-				const int out_w = dense ? 1 : L.out_w;
 				emm_mm_args A;
-				A.bsrc = a; A.img = lin.img;
-				if (ML.expand)
+				A.bsrc = a; A.img = R.in_img;
+				if (R.expand)
 				{
 					/* one aligned record of 16 * cpr bytes per (input row, output x): the kw * C_in bytes under a kernel row.
 					 * 16 bytes from an arbitrary byte offset: five aligned dwords around them, funnel-shifted (v_alignbit), the
 					 * bytes past the end of the kernel-row segment zeroed (the image buffers carry 16 bytes of slack) */
-					const int in_c = dense ? L.in_n : L.in_c, seg = (dense ? 1 : L.kw) * in_c, sw = dense ? 1 : L.sw;
-					const int rec_per_img = (dense ? 1 : lin.hp) * out_w * ML.cpr;
-					if (ML.xtab_off >= 0)
+					if (R.xtab_off >= 0)
 					{
-						const lds8 *xt = reinterpret_cast<const lds8 *>(xtab_l + 2 * ML.xtab_off);
-						for (int i = lane; i < rec_per_img; i += 64)
+						const lds8 *xt = reinterpret_cast<const lds8 *>(xtab_l + 2 * R.xtab_off);
+						for (int i = lane; i < R.rec_per_img; i += 64)
 						{
 							const int w0_ = EMM_LD32(xt + 8 * i), doff = EMM_LD32(xt + 8 * i + 4);
 							const int soff0 = w0_ & 0xffffff, keep = w0_ >> 24;
 							for (int b = 0; b < nb; b++)
-							{
-								const int soff = b * lin.img + soff0;
-								EMM_ST128(xbuf + b * ML.x_img + doff, emm_gather16(a, soff, keep));
-							}
+								EMM_ST128(xbuf + b * R.x_img + doff, emm_gather16(a, b * R.in_img + soff0, keep));
 						}
 					}
 					else
 					{
-						const float inv_rec = __builtin_amdgcn_rcpf((float)rec_per_img), inv_row = __builtin_amdgcn_rcpf((float)(out_w * ML.cpr)), inv_cpr = __builtin_amdgcn_rcpf((float)ML.cpr);
-						for (int i = lane; i < nb * rec_per_img; i += 64)
+						/* no table (ED_MM_MAX_XTAB): the rare path reads the layer records and divides */
+						const ed_net_layer_t L = PL[li];
+						const ed_mm_layer_t ML = MLs[li];
+						const int dense = L.type == ED_NET_DENSE, out_w = dense ? 1 : L.out_w;
+						const int in_c = dense ? L.in_n : L.in_c, seg = (dense ? 1 : L.kw) * in_c, sw = dense ? 1 : L.sw;
+						const float inv_rec = __builtin_amdgcn_rcpf((float)R.rec_per_img), inv_row = __builtin_amdgcn_rcpf((float)(out_w * ML.cpr)), inv_cpr = __builtin_amdgcn_rcpf((float)ML.cpr);
+						for (int i = lane; i < nb * R.rec_per_img; i += 64)
 						{
 							int b, e, r, e2, xo, j;
-							emm_divmod(i, rec_per_img, inv_rec, b, e); emm_divmod(e, out_w * ML.cpr, inv_row, r, e2); emm_divmod(e2, ML.cpr, inv_cpr, xo, j);
-							const int soff = b * lin.img + (r * lin.wp + xo * sw) * in_c + 16 * j;
-							EMM_ST128(xbuf + b * ML.x_img + r * ML.pitch_y + xo * ML.pitch_x + 16 * j, emm_gather16(a, soff, seg - 16 * j));
+							emm_divmod(i, R.rec_per_img, inv_rec, b, e); emm_divmod(e, out_w * ML.cpr, inv_row, r, e2); emm_divmod(e2, ML.cpr, inv_cpr, xo, j);
+							const int soff = b * R.in_img + (r * ML.in_wp + xo * sw) * in_c + 16 * j;
+							EMM_ST128(xbuf + b * R.x_img + r * R.pitch_y + xo * R.pitch_x + 16 * j, emm_gather16(a, soff, seg - 16 * j));
 						}
 					}
 					A.bsrc = xbuf;
-					A.img = ML.x_img;
+					A.img = R.x_img;
 				}
 				EMM_ST(1 + 5 * li)
 				emm_sync();
-				A.o = o; A.o_img = lo.img;
-				A.fragl = fragl + ML.frag_off; A.fragg = frag + ML.frag_off;
-				A.koff = reinterpret_cast<const lds8 *>(koff_all + ML.koff_off);
-				A.seeds = reinterpret_cast<const lds8 *>(seeds_l + ML.seed_off);
-				A.coltab = ML.col_off >= 0 ? reinterpret_cast<const lds8 *>(coltab_l + 2 * ML.col_off) : nullptr;
-				A.n_ks = ML.n_ks; A.n_rt = ML.n_rt;
-				A.col_w = dense ? 1 : st_w;
-				A.pix_per_img = dense ? 1 : st_h * st_w;
-				A.n_cols = nb * A.pix_per_img;
-				A.pitch_x = ML.pitch_x; A.pitch_y = ML.pitch_y; A.sh = dense ? 1 : L.sh;
-				A.ph = fused ? ML.pool_h : 1; A.pw = fused ? ML.pool_w : 1;
-				A.o_origin = o_origin; A.o_row = o_row; A.oc_pitch = oc_pitch; A.out_c = L.out_c; A.rs = L.rs; A.lo_clamp = L.relu ? 0 : -128;
+				A.o = o; A.o_img = R.o_img;
+				A.fragl = fragl + R.frag_off; A.fragg = frag + R.frag_off;
+				A.koff = reinterpret_cast<const lds8 *>(koff_all + R.koff_off);
+				A.seeds = reinterpret_cast<const lds8 *>(seeds_l + R.seed_off);
+				A.coltab = R.col_off >= 0 ? reinterpret_cast<const lds8 *>(coltab_l + 2 * R.col_off) : nullptr;
+				A.n_ks = R.n_ks; A.n_rt = R.n_rt;
+				A.col_w = R.col_w;
+				A.pix_per_img = R.pix_per_img;
+				A.n_cols = nb * R.pix_per_img;
+				A.pitch_x = R.pitch_x; A.pitch_y = R.pitch_y; A.sh = R.sh;
+				A.ph = R.ph; A.pw = R.pw;
+				A.o_origin = R.o_origin; A.o_row = R.o_row; A.oc_pitch = R.oc_pitch; A.out_c = R.out_c; A.rs = R.rs; A.lo_clamp = R.lo_clamp;
 #if EMM_STAMP
 				A.st_ = stamp_; A.tl_p = &tl_;
 #endif
 				emm_layer_dispatch<FRAG_LDS>(A, lane); /* windows: 1, 2 or 4 (model_net_mm.c fuses nothing else) */
 			}
-			else if (L.type == ED_NET_POOL && (L.in_c & 3) == 0)
+			else if (R.kind == ED_RUN_POOL4)
 			{
+				const ed_net_layer_t L = PL[li];
 				/* four channels per thread: byte-wise signed maximum of dwords */
 				const int c4n = L.in_c >> 2, per_img = L.out_h * L.out_w * c4n;
 				const float inv_img = __builtin_amdgcn_rcpf((float)per_img), inv_c4 = __builtin_amdgcn_rcpf((float)c4n), inv_ow = __builtin_amdgcn_rcpf((float)L.out_w);
@@ -593,17 +586,18 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 						{
 							const int ix = x * L.sw - L.pad_w + kx;
 							if ((unsigned)ix >= (unsigned)L.in_w) continue;
-							const int v = EMM_LD32(a + b * lin.img + (iy * L.in_w + ix) * L.in_c + 4 * c4);
+							const int v = EMM_LD32(a + b * R.in_img + (iy * L.in_w + ix) * L.in_c + 4 * c4);
 							const int v0 = (int)(int8_t)v, v1 = (int)(int8_t)(v >> 8), v2 = (int)(int8_t)(v >> 16), v3 = v >> 24;
 							m0 = v0 > m0 ? v0 : m0; m1 = v1 > m1 ? v1 : m1; m2 = v2 > m2 ? v2 : m2; m3 = v3 > m3 ? v3 : m3;
 						}
 					}
-					EMM_ST32(o + b * lo.img + o_origin + y * o_row + x * oc_pitch + 4 * c4,
+					EMM_ST32(o + b * R.o_img + R.o_origin + y * R.o_row + x * R.oc_pitch + 4 * c4,
 					         (uint32_t)(uint8_t)m0 | ((uint32_t)(uint8_t)m1 << 8) | ((uint32_t)(uint8_t)m2 << 16) | ((uint32_t)(uint8_t)m3 << 24));
 				}
 			}
-			else if (L.type == ED_NET_POOL)
+			else if (R.kind == ED_RUN_POOL1)
 			{
+				const ed_net_layer_t L = PL[li];
 				const int per_img = L.out_n;
 				for (int i = lane; i < nb * per_img; i += 64)
 				{
@@ -618,69 +612,70 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 						{
 							const int ix = x * L.sw - L.pad_w + kx;
 							if ((unsigned)ix >= (unsigned)L.in_w) continue;
-							const int v = a[b * lin.img + (iy * L.in_w + ix) * L.in_c + c];
+							const int v = a[b * R.in_img + (iy * L.in_w + ix) * L.in_c + c];
 							mx = v > mx ? v : mx;
 						}
 					}
-					o[b * lo.img + o_origin + y * o_row + x * oc_pitch + c] = (int8_t)mx;
+					o[b * R.o_img + R.o_origin + y * R.o_row + x * R.oc_pitch + c] = (int8_t)mx;
 				}
 			}
 			else /* softmax: arm_softmax_q7.c:215-260 */
 			{
-				if (L.in_n <= 64)
+				const int in_n = R.in_n;
+				if (in_n <= 64)
 				{
 					/* one lane per class, one image after the other: maximum and sum are wave reductions, the division
 					 * happens once, in float with a one-step correction (2^20 < 2^24) */
 					for (int b = 0; b < nb; b++)
 					{
-						const bool in = lane < L.in_n;
-						const int x = in ? (int)a[b * lin.img + lane] : -128;
+						const bool in = lane < in_n;
+						const int x = in ? (int)a[b * R.in_img + lane] : -128;
 						const int base = emm_wave_max(x) - 8;
 						const int sum = emm_wave_add(in ? 1 << emm_med3(x - base, 0, 7) : 0);
 						int output_base, rem;
 						emm_divmod(1 << 20, sum, __builtin_amdgcn_rcpf((float)sum), output_base, rem);
-						if (in) o[b * lo.img + lane] = (int8_t)emm_med3(output_base >> emm_med3(13 + base - x, 0, 31), -128, 127);
+						if (in) o[b * R.o_img + lane] = (int8_t)emm_med3(output_base >> emm_med3(13 + base - x, 0, 31), -128, 127);
 					}
 				}
 				else if (lane < nb)
 				{
-					const lds8 *v = a + lane * lin.img;
-					lds8 *w = o + lane * lo.img;
+					const lds8 *v = a + lane * R.in_img;
+					lds8 *w = o + lane * R.o_img;
 					int base = -128;
-					for (int i = 0; i < L.in_n; i++) base = v[i] > base ? v[i] : base;
+					for (int i = 0; i < in_n; i++) base = v[i] > base ? v[i] : base;
 					base -= 8;
 					int sum = 0;
-					for (int i = 0; i < L.in_n; i++) sum += 1 << emm_med3(v[i] - base, 0, 7);
+					for (int i = 0; i < in_n; i++) sum += 1 << emm_med3(v[i] - base, 0, 7);
 					const int output_base = (1 << 20) / sum;
-					for (int i = 0; i < L.in_n; i++) w[i] = (int8_t)emm_med3(output_base >> emm_med3(13 + base - v[i], 0, 31), -128, 127);
+					for (int i = 0; i < in_n; i++) w[i] = (int8_t)emm_med3(output_base >> emm_med3(13 + base - v[i], 0, 31), -128, 127);
 				}
 			}
 			EMM_ST(2 + 5 * li)
 			emm_sync();
 			/* outputs (the layouts of the logits layer's and the last layer's outputs are compact); what this pass stored is
 			 * the output of layer li_out: the fused MaxPool's when there is one */
-			const int li_out = fused ? li + 1 : li;
+			const int li_out = R.li_out;
 			if (li_out == logits_layer && logits)
 				for (int b = 0; b < nb; b++)
-					for (int i = lane; i < out_n; i += 64) logits[(u0 + b) * out_n + i] = o[b * lo.img + i];
+					for (int i = lane; i < out_n; i += 64) logits[(u0 + b) * out_n + i] = o[b * R.o_img + i];
 			if (li_out == n_layers - 1)
 			{
 				if (has_softmax && softmax)
 					for (int b = 0; b < nb; b++)
-						for (int i = lane; i < out_n; i += 64) softmax[(u0 + b) * out_n + i] = o[b * lo.img + i];
+						for (int i = lane; i < out_n; i += 64) softmax[(u0 + b) * out_n + i] = o[b * R.o_img + i];
 				if (argmax && out_n <= 64)
 				{
 					/* first maximum: the largest (value, 63 - index) pair of the wave */
 					for (int b = 0; b < nb; b++)
 					{
-						const int key = lane < out_n ? (((int)o[b * lo.img + lane] + 128) << 6) | (63 - lane) : -1;
+						const int key = lane < out_n ? (((int)o[b * R.o_img + lane] + 128) << 6) | (63 - lane) : -1;
 						const int best = 63 - (emm_wave_max(key) & 63);
 						if (lane == 0) argmax[u0 + b] = best;
 					}
 				}
 				else if (argmax && lane < nb)
 				{
-					const lds8 *v = o + lane * lo.img;
+					const lds8 *v = o + lane * R.o_img;
 					int best = 0, mx = -129;
 					for (int i = 0; i < out_n; i++)
 						if (v[i] > mx) { mx = v[i]; best = i; }

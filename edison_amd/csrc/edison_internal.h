@@ -264,6 +264,25 @@ typedef struct {
 	int32_t pad_[3];
 } ed_mm_layer_t;
 
+/* What one pass of the kernel's layer loop needs, worked out on the host: one 128-byte record per layer that the wave
+ * reads with two scalar loads (the kernel used to derive it from ed_net_layer_t + ed_mm_layer_t + the consumer's record:
+ * a chain of dependent scalar loads and ~100 scalar instructions per layer and input). */
+enum { ED_RUN_SKIP = 0, ED_RUN_MM = 1, ED_RUN_POOL4 = 2, ED_RUN_POOL1 = 3, ED_RUN_SOFTMAX = 4 };
+typedef struct {
+	int32_t kind;               /* ED_RUN_*                                                                            */
+	int32_t zero_border;        /* 1: the consumer wants a zero border: clear the output images first                  */
+	int32_t in_img, o_img;      /* bytes per image: this layer's input layout, the layout it stores into               */
+	int32_t o_origin, o_row, oc_pitch; /* output pixel (y, x) goes to o_origin + y * o_row + x * oc_pitch              */
+	int32_t li_out;             /* the layer whose output this pass stores (the fused MaxPool's when there is one)      */
+	int32_t expand, x_img, rec_per_img, xtab_off; /* expansion: bytes per expanded image, records per image, table      */
+	int32_t pitch_x, pitch_y, sh, ph, pw; /* B addressing; rows per output row; fused pooling window (1x1: none)        */
+	int32_t n_ks, n_rt, frag_off, seed_off, koff_off, col_off;
+	int32_t pix_per_img, col_w; /* stored pixels per image, per row                                                    */
+	int32_t out_c, rs, lo_clamp;
+	int32_t in_n;               /* Softmax: classes                                                                    */
+	int32_t pad_[5];
+} ed_mm_run_t;
+
 typedef struct {
 	int32_t ok;                 /* 0: this graph stays on the layer-by-layer kernel (why: the loader's error text)     */
 	int32_t batch;              /* inputs a WAVEFRONT takes through the layer list at a time                          */
@@ -280,6 +299,7 @@ typedef struct {
 	int32_t n_intab;            /* entries of intab[] in use: in_n, or 0 (the kernel divides)                          */
 	int32_t pad_;
 	ed_mm_layer_t L[ED_NET_MAX_LAYERS];
+	ed_mm_run_t R[ED_NET_MAX_LAYERS];
 	int32_t koff[ED_MM_MAX_KOFF];
 	/* per stored pixel (y, x) of a matrix-core layer, in pixel order: byte offset of its first window's first chunk in
 	 * the layer's B source, and of its output pixel in the consumer's layout (what the kernel would otherwise work out

@@ -265,6 +265,22 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 			bad |= M->expand ? (batch * up16(M->x_img) > mm->x_bytes + 0) : 0;
 		}
 		if (bad) { free(fb); free(sb); return EDISON_OK; } /* mm->ok stays 0 */
+		/* the run record */
+		ed_mm_run_t *R = &mm->R[i];
+		const int dense = L->type == ED_NET_DENSE;
+		R->kind = M->mm ? ED_RUN_MM : (L->type == ED_NET_POOL ? ((L->in_c & 3) == 0 ? ED_RUN_POOL4 : ED_RUN_POOL1) : ED_RUN_SOFTMAX);
+		R->zero_border = ohp != st_h || owp != st_w;
+		R->in_img = M->in_img; R->o_img = oimg;
+		R->oc_pitch = L->out_c; R->o_origin = (opy * owp + opx) * L->out_c; R->o_row = owp * L->out_c;
+		R->li_out = fused ? i + 1 : i;
+		R->expand = M->expand; R->x_img = M->x_img; R->xtab_off = M->xtab_off;
+		R->rec_per_img = M->mm ? (dense ? 1 : M->in_hp) * (dense ? 1 : L->out_w) * M->cpr : 0;
+		R->pitch_x = M->pitch_x; R->pitch_y = M->pitch_y; R->sh = dense ? 1 : L->sh;
+		R->ph = fused ? M->pool_h : 1; R->pw = fused ? M->pool_w : 1;
+		R->n_ks = M->n_ks; R->n_rt = M->n_rt; R->frag_off = M->frag_off; R->seed_off = M->seed_off; R->koff_off = M->koff_off; R->col_off = M->col_off;
+		R->pix_per_img = dense ? 1 : st_h * st_w; R->col_w = dense ? 1 : st_w;
+		R->out_c = L->out_c; R->rs = L->rs; R->lo_clamp = L->relu ? 0 : -128;
+		R->in_n = L->in_n;
 	}
 	*frag = fb;
 	*seeds = sb;
