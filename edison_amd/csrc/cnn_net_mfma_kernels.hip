@@ -33,6 +33,11 @@ extern "C" void ed_set_net_debug_buffer(void *p) { (void)hipMemcpyToSymbol(HIP_S
 #else
 #define EMM_ST(i)
 #endif
+/* timing-only ablations for A/B work (tools/lab; results are WRONG when non-zero): 1 no epilogue, 2 no k-loop (the
+ * accumulators stay the seeds), 4 no expansion, 8 no input load, 16 no softmax / outputs */
+#ifndef EMM_SKIP
+#define EMM_SKIP 0
+#endif
 #define EMM_MAX_THREADS 768 /* 12 waves: 168 VGPRs each (four accumulator tiles + the pipeline's operands need ~150) */
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -193,7 +198,7 @@ __device__ __forceinline__ void emm_chain(const lds8 *(&fl)[U], const int8_t *(&
 	for (int u = 0; u < U; u++) a[u] = emm_load_a<FRAG_LDS>(fl[u], fg[u], 0);
 #pragma unroll
 	for (int c = 0; c < NC; c++) b[c] = EMM_LD128(bw[c] + k_cur);
-	for (int s = 0; s < n_ks; s++)
+	for (int s = 0; s < ((EMM_SKIP & 2) ? 0 : n_ks); s++)
 	{
 		const int s1 = s + 1 < n_ks ? s + 1 : last, s2 = s + 2 < n_ks ? s + 2 : last;
 		const int k3 = EMM_LD32(kp + 8 * s2);
@@ -318,7 +323,7 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 #pragma unroll
 			for (int g = 0; g < 4; g++)
 			{
-				if (32 * rts[k] + 8 * g >= A.out_c) continue; /* uniform */
+				if ((EMM_SKIP & 1) || 32 * rts[k] + 8 * g >= A.out_c) continue; /* uniform */
 				const int r0 = 32 * rts[k] + 8 * g + 4 * h;
 				const int v0 = emm_med3(acc[k][4 * g] >> A.rs, A.lo_clamp, 127), v1 = emm_med3(acc[k][4 * g + 1] >> A.rs, A.lo_clamp, 127);
 				const int v2 = emm_med3(acc[k][4 * g + 2] >> A.rs, A.lo_clamp, 127), v3 = emm_med3(acc[k][4 * g + 3] >> A.rs, A.lo_clamp, 127);
@@ -426,7 +431,8 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 				emm_zero(bufs[0], batch * l0.img, lane);
 				emm_sync();
 			}
-			if (prefetch)
+			if (EMM_SKIP & 8) {}
+			else if (prefetch)
 			{
 				uint32_t v[EMM_PRE];
 #pragma unroll
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 			{
 				emm_mm_args A;
 				A.bsrc = a; A.img = R.in_img;
-				if (R.expand)
+				if (R.expand && !(EMM_SKIP & 4))
 				{
 					/* one aligned record of 16 * cpr bytes per (input row, output x): the kw * C_in bytes under a kernel row.
 					 * 16 bytes from an arbitrary byte offset: five aligned dwords around them, funnel-shifted (v_alignbit), the
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 			}
 			else /* softmax: arm_softmax_q7.c:215-260 */
 			{
-				const int in_n = R.in_n;
+				const int in_n = (EMM_SKIP & 16) ? 0 : R.in_n;
 				if (in_n <= 64)
 				{
 					/* one lane per class, one image after the other: maximum and sum are wave reductions, the division
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 			emm_sync();
 			/* outputs (the layouts of the logits layer's and the last layer's outputs are compact); what this pass stored is
 			 * the output of layer li_out: the fused MaxPool's when there is one */
-			const int li_out = R.li_out;
+			const int li_out = (EMM_SKIP & 16) ? -1 : R.li_out;
 			if (li_out == logits_layer && logits)
 				for (int b = 0; b < nb; b++)
 					for (int i = lane; i < out_n; i += 64) logits[(u0 + b) * out_n + i] = o[b * R.o_img + i];
