@@ -332,12 +332,19 @@ def main():
 
     def mfcc_step(i):
         ctx.mfcc_t(bufs[i % len(bufs)], nf, 1024, _lib.MFCC_B, 13, out=out)
+    # first, on the board as it comes: W warm-up + K timed steps and nothing else (the review's point: the settle phase
+    # below is more than the contract asks for). Reported beside the headline as `as_specified`.
+    cold_ms, cold_ev_ms = timed_region(mfcc_step, args.steps, args.warmup, world, 0.0)
     wall_ms, ev_ms = timed_region(mfcc_step, args.steps, args.warmup, world, args.settle_ms)
     frames_per_s = world * nf / (wall_ms * 1e-3)
     ach = MFCC_BYTES_PER_FRAME * nf / (ev_ms * 1e-3) / 1e9
     roofline = dict(bound="hbm", kernel="ed_mfcc2_kernel<true, true, 2, 5>", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, bytes_per_unit=MFCC_BYTES_PER_FRAME,
                     units_per_launch=nf, kernel_ms=round(ev_ms, 4))
+    as_specified = dict(value=round(world * nf / (cold_ms * 1e-3), 1), unit="frames/s", ms_per_step=round(cold_ms, 4), kernel_ms=round(cold_ev_ms, 4),
+                        roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (cold_ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        what="the same workload measured FIRST with W warm-up + K timed steps only (no settle phase): with few steps this is the "
+                             "power-management transient of a board that was idle, DESIGN.md section 5")
     checksum = float(out.double().sum().item())
 
     # ------------------------------------------------------------------ variant A (log-mel, mfcc_utils.mfcc), same batch
@@ -514,6 +521,7 @@ def main():
                     config=dict(workload="mfcc_batch_%dx1024_int16_per_gpu_variantB_13coef" % nf, global_batch=world * nf,
                                 frame_len=1024, parallelism="dp%d" % world, rotate_buffers=args.rotate, settle_ms=args.settle_ms),
                     roofline=roofline, device=info["name"], checksum=checksum)
+        line["as_specified"] = as_specified
         line["mfcc_variant_a"] = variant_a
         if variant_d is not None:
             line["mfcc_variant_d"] = variant_d
