@@ -383,6 +383,9 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 #define ED2_TW_LDS 0      /* 1: pass-1/2 twiddles read from LDS (14 ds_read_b64 per pair) instead of 28 registers */
 #endif
 #define ED2_TWTAB_FLOATS (ED2_TW_LDS ? 2 * 7 * 64 * 2 : 0)
+#ifndef ED2_LANE0_BRANCH
+#define ED2_LANE0_BRANCH 1
+#endif
 #ifndef ED2_TABLES_FIRST
 #define ED2_TABLES_FIRST 0 /* 1: prologue issues the table loads before the first pair's sample loads */
 #endif
@@ -694,19 +697,36 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		ED2_ST(5)
 		/* ---- 3. real-FFT split (see ed_mfcc_kernel); the partner values come per frame through ds_bpermute */
 		ed_f2 slo[4], shi[4];
+		ed_f2 pzr_[4], pzi_[4];
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 		{
-			ed_f2 pzr, pzi;
 			if (!(ED2_SKIP & 8))
 			{
-				pzr.x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].x)));
-				pzr.y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].y)));
-				pzi.x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].x)));
-				pzi.y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].y)));
+				pzr_[m].x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].x)));
+				pzr_[m].y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].y)));
+				pzi_[m].x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].x)));
+				pzi_[m].y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].y)));
 			}
-			if (ED2_SKIP & 8) { pzr = re[7 - m]; pzi = im[7 - m]; }
+			if (ED2_SKIP & 8) { pzr_[m] = re[7 - m]; pzi_[m] = im[7 - m]; }
+		}
+#if ED2_LANE0_BRANCH
+		/* lane 0 is its own partner, one register further up: ONE exec-masked block of 16 v_mov_b32 (2.5 cycles each)
+		 * instead of 16 v_cndmask_b32_e64 (4.4 each) -- the empty asm keeps the compiler from if-converting it back */
+		if (lane == 0)
+		{
+			asm volatile("");
+#pragma unroll
+			for (int m = 0; m < 4; m++) { pzr_[m] = re[(8 - m) & 7]; pzi_[m] = im[(8 - m) & 7]; }
+		}
+#endif
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+		{
+			ed_f2 pzr = pzr_[m], pzi = pzi_[m];
+#if !ED2_LANE0_BRANCH
 			if (lane == 0) { pzr = re[(8 - m) & 7]; pzi = im[(8 - m) & 7]; }
+#endif
 			if (ED2_SKIP & 64) { slo[m] = re[m] + pzr; shi[m] = im[m] + pzi; continue; }
 			const float2 tw = tpl[64 * m + lane];
 			const ed_f2 twx = ed_splat(tw.x), twy = ed_splat(tw.y);
