@@ -13,8 +13,9 @@
  * rows i..i+30 of one [30 + chunk][13] int8 buffer, which the CNN kernel reads with a 13-byte "utterance" stride.
  *
  * The device operations of a push (MFCC kernel, CNN kernel, output filter, history shift) are captured ONCE into a
- * hipGraph and replayed per push. The net input starts as zeros like the firmware's static netInput buffer, the
- * filter state as zeros like netOutFilt (app.c:299-300).
+ * hipGraph and replayed per push -- except for host-pointer pushes of a few frames (the microphone case), which run
+ * against host-mapped buffers with two or three direct kernel launches and no copies (see the struct). The net input
+ * starts as zeros like the firmware's static netInput buffer, the filter state as zeros like netOutFilt (app.c:299-300).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -50,12 +51,26 @@ struct edison_stream
 	hipGraph_t graph_h;
 	hipGraphExec_t exec_h;
 	int last_push_staged;
+	/* host-pointer pushes of a few frames (the microphone case, one frame per push): NO copy nodes at all. The audio ring,
+	 * the feature rows and the outputs live in pinned host memory that the kernels read and write over the bus (2 KB of
+	 * samples, 403 feature bytes, 24 bytes of results per frame); the host shifts the ring and the rows itself. The device
+	 * work is MFCC -> CNN (-> filter), launched DIRECTLY: measured on MI355X (tools/lab/lat_parts.py, bench.py streaming),
+	 * an empty kernel's launch + synchronize is 16 us, the staged six-node graph 43 us, the same two kernels as a graph
+	 * 39 us, launched directly 32 us -- hipGraphLaunch costs more than two plain launches. */
+	int16_t *m_audio;     /* [tail + chunk*hop], pinned + mapped */
+	int8_t *m_feat;       /* [(30 + chunk) * 13]                 */
+	unsigned char *m_out; /* the d_out block's layout            */
+	int mapped;           /* 1: this stream has the host-mapped path */
+	const int16_t *md_audio; int8_t *md_feat; unsigned char *md_out; /* their device addresses */
+	int state_host;       /* 1: the newest tail samples / 30 feature rows are in m_audio / m_feat, 0: in d_audio / d_feat */
+	int last_push_mapped;
 	int64_t frames_seen;
 	int tables_epoch;     /* likewise for the MFCC tables (edison_mfcc_configure) */
 	int model_epoch;      /* the graphs hold the device addresses of the model that was loaded when they were captured */
 };
 
 #define ED_STREAM_STAGED_MAX_BYTES (1u << 20) /* chunks above 1 MB of samples go through plain async copies */
+#define ED_STREAM_MAPPED_MAX_BYTES (16u << 10) /* pushes of at most 16 KB of samples run against host-mapped buffers */
 
 __global__ void ed_stream_shift_kernel(int16_t *audio, int tail, int new_samples, int8_t *feat, int chunk)
 {
@@ -115,6 +130,7 @@ __global__ __launch_bounds__(256) void ed_stream_filter_kernel(const int8_t *sof
 }
 
 static int enqueue_push_on_ctx_stream(edison_stream *s);
+static int enqueue_mapped_push(edison_stream *s);
 
 /* enqueue the device operations of a push on the stream's private hipStream */
 static int enqueue_push(edison_stream *s)
@@ -147,6 +163,28 @@ static int enqueue_push_on_ctx_stream(edison_stream *s)
 	return hipGetLastError() == hipSuccess ? EDISON_OK : ed_set_err(ctx, EDISON_E_RUNTIME, "stream: shift launch failed");
 }
 
+/* the device work of a push against the host-mapped buffers, on the stream's private hipStream */
+static int enqueue_mapped_push(edison_stream *s)
+{
+	edison_ctx *ctx = s->ctx;
+	hipStream_t saved = ctx->stream;
+	ctx->stream = s->own;
+	unsigned char *o8 = s->md_out;
+	int r = ed_ctx_mfcc_launch(ctx, s->md_audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
+	                           s->md_feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
+	if (r == EDISON_OK)
+		r = ed_ctx_kws_cnn_launch(ctx, s->md_feat, s->chunk, EDISON_NUM_MFCC, (int8_t *)o8, (int8_t *)(o8 + s->off_soft), (int32_t *)(o8 + s->off_argmax));
+	if (r == EDISON_OK && s->filter)
+	{
+		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, ctx->stream, (const int8_t *)(o8 + s->off_soft), s->chunk, s->alpha,
+		                   s->one_minus_alpha, s->threshold, s->d_filt_state, (float *)(o8 + s->off_filt), (int32_t *)(o8 + s->off_likely),
+		                   (int32_t *)(o8 + s->off_spotted));
+		if (hipGetLastError() != hipSuccess) r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: filter launch failed");
+	}
+	ctx->stream = saved;
+	return r;
+}
+
 extern "C" void edison_stream_destroy(edison_stream *s)
 {
 	if (!s) return;
@@ -155,6 +193,9 @@ extern "C" void edison_stream_destroy(edison_stream *s)
 	if (s->graph) (void)hipGraphDestroy(s->graph);
 	if (s->exec_h) (void)hipGraphExecDestroy(s->exec_h);
 	if (s->graph_h) (void)hipGraphDestroy(s->graph_h);
+	if (s->m_audio) (void)hipHostFree(s->m_audio);
+	if (s->m_feat) (void)hipHostFree(s->m_feat);
+	if (s->m_out) (void)hipHostFree(s->m_out);
 	if (s->h_in) (void)hipHostFree(s->h_in);
 	if (s->h_out) (void)hipHostFree(s->h_out);
 	if (s->d_audio) (void)hipFree(s->d_audio);
@@ -175,7 +216,23 @@ extern "C" int edison_stream_reset(edison_stream *s)
 	ED_HIP(ctx, hipMemsetAsync(s->d_feat, 0, (size_t)(30 + s->chunk) * EDISON_NUM_MFCC, s->own));
 	if (s->filter) ED_HIP(ctx, hipMemsetAsync(s->d_filt_state, 0, sizeof(float) * EDISON_NET_OUT, s->own));
 	ED_HIP(ctx, hipStreamSynchronize(s->own));
+	if (s->m_audio) memset(s->m_audio, 0, sizeof(int16_t) * (size_t)(s->tail + s->chunk * s->hop));
+	if (s->m_feat) memset(s->m_feat, 0, (size_t)(30 + s->chunk) * EDISON_NUM_MFCC);
 	s->frames_seen = 0;
+	return EDISON_OK;
+}
+
+/* Moves the stream's state (newest tail samples, newest 30 feature rows: always at the FRONT of their buffers between
+ * pushes) to where the next push wants it. Only a caller that alternates host and device pushes pays for this. */
+static int stream_state_to(edison_stream *s, int host)
+{
+	edison_ctx *ctx = s->ctx;
+	if (!s->m_audio || s->state_host == host) return EDISON_OK;
+	const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+	if (s->tail) ED_HIP(ctx, hipMemcpyAsync(host ? (void *)s->m_audio : (void *)s->d_audio, host ? (void *)s->d_audio : (void *)s->m_audio, sizeof(int16_t) * (size_t)s->tail, kind, s->own));
+	ED_HIP(ctx, hipMemcpyAsync(host ? (void *)s->m_feat : (void *)s->d_feat, host ? (void *)s->d_feat : (void *)s->m_feat, 30 * EDISON_NUM_MFCC, kind, s->own));
+	ED_HIP(ctx, hipStreamSynchronize(s->own));
+	s->state_host = host;
 	return EDISON_OK;
 }
 
@@ -292,6 +349,25 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 		else
 			r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: pinned staging buffers / capture unavailable");
 	}
+	if (r == EDISON_OK && in_bytes <= ED_STREAM_MAPPED_MAX_BYTES)
+	{
+		const size_t audio_bytes = sizeof(int16_t) * (size_t)(s->tail + s->chunk * s->hop) + 16, feat_bytes = (size_t)(30 + s->chunk) * EDISON_NUM_MFCC + 16;
+		e = hipHostMalloc((void **)&s->m_audio, audio_bytes, hipHostMallocMapped);
+		if (e == hipSuccess) e = hipHostMalloc((void **)&s->m_feat, feat_bytes, hipHostMallocMapped);
+		if (e == hipSuccess) e = hipHostMalloc((void **)&s->m_out, s->h_out_bytes + 16, hipHostMallocMapped);
+		void *da = NULL, *df = NULL, *dout = NULL;
+		if (e == hipSuccess) e = hipHostGetDevicePointer(&da, s->m_audio, 0);
+		if (e == hipSuccess) e = hipHostGetDevicePointer(&df, s->m_feat, 0);
+		if (e == hipSuccess) e = hipHostGetDevicePointer(&dout, s->m_out, 0);
+		if (e == hipSuccess)
+		{
+			memset(s->m_audio, 0, audio_bytes); memset(s->m_feat, 0, feat_bytes); memset(s->m_out, 0, s->h_out_bytes + 16);
+			s->md_audio = (const int16_t *)da; s->md_feat = (int8_t *)df; s->md_out = (unsigned char *)dout;
+			s->mapped = 1;
+		}
+		else
+			r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: host-mapped buffers unavailable");
+	}
 	if (r != EDISON_OK) { edison_stream_destroy(s); return r; }
 	*out = s;
 	return EDISON_OK;
@@ -316,6 +392,8 @@ extern "C" int edison_stream_push_dev(edison_stream *s, const int16_t *samples, 
 	if (s->model_epoch != ctx->model_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: the model was reloaded after this stream was created; create a new stream");
 	if (s->tables_epoch != ctx->tables_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: edison_mfcc_configure was called after this stream was created; create a new stream");
 	const size_t nnew = (size_t)s->chunk * s->hop;
+	{ const int rs = stream_state_to(s, 0); if (rs != EDISON_OK) return rs; }
+	s->last_push_mapped = 0;
 	/* the caller produced `samples` on the context's stream: the private stream waits for that point ... */
 	ED_HIP(ctx, hipEventRecord(s->ev_in, ctx->stream));
 	ED_HIP(ctx, hipStreamWaitEvent(s->own, s->ev_in, 0));
@@ -340,6 +418,27 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 	if (s->model_epoch != ctx->model_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: the model was reloaded after this stream was created; create a new stream");
 	if (s->tables_epoch != ctx->tables_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: edison_mfcc_configure was called after this stream was created; create a new stream");
 	const size_t nnew = (size_t)s->chunk * s->hop;
+	static const int no_mapped = getenv("EDISON_STREAM_NO_MAPPED") ? atoi(getenv("EDISON_STREAM_NO_MAPPED")) : 0; /* A/B knob: the staged graph */
+	if (s->mapped && !no_mapped)
+	{
+		const size_t c = (size_t)s->chunk;
+		{ const int rs = stream_state_to(s, 1); if (rs != EDISON_OK) return rs; }
+		memcpy(s->m_audio + s->tail, samples, nnew * sizeof(int16_t));
+		{ const int rd = enqueue_mapped_push(s); if (rd != EDISON_OK) return rd; }
+		ED_HIP(ctx, hipStreamSynchronize(s->own));
+		if (logits) memcpy(logits, s->m_out, c * EDISON_NET_OUT);
+		if (softmax) memcpy(softmax, s->m_out + s->off_soft, c * EDISON_NET_OUT);
+		if (argmax) memcpy(argmax, s->m_out + s->off_argmax, c * sizeof(int32_t));
+		/* what the shift kernel does on the device path: the newest tail samples and 30 rows to the front */
+		if (s->tail) memmove(s->m_audio, s->m_audio + nnew, sizeof(int16_t) * (size_t)s->tail);
+		memmove(s->m_feat, s->m_feat + c * EDISON_NUM_MFCC, 30 * EDISON_NUM_MFCC);
+		s->last_push_staged = 0;
+		s->last_push_mapped = 1;
+		s->frames_seen += s->chunk;
+		return EDISON_OK;
+	}
+	{ const int rs = stream_state_to(s, 0); if (rs != EDISON_OK) return rs; }
+	s->last_push_mapped = 0;
 	if (s->exec_h)
 	{
 		const size_t c = (size_t)s->chunk;
@@ -371,6 +470,24 @@ static int stream_filter_out(edison_stream *s, float *filt, int32_t *likely, int
 	if (!s) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
 	if (!s->filter) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: created without the output filter");
+	if (s->last_push_mapped)
+	{
+		/* the mapped push wrote them into pinned host memory */
+		const size_t c = (size_t)s->chunk;
+		if (host)
+		{
+			if (filt) memcpy(filt, s->m_out + s->off_filt, c * EDISON_NET_OUT * sizeof(float));
+			if (likely) memcpy(likely, s->m_out + s->off_likely, c * sizeof(int32_t));
+			if (spotted) memcpy(spotted, s->m_out + s->off_spotted, c * sizeof(int32_t));
+			return EDISON_OK;
+		}
+		if (filt) ED_HIP(ctx, hipMemcpyAsync(filt, s->m_out + s->off_filt, c * EDISON_NET_OUT * sizeof(float), hipMemcpyHostToDevice, s->own));
+		if (likely) ED_HIP(ctx, hipMemcpyAsync(likely, s->m_out + s->off_likely, c * sizeof(int32_t), hipMemcpyHostToDevice, s->own));
+		if (spotted) ED_HIP(ctx, hipMemcpyAsync(spotted, s->m_out + s->off_spotted, c * sizeof(int32_t), hipMemcpyHostToDevice, s->own));
+		ED_HIP(ctx, hipEventRecord(s->ev_out, s->own));
+		ED_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_out, 0));
+		return EDISON_OK;
+	}
 	if (host && s->last_push_staged)
 	{
 		/* the staged push already brought them to the host */

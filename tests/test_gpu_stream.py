@@ -153,3 +153,37 @@ def test_stream_refuses_pushes_after_reconfigure(oracle_mod, oracle_model):
         st2.close()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("hop,chunk,filt", [(512, 1, True), (1024, 3, False)])
+def test_stream_host_and_device_pushes_share_one_state(ctx, hop, chunk, filt):
+    """Host-pointer pushes of a few frames run against host-mapped buffers (the history lives in pinned host memory),
+    device-pointer pushes against device buffers: a caller that alternates them must get what a stream fed by host
+    pushes alone answers -- the history moves with the caller (stream_state_to)."""
+    import torch
+    from edison_amd.stream import Stream
+    rng = np.random.default_rng(99 + chunk)
+    n_push = 10
+    audio = np.clip(rng.normal(0, 2500, n_push * chunk * hop), -32768, 32767).astype(np.int16)
+    a = Stream(ctx, hop=hop, chunk_frames=chunk, output_filter=filt)
+    b = Stream(ctx, hop=hop, chunk_frames=chunk, output_filter=filt)
+    dev = torch.device("cuda", 0)
+    for i in range(n_push):
+        x = audio[i * chunk * hop:(i + 1) * chunk * hop]
+        want = a.push(x)
+        if i % 3 == 1:                                 # every third push through the device entry point
+            soft = torch.zeros((chunk, 10), dtype=torch.int8, device=dev)
+            am = torch.zeros((chunk,), dtype=torch.int32, device=dev)
+            fl = torch.zeros((chunk, 10), dtype=torch.float32, device=dev) if filt else None
+            b.push_t(torch.from_numpy(x.copy()).to(dev), softmax=soft, argmax=am, filtered=fl)
+            torch.cuda.synchronize()
+            assert np.array_equal(soft.cpu().numpy(), want["softmax"]) and np.array_equal(am.cpu().numpy(), want["argmax"]), i
+            if filt:
+                assert np.array_equal(fl.cpu().numpy().view(np.uint32), want["filtered"].view(np.uint32)), i
+        else:
+            got = b.push(x)
+            assert np.array_equal(got["softmax"], want["softmax"]) and np.array_equal(got["argmax"], want["argmax"]), i
+            if filt:
+                assert np.array_equal(got["filtered"].view(np.uint32), want["filtered"].view(np.uint32)), i
+    a.close()
+    b.close()
