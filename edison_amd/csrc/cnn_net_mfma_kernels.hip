@@ -242,6 +242,7 @@ struct emm_mm_args
 	int n_ks, n_rt, n_cols, pix_per_img, col_w;
 	int pitch_x, pitch_y, sh, ph, pw;
 	int o_origin, o_row, oc_pitch, out_c, rs, lo_clamp;
+	int small;              /* 16 x 16 x 64 tiles (n_ks / n_rt count those) */
 #if EMM_STAMP
 	unsigned long long *st_, *tl_p;
 #endif
@@ -344,10 +345,100 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 	}
 }
 
+/*
+ * Layers with at most 16 columns per wave and no fused pooling (model_net_mm.c: `small`): v_mfma_i32_16x16x64_i8 tiles --
+ * 16 output channels x 16 columns, four 16-byte chunks per k-step (lane l: row / column l & 15, chunk l >> 4). A 32 x 32
+ * tile there would be mostly padding that the epilogue requantises all the same (conv4 of kws_conv: 3 live columns, the
+ * dense layer: 1); here a tile is 4 accumulator registers instead of 16 and the k-loop half as long. Up to four row
+ * tiles run at once and share the B fragment of a k-step; same one-deep pipeline as emm_chain.
+ */
+template <bool FRAG_LDS>
+__device__ __forceinline__ void emm_layer_small(const emm_mm_args &A, int lane)
+{
+	constexpr int U = 4;
+	const int col = lane & 15, kq = lane >> 4;
+	const bool live = col < A.n_cols;
+	const int qq = live ? col : A.n_cols - 1;
+	int b = 0, pp = qq;
+	if (A.n_cols > A.pix_per_img) emm_divmod(qq, A.pix_per_img, __builtin_amdgcn_rcpf((float)A.pix_per_img), b, pp);
+	int boff, ooff;
+	if (A.coltab)
+	{
+		boff = EMM_LD32(A.coltab + 8 * pp); ooff = EMM_LD32(A.coltab + 8 * pp + 4);
+	}
+	else
+	{
+		int y, x;
+		emm_divmod(pp, A.col_w, __builtin_amdgcn_rcpf((float)A.col_w), y, x);
+		boff = (y * A.sh) * A.pitch_y + x * A.pitch_x;
+		ooff = A.o_origin + y * A.o_row + x * A.oc_pitch;
+	}
+	const lds8 *bp = A.bsrc + b * A.img + boff;
+	lds8 *op = A.o + b * A.o_img + ooff;
+	const lds8 *kp = A.koff + 4 * kq;
+	const int n_ks = A.n_ks, last = n_ks - 1;
+	for (int rt0 = 0; rt0 < A.n_rt; rt0 += U)
+	{
+		v4i aw[U], a[U];
+		int rts[U];
+		const lds8 *fl[U];
+		const int8_t *fg[U];
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			rts[u] = rt0 + u < A.n_rt ? rt0 + u : A.n_rt - 1; /* spare slots repeat the last tile and store nothing */
+			aw[u] = EMM_LD128(A.seeds + 4 * (16 * rts[u] + 4 * kq));
+			fl[u] = A.fragl + rts[u] * n_ks * 1024 + lane * 16;
+			fg[u] = A.fragg + (size_t)rts[u] * n_ks * 1024 + lane * 16;
+			a[u] = emm_load_a<FRAG_LDS>(fl[u], fg[u], 0);
+		}
+		int k_cur = EMM_LD32(kp), k_nxt = EMM_LD32(kp + 16 * (last < 1 ? last : 1));
+		v4i bq = EMM_LD128(bp + k_cur);
+		for (int s = 0; s < ((EMM_SKIP & 2) ? 0 : n_ks); s++)
+		{
+			const int s1 = s + 1 < n_ks ? s + 1 : last, s2 = s + 2 < n_ks ? s + 2 : last;
+			const int k3 = EMM_LD32(kp + 16 * s2);
+			v4i an[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) an[u] = emm_load_a<FRAG_LDS>(fl[u], fg[u], s1);
+			const v4i bn = EMM_LD128(bp + k_nxt);
+#pragma unroll
+			for (int u = 0; u < U; u++) aw[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[u], bq, aw[u], 0, 0, 0);
+			k_nxt = k3; bq = bn;
+#pragma unroll
+			for (int u = 0; u < U; u++) a[u] = an[u];
+			asm volatile("" : "+v"(k_nxt), "+v"(bq));
+			emm_keep(a);
+		}
+		/* lane (column, kq) holds rows 16 rt + 4 kq .. +3 */
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int r0 = 16 * rts[u] + 4 * kq;
+			if ((EMM_SKIP & 1) || rt0 + u >= A.n_rt) continue; /* uniform */
+			const int v0 = emm_med3(aw[u].x >> A.rs, A.lo_clamp, 127), v1 = emm_med3(aw[u].y >> A.rs, A.lo_clamp, 127);
+			const int v2 = emm_med3(aw[u].z >> A.rs, A.lo_clamp, 127), v3 = emm_med3(aw[u].w >> A.rs, A.lo_clamp, 127);
+			if ((A.out_c & 3) == 0)
+			{
+				const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x0c0c0400u), p23 = __builtin_amdgcn_perm((uint32_t)v3, (uint32_t)v2, 0x0c0c0400u);
+				if (live && r0 < A.out_c) EMM_ST32(op + r0, __builtin_amdgcn_perm(p23, p01, 0x05040100u));
+			}
+			else if (live)
+			{
+				if (r0 < A.out_c) op[r0] = (int8_t)v0;
+				if (r0 + 1 < A.out_c) op[r0 + 1] = (int8_t)v1;
+				if (r0 + 2 < A.out_c) op[r0 + 2] = (int8_t)v2;
+				if (r0 + 3 < A.out_c) op[r0 + 3] = (int8_t)v3;
+			}
+		}
+	}
+}
+
 /* NW windows per unit (1, 2 or 4); two units at once when the layer has them and four accumulator tiles hold them */
 template <bool FRAG_LDS>
 __device__ __forceinline__ void emm_layer_dispatch(const emm_mm_args &A, int lane)
 {
+	if (A.small) { emm_layer_small<FRAG_LDS>(A, lane); return; }
 	const int nwin = A.ph * A.pw, n_units = A.n_rt * ((A.n_cols + 31) >> 5);
 	if (nwin == 1)
 	{
@@ -567,6 +658,7 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 				A.n_cols = nb * R.pix_per_img;
 				A.pitch_x = R.pitch_x; A.pitch_y = R.pitch_y; A.sh = R.sh;
 				A.ph = R.ph; A.pw = R.pw;
+				A.small = R.small;
 				A.o_origin = R.o_origin; A.o_row = R.o_row; A.oc_pitch = R.oc_pitch; A.out_c = R.out_c; A.rs = R.rs; A.lo_clamp = R.lo_clamp;
 #if EMM_STAMP
 				A.st_ = stamp_; A.tl_p = &tl_;

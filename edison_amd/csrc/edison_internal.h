@@ -261,7 +261,9 @@ typedef struct {
 	int32_t skip;               /* 1: this MaxPool is fused into the layer in front of it                              */
 	int32_t col_off;            /* >= 0: index of this layer's column table in coltab[] (pairs), -1: the kernel divides    */
 	int32_t xtab_off;           /* >= 0: index of this layer's expansion table in xtab[] (pairs), -1: the kernel divides   */
-	int32_t pad_[3];
+	int32_t small;              /* 1: at most 16 columns per wave and nothing fused: v_mfma_i32_16x16x64_i8 tiles (16 rows x
+	                             * 16 columns, four 16-byte chunks per k-step); n_ks16 / n_rt16 count those                */
+	int32_t n_ks16, n_rt16;
 } ed_mm_layer_t;
 
 /* What one pass of the kernel's layer loop needs, worked out on the host: one 128-byte record per layer that the wave
@@ -280,7 +282,8 @@ typedef struct {
 	int32_t pix_per_img, col_w; /* stored pixels per image, per row                                                    */
 	int32_t out_c, rs, lo_clamp;
 	int32_t in_n;               /* Softmax: classes                                                                    */
-	int32_t pad_[5];
+	int32_t small;              /* 1: the 16 x 16 x 64 tiles (n_ks / n_rt then count those)                            */
+	int32_t pad_[4];
 } ed_mm_run_t;
 
 typedef struct {

@@ -72,12 +72,15 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 			M->x_img = 0;
 		}
 		(void)sh;
+		/* the small-tile form of the same layer (chosen in pass 2, once the per-wave batch is known): room for either */
+		M->n_ks16 = (kh * M->cpr + 3) / 4;
+		M->n_rt16 = (L->out_c + 15) / 16;
 		M->frag_off = (int32_t)frag_bytes;
-		frag_bytes += (size_t)M->n_rt * M->n_ks * 1024;
+		frag_bytes += (size_t)imax(M->n_rt * M->n_ks, M->n_rt16 * M->n_ks16) * 1024;
 		M->seed_off = n_seeds;
 		n_seeds += 32 * M->n_rt;
 		M->koff_off = n_koff;
-		n_koff += 2 * M->n_ks;
+		n_koff += imax(2 * M->n_ks, 4 * M->n_ks16);
 		if (n_koff > ED_MM_MAX_KOFF || 2 * M->n_ks > 256 || frag_bytes > ((size_t)64 << 20)) return EDISON_OK; /* mm->ok stays 0 */
 	}
 
@@ -172,7 +175,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 	 * (two ping-pong buffers + the expansion buffer for `batch` inputs); as many waves as fit, at most 12, at least 4; the
 	 * per-wave batch grows (up to 4) only while 8 waves still fit -- independent waves hide each other's latencies, a
 	 * bigger batch only fills the 32-column tiles of small late layers better. */
-	const int lds_cap = 150 * 1024;
+	const int lds_cap = 156 * 1024; /* of the CU's 160 KB */
 	const int tbl = up16(4 * n_koff) + up16(4 * n_seeds) + up16(8 * n_cols) + up16(8 * n_xtab) + up16(2 * mm->n_intab);
 	if (tbl > 24 * 1024) return EDISON_OK;
 	int batch = 0, waves = 0, frag_lds = 0, frag_mode = 0;
@@ -201,6 +204,45 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 	mm->n_seeds = n_seeds;
 	mm->n_koff = n_koff;
 
+	/* layers whose columns (stored pixels x per-wave batch) fit 16 and that fuse no MaxPool run on 16 x 16 x 64 tiles: a
+	 * quarter of the accumulator registers to requantise per tile and half the k-steps, where a 32-column tile would be
+	 * mostly padding (the late layers of a classifier: 3 pixels, 1 pixel). EDISON_NET_NO_SMALL_TILES=1: A/B knob. */
+	{
+		const char *env = getenv("EDISON_NET_NO_SMALL_TILES");
+		const int no_small = env && atoi(env);
+		for (int i = 0; i < n_layers; i++)
+		{
+			const ed_net_layer_t *L = &plan->L[i];
+			ed_mm_layer_t *M = &mm->L[i];
+			if (!M->mm) continue;
+			const int dense = L->type == ED_NET_DENSE;
+			const int pix = dense ? 1 : L->out_h * L->out_w;
+			M->small = !no_small && M->pool_h == 0 && batch * pix <= 16;
+		}
+		/* now that every layer's form is known: the exact fragment layout (pass 1 reserved room for either form), and
+		 * the waves that fit beside it */
+		size_t fexact = 0;
+		for (int i = 0; i < n_layers; i++)
+		{
+			ed_mm_layer_t *M = &mm->L[i];
+			if (!M->mm) continue;
+			M->frag_off = (int32_t)fexact;
+			fexact += (size_t)(M->small ? M->n_rt16 * M->n_ks16 : M->n_rt * M->n_ks) * 1024;
+		}
+		frag_bytes = fexact;
+		if (frag_mode == 2) frag_lds = (int)fexact;
+		{
+			const int64_t per_wave = 2 * (int64_t)batch * max_img + (int64_t)batch * up16(max_x);
+			int64_t w = (lds_cap - tbl - frag_lds) / per_wave;
+			if (w > 12) w = 12;
+			if (w > waves) waves = (int)w;
+		}
+		mm->waves = waves;
+		mm->frag_lds = frag_lds;
+		mm->lds_bytes = tbl + frag_lds + waves * (2 * mm->buf_bytes + mm->x_bytes);
+		mm->frag_bytes = (int32_t)frag_bytes;
+	}
+
 	/* pass 2: fragments, seeds, chunk offsets */
 	int8_t *fb = (int8_t *)calloc(frag_bytes + 16, 1);
 	int32_t *sb = (int32_t *)calloc((size_t)n_seeds + 4, sizeof(int32_t));
@@ -216,6 +258,26 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		const int in_c = dense ? L->in_n : L->in_c, kh = dense ? 1 : L->kh, kw = dense ? 1 : L->kw;
 		const int seg = kw * in_c;
 		const int8_t *w = payload + r.v[9], *bias = payload + r.v[10]; /* OHWI / [out][in]: row o = kh segments of seg bytes */
+		if (M->small)
+		{
+			/* lane l of k-step s of row tile rt: row 16 rt + (l & 15), chunk 4 s + (l >> 4) */
+			for (int rt = 0; rt < M->n_rt16; rt++)
+				for (int s = 0; s < M->n_ks16; s++)
+				{
+					int8_t *f = fb + M->frag_off + ((size_t)rt * M->n_ks16 + s) * 1024;
+					for (int l = 0; l < 64; l++)
+					{
+						const int row = 16 * rt + (l & 15), c = 4 * s + (l >> 4);
+						const int ky = c / M->cpr, jc = c - ky * M->cpr;
+						for (int j = 0; j < 16; j++)
+						{
+							const int q = 16 * jc + j;
+							f[l * 16 + j] = (row < L->out_c && ky < kh && q < seg) ? w[((size_t)row * kh + ky) * seg + q] : 0;
+						}
+					}
+				}
+		}
+		else
 		for (int rt = 0; rt < M->n_rt; rt++)
 			for (int s = 0; s < M->n_ks; s++)
 			{
@@ -233,7 +295,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 			}
 		for (int o = 0; o < L->out_c; o++)
 			sb[M->seed_off + o] = (int32_t)((uint32_t)(int32_t)bias[o] << r.v[6]) + (int32_t)((1u << r.v[7]) >> 1);
-		for (int c = 0; c < 2 * M->n_ks; c++)
+		for (int c = 0; c < (M->small ? 4 * M->n_ks16 : 2 * M->n_ks); c++)
 		{
 			const int ky = c / M->cpr, jc = c - ky * M->cpr;
 			mm->koff[M->koff_off + c] = ky < kh ? ky * M->pitch_y + 16 * jc : 0; /* chunks past the end meet zero weights */
@@ -259,7 +321,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 			const int out_h = dense ? 1 : L->out_h, out_w = dense ? 1 : L->out_w, sh = dense ? 1 : L->sh;
 			const int img = M->expand ? M->x_img : M->in_img;
 			int max_koff = 0;
-			for (int c = 0; c < 2 * M->n_ks; c++) if (mm->koff[M->koff_off + c] > max_koff) max_koff = mm->koff[M->koff_off + c];
+			for (int c = 0; c < (M->small ? 4 * M->n_ks16 : 2 * M->n_ks); c++) if (mm->koff[M->koff_off + c] > max_koff) max_koff = mm->koff[M->koff_off + c];
 			const int64_t last_read = (int64_t)(out_h - 1) * sh * M->pitch_y + (int64_t)(out_w - 1) * M->pitch_x + max_koff + 16;
 			bad |= last_read > img || (M->pitch_x & 15) || (M->pitch_y & 15) || (M->in_img & 15) || (M->x_img & 15);
 			bad |= M->expand ? (batch * up16(M->x_img) > mm->x_bytes + 0) : 0;
@@ -277,7 +339,8 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		R->rec_per_img = M->mm ? (dense ? 1 : M->in_hp) * (dense ? 1 : L->out_w) * M->cpr : 0;
 		R->pitch_x = M->pitch_x; R->pitch_y = M->pitch_y; R->sh = dense ? 1 : L->sh;
 		R->ph = fused ? M->pool_h : 1; R->pw = fused ? M->pool_w : 1;
-		R->n_ks = M->n_ks; R->n_rt = M->n_rt; R->frag_off = M->frag_off; R->seed_off = M->seed_off; R->koff_off = M->koff_off; R->col_off = M->col_off;
+		R->small = M->small;
+		R->n_ks = M->small ? M->n_ks16 : M->n_ks; R->n_rt = M->small ? M->n_rt16 : M->n_rt; R->frag_off = M->frag_off; R->seed_off = M->seed_off; R->koff_off = M->koff_off; R->col_off = M->col_off;
 		R->pix_per_img = dense ? 1 : st_h * st_w; R->col_w = dense ? 1 : st_w;
 		R->out_c = L->out_c; R->rs = L->rs; R->lo_clamp = L->relu ? 0 : -128;
 		R->in_n = L->in_n;
