@@ -153,7 +153,7 @@ def timed_region(step_fn, steps, warmup, world, settle_ms=0.0, settle_chunk=256)
 def stream_bench(ctx, dev):
     """BASELINE configs[4]: 1 h of synthetic 16 kHz audio (57.6 M samples), 1024-sample frames at hop 512
     (50 % overlap) -> 112 499 frames, an inference on the newest 31 frames after every frame.
-    (a) latency: one frame per push (one hipGraph launch each), host-timed push -> result on the host;
+    (a) latency: one frame per push (two direct launches against host-mapped buffers), host-timed push -> result on the host;
     (b) throughput: the whole hour in pushes of 4096 frames."""
     from edison_amd.stream import Stream
     hop, total = 512, 57600000
@@ -189,7 +189,7 @@ def stream_bench(ctx, dev):
     return dict(workload="1 h stream, 16 kHz, frame 1024, hop 512, window 31 frames, inference per frame",
                 latency_us=dict(p50=round(float(np.percentile(lat, 50)), 1), p90=round(float(np.percentile(lat, 90)), 1),
                                 p99=round(float(np.percentile(lat, 99)), 1), pushes=int(lat.size),
-                                what="host push of 512 new samples -> softmax/argmax on the host: MFCC + CNN launched directly against host-mapped buffers, no copy nodes (the staged six-node hipGraph it replaces: 43 us)"),
+                                what="host push of 512 new samples -> softmax/argmax on the host: MFCC + CNN launched directly against host-mapped buffers, no copy nodes, completion by a command-processor write the host spins on (the staged six-node hipGraph it replaces: 43 us)"),
                 throughput=dict(frames_per_s=round(n_push * chunk / dt, 1), inferences_per_s=round(n_push * chunk / dt, 1),
                                 frames=n_push * chunk, chunk_frames=chunk, seconds=round(dt, 4),
                                 realtime_factor=round(n_push * chunk * hop / 16000.0 / dt, 1)))

@@ -61,6 +61,12 @@ struct edison_stream
 	int8_t *m_feat;       /* [(30 + chunk) * 13]                 */
 	unsigned char *m_out; /* the d_out block's layout            */
 	int mapped;           /* 1: this stream has the host-mapped path */
+	/* completion of a mapped push: the command processor writes a sequence number into host-mapped memory behind the
+	 * last kernel (hipStreamWriteValue32) and the host spins on it: 2.8 us less than hipStreamSynchronize on this
+	 * platform (tools/ubench/launch_lat: 13.7 us -> 10.9 us for two dependent empty kernels) */
+	volatile unsigned *m_flag;
+	unsigned *md_flag;
+	unsigned flag_seq;
 	const int16_t *md_audio; int8_t *md_feat; unsigned char *md_out; /* their device addresses */
 	int state_host;       /* 1: the newest tail samples / 30 feature rows are in m_audio / m_feat, 0: in d_audio / d_feat */
 	int last_push_mapped;
@@ -196,6 +202,7 @@ extern "C" void edison_stream_destroy(edison_stream *s)
 	if (s->m_audio) (void)hipHostFree(s->m_audio);
 	if (s->m_feat) (void)hipHostFree(s->m_feat);
 	if (s->m_out) (void)hipHostFree(s->m_out);
+	if (s->m_flag) (void)hipHostFree((void *)s->m_flag);
 	if (s->h_in) (void)hipHostFree(s->h_in);
 	if (s->h_out) (void)hipHostFree(s->h_out);
 	if (s->d_audio) (void)hipFree(s->d_audio);
@@ -355,7 +362,10 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 		e = hipHostMalloc((void **)&s->m_audio, audio_bytes, hipHostMallocMapped);
 		if (e == hipSuccess) e = hipHostMalloc((void **)&s->m_feat, feat_bytes, hipHostMallocMapped);
 		if (e == hipSuccess) e = hipHostMalloc((void **)&s->m_out, s->h_out_bytes + 16, hipHostMallocMapped);
-		void *da = NULL, *df = NULL, *dout = NULL;
+		void *da = NULL, *df = NULL, *dout = NULL, *dflag = NULL;
+		if (e == hipSuccess) e = hipHostMalloc((void **)&s->m_flag, 64, hipHostMallocMapped);
+		if (e == hipSuccess) e = hipHostGetDevicePointer(&dflag, (void *)s->m_flag, 0);
+		if (e == hipSuccess) { *s->m_flag = 0; s->md_flag = (unsigned *)dflag; s->flag_seq = 0; }
 		if (e == hipSuccess) e = hipHostGetDevicePointer(&da, s->m_audio, 0);
 		if (e == hipSuccess) e = hipHostGetDevicePointer(&df, s->m_feat, 0);
 		if (e == hipSuccess) e = hipHostGetDevicePointer(&dout, s->m_out, 0);
@@ -425,7 +435,21 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 		{ const int rs = stream_state_to(s, 1); if (rs != EDISON_OK) return rs; }
 		memcpy(s->m_audio + s->tail, samples, nnew * sizeof(int16_t));
 		{ const int rd = enqueue_mapped_push(s); if (rd != EDISON_OK) return rd; }
-		ED_HIP(ctx, hipStreamSynchronize(s->own));
+		{
+			/* wait for the answer: spin on the sequence number the command processor writes behind the last kernel; if
+			 * that stream operation is unavailable, or nothing arrives within 20 ms, synchronize the ordinary way (which
+			 * also surfaces a device error) */
+			const unsigned seq = ++s->flag_seq;
+			int waited = 0;
+			if (hipStreamWriteValue32(s->own, s->md_flag, seq, 0) == hipSuccess)
+			{
+				for (unsigned spins = 0; spins < 40000000u; spins++)
+					if (*s->m_flag == seq) { waited = 1; break; }
+			}
+			else
+				(void)hipGetLastError();
+			if (!waited) ED_HIP(ctx, hipStreamSynchronize(s->own));
+		}
 		if (logits) memcpy(logits, s->m_out, c * EDISON_NET_OUT);
 		if (softmax) memcpy(softmax, s->m_out + s->off_soft, c * EDISON_NET_OUT);
 		if (argmax) memcpy(argmax, s->m_out + s->off_argmax, c * sizeof(int32_t));

@@ -35,6 +35,7 @@ class Stream:
         self.ctx._check(self._L.edison_stream_create_ex(self.ctx._h, ctypes.byref(o), ctypes.byref(h)))
         self._h = h
         self.hop, self.chunk, self.output_filter = int(hop), int(chunk_frames), bool(output_filter)
+        self._bufs = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -57,21 +58,31 @@ class Stream:
     def push(self, samples):
         """samples: chunk_frames*hop new int16 samples (host). Returns dict(logits, softmax, argmax, keywords) plus,
         with the output filter, filtered [chunk,10] fp32, likely [chunk], spotted [chunk] (-1 = below threshold)."""
-        x = np.ascontiguousarray(samples, dtype=np.int16).ravel()
+        x = samples if (type(samples) is np.ndarray and samples.dtype == np.int16 and samples.ndim == 1 and samples.flags.c_contiguous) \
+            else np.ascontiguousarray(samples, dtype=np.int16).ravel()
         if x.shape[0] != self.chunk * self.hop:
             raise ValueError("push needs exactly chunk_frames*hop = %d samples" % (self.chunk * self.hop))
-        logits = np.zeros((self.chunk, NET_OUT), np.int8)
-        soft = np.zeros((self.chunk, NET_OUT), np.int8)
-        am = np.zeros(self.chunk, np.int32)
-        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        self.ctx._check(self._L.edison_stream_push(self._h, p(x), p(logits), p(soft), p(am)))
-        out = dict(logits=logits, softmax=soft, argmax=am, keywords=[KEYWORDS[i] for i in am])
+        # the microphone path calls this once per frame: the result buffers and their addresses are made once, the call
+        # writes into them, the caller gets copies (10 + 10 + 4 bytes per frame)
+        b = self._bufs
+        if b is None:
+            b = self._bufs = self._make_bufs()
+        r = self._push(self._h, x.ctypes.data, b[3], b[4], b[5])
+        if r != _lib.OK:
+            self.ctx._check(r)
+        am = b[2].copy()
+        out = dict(logits=b[0].copy(), softmax=b[1].copy(), argmax=am, keywords=[KEYWORDS[i] for i in am])
         if self.output_filter:
-            filt = np.zeros((self.chunk, NET_OUT), np.float32)
-            likely, spotted = np.zeros(self.chunk, np.int32), np.zeros(self.chunk, np.int32)
-            self.ctx._check(self._L.edison_stream_filtered(self._h, p(filt), p(likely), p(spotted)))
-            out.update(filtered=filt, likely=likely, spotted=spotted)
+            self.ctx._check(self._L.edison_stream_filtered(self._h, b[9], b[10], b[11]))
+            out.update(filtered=b[6].copy(), likely=b[7].copy(), spotted=b[8].copy())
         return out
+
+    def _make_bufs(self):
+        c = self.chunk
+        lo, so, am = np.zeros((c, NET_OUT), np.int8), np.zeros((c, NET_OUT), np.int8), np.zeros(c, np.int32)
+        fl, li, sp = np.zeros((c, NET_OUT), np.float32), np.zeros(c, np.int32), np.zeros(c, np.int32)
+        self._push = self._L.edison_stream_push
+        return (lo, so, am, lo.ctypes.data, so.ctypes.data, am.ctypes.data, fl, li, sp, fl.ctypes.data, li.ctypes.data, sp.ctypes.data)
 
     def push_t(self, samples, logits=None, softmax=None, argmax=None, filtered=None, likely=None, spotted=None):
         """Device tensors (torch, int16 / int8 / int32 / fp32 on the context's GPU); asynchronous on the context's stream."""
