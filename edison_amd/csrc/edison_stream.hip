@@ -12,9 +12,11 @@
  * feature rows and the ten filtered outputs. The sliding window is never copied per frame: window i of a push is
  * rows i..i+30 of one [30 + chunk][13] int8 buffer, which the CNN kernel reads with a 13-byte "utterance" stride.
  *
- * The device operations of a push (MFCC kernel, CNN kernel, output filter, history shift) are captured ONCE into a
- * hipGraph and replayed per push -- except for host-pointer pushes of a few frames (the microphone case), which run
- * against host-mapped buffers with two or three direct kernel launches and no copies (see the struct). The net input
+ * The device operations of a push are the MFCC kernel, the CNN kernel, the output filter and the history shift, launched
+ * directly on a private stream (a captured hipGraph of the same nodes exists -- EDISON_STREAM_GRAPH=1 -- but replaying it
+ * measured slower than the plain launches on this platform; host pushes of 16 KB..1 MB still use the staged graph that
+ * also holds the upload and the download). Host-pointer pushes of a few frames (the microphone case) run against
+ * host-mapped buffers with two or three launches and no copies at all (see the struct). The net input
  * starts as zeros like the firmware's static netInput buffer, the filter state as zeros like netOutFilt (app.c:299-300).
  */
 #include <stdlib.h>
@@ -408,7 +410,14 @@ extern "C" int edison_stream_push_dev(edison_stream *s, const int16_t *samples, 
 	ED_HIP(ctx, hipEventRecord(s->ev_in, ctx->stream));
 	ED_HIP(ctx, hipStreamWaitEvent(s->own, s->ev_in, 0));
 	ED_HIP(ctx, hipMemcpyAsync(s->d_audio + s->tail, samples, nnew * sizeof(int16_t), hipMemcpyDeviceToDevice, s->own));
-	ED_HIP(ctx, hipGraphLaunch(s->exec, s->own));
+	{
+		/* the kernels of a push are launched directly: on this platform replaying the captured graph is SLOWER than its
+		 * three or four plain launches (1 h stream in 4096-frame pushes: 60.0 M frames/s with hipGraphLaunch, 67.2 M
+		 * without; one-frame pushes: 39 -> 32 us). EDISON_STREAM_GRAPH=1 replays the graph (A/B knob). */
+		static const int use_graph = getenv("EDISON_STREAM_GRAPH") ? atoi(getenv("EDISON_STREAM_GRAPH")) : 0;
+		if (!use_graph) { const int rd = enqueue_push(s); if (rd != EDISON_OK) return rd; }
+		else ED_HIP(ctx, hipGraphLaunch(s->exec, s->own));
+	}
 	s->last_push_staged = 0;
 	if (logits) ED_HIP(ctx, hipMemcpyAsync(logits, s->d_logits, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToDevice, s->own));
 	if (softmax) ED_HIP(ctx, hipMemcpyAsync(softmax, s->d_soft, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToDevice, s->own));
@@ -478,7 +487,7 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 	}
 	s->last_push_staged = 0;
 	ED_HIP(ctx, hipMemcpyAsync(s->d_audio + s->tail, samples, nnew * sizeof(int16_t), hipMemcpyHostToDevice, s->own));
-	ED_HIP(ctx, hipGraphLaunch(s->exec, s->own));
+	{ const int rd = enqueue_push(s); if (rd != EDISON_OK) return rd; } /* plain launches (see edison_stream_push_dev) */
 	if (logits) ED_HIP(ctx, hipMemcpyAsync(logits, s->d_logits, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToHost, s->own));
 	if (softmax) ED_HIP(ctx, hipMemcpyAsync(softmax, s->d_soft, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToHost, s->own));
 	if (argmax) ED_HIP(ctx, hipMemcpyAsync(argmax, s->d_argmax, (size_t)s->chunk * sizeof(int32_t), hipMemcpyDeviceToHost, s->own));
