@@ -1,6 +1,6 @@
 /*
  * cnn_net_mfma_kernels.hip -- ANY sequential NNoM int8 graph the planner accepts, with every Conv2D / Dense layer on the
- * gfx950 matrix cores (v_mfma_i32_32x32x32_i8). The GPU's model_run() (nnom.c:975-1040) for batch scoring; the
+ * gfx950 matrix cores (v_mfma_i32_32x32x32_i8, v_mfma_i32_16x16x64_i8). The GPU's model_run() (nnom.c:975-1040) for batch scoring; the
  * layer-by-layer kernel of cnn_net_kernels.hip stays for per-layer dumps and for graphs whose plan does not fit here.
  *
  * Arithmetic: exactly the reference's -- out = sat8((sum x*w + (bias << BL) + NN_ROUND(RS)) >> RS), ReLU as a tail
@@ -15,6 +15,13 @@
  * instructions are serviced in order); the first version ran the workgroup in lockstep phases and spent a third of its
  * time in barriers. The weight fragments stay in LDS for the whole launch, shared by the waves, when they fit beside the
  * activation slices (mode 2), else they stream from L2 (0).
+ *
+ * What the wave does NOT work out itself (the kernel is bound by vector-instruction issue, so every index calculation
+ * counts): the planner ships one run record per layer (ed_mm_run_t, two scalar loads), the place of every input byte in
+ * layer 0's layout, source / destination / valid bytes of every expansion record and the operand / output offsets of
+ * every stored pixel; they are copied into LDS once per workgroup. Tiles: 32 x 32 x 32 with up to four MFMA chains at
+ * once (the positions of a fused pooling window share an A fragment; two output tiles side by side), or 16 x 16 x 64
+ * for layers with at most 16 columns per wave, where a 32-column tile would be mostly padding.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
