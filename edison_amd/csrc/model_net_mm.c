@@ -325,7 +325,30 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 			const int64_t last_read = (int64_t)(out_h - 1) * sh * M->pitch_y + (int64_t)(out_w - 1) * M->pitch_x + max_koff + 16;
 			bad |= last_read > img || (M->pitch_x & 15) || (M->pitch_y & 15) || (M->in_img & 15) || (M->x_img & 15);
 			bad |= M->expand ? (batch * up16(M->x_img) > mm->x_bytes + 0) : 0;
+			/* the tables the kernel follows blindly: every entry re-checked against the buffers it indexes */
+			if (M->col_off >= 0)
+			{
+				const int pix = dense ? 1 : st_h * st_w, wmax = fused ? ((M->pool_h - 1) * sh) * M->pitch_y + (M->pool_w - 1) * M->pitch_x : 0;
+				for (int q = 0; q < pix; q++)
+				{
+					const int boff = mm->coltab[2 * (M->col_off + q)], ooff = mm->coltab[2 * (M->col_off + q) + 1];
+					bad |= boff < 0 || (boff & 15) || (int64_t)boff + wmax + max_koff + 16 > img || ooff < 0 || ooff + L->out_c > oimg;
+				}
+			}
+			if (M->xtab_off >= 0)
+			{
+				const int rec = (dense ? 1 : M->in_hp) * out_w * M->cpr;
+				for (int q = 0; q < rec; q++)
+				{
+					const int w0 = mm->xtab[2 * (M->xtab_off + q)], doff = mm->xtab[2 * (M->xtab_off + q) + 1];
+					const int soff = w0 & 0xffffff, keep = w0 >> 24;
+					/* the gather reads five aligned dwords around soff: up to soff + 20 */
+					bad |= keep < 1 || keep > 16 || soff + 20 > M->in_img + 4 || doff < 0 || (doff & 15) || doff + 16 > M->x_img;
+				}
+			}
 		}
+		if (i == 0)
+			for (int e = 0; e < mm->n_intab; e++) bad |= mm->intab[e] >= M->in_img;
 		if (bad) { free(fb); free(sb); return EDISON_OK; } /* mm->ok stays 0 */
 		/* the run record */
 		ed_mm_run_t *R = &mm->R[i];
