@@ -111,8 +111,10 @@ __device__ __forceinline__ v4i emm_gather16(const lds8 *a, int soff, int keep)
 	return (v4i){(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
 }
 
-/* elements 4 lane + 256 k .. +3 of one input image into x[k], k < EMM_PRE (zero past the image); the image's last bytes
- * are not overrun (the batch may end there) */
+/* elements 4 lane + 256 k .. +3 of one input image (in_n >= 4) into x[k], k < EMM_PRE, zero past the image. Branch-free:
+ * a dword that would overrun the image's last byte (the batch may end there) is fetched from in_n - 4 instead and shifted
+ * down; lanes past the image fetch that same dword and drop it. (With byte loads under divergent branches for the tail
+ * the compiler put a full vmcnt(0) behind every one of them -- inside the code that was meant to PREFETCH.) */
 #define EMM_PRE 2
 __device__ __forceinline__ void emm_load_image(const int8_t *src, int in_n, int lane, uint32_t (&x)[EMM_PRE])
 {
@@ -120,16 +122,15 @@ __device__ __forceinline__ void emm_load_image(const int8_t *src, int in_n, int 
 	for (int k = 0; k < EMM_PRE; k++)
 	{
 		const int e = 4 * lane + 256 * k;
-		uint32_t v = 0;
-		if (e + 4 <= in_n) v = *reinterpret_cast<const uint32_t *>(src + e);
-		else if (e < in_n)
-		{
-			v = (uint32_t)(uint8_t)src[e];
-			if (e + 1 < in_n) v |= (uint32_t)(uint8_t)src[e + 1] << 8;
-			if (e + 2 < in_n) v |= (uint32_t)(uint8_t)src[e + 2] << 16;
-		}
-		x[k] = v;
+		const int at = e + 4 <= in_n ? e : in_n - 4;
+		x[k] = *reinterpret_cast<const uint32_t *>(src + at); /* raw: shifted where it is USED (emm_image_dword), an iteration later */
 	}
+}
+__device__ __forceinline__ uint32_t emm_image_dword(uint32_t raw, int in_n, int lane, int k)
+{
+	const int e = 4 * lane + 256 * k;
+	const int at = e + 4 <= in_n ? e : in_n - 4, sh = 8 * (e - at);
+	return sh < 32 ? raw >> sh : 0u; /* e - at >= 4: nothing of this lane's four bytes lies inside the image */
 }
 
 struct emm_layout { int hp, wp, py, px, img; }; /* how an activation tensor lies in LDS: padded dims, origin, bytes per image */
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 	/* One image per wave and at most 512 bytes of it: the next image's dwords are requested from HBM before this one's layers
 	 * run (two registers; more would spill), so that the wave never waits a memory latency per input. */
 	const int64_t u_first = ((int64_t)blockIdx.x * n_waves + wave) * batch, u_step = (int64_t)gridDim.x * n_waves * batch;
-	const bool prefetch = n_intab && batch == 1 && P->in_n <= EMM_PRE * 256;
+	const bool prefetch = n_intab && batch == 1 && P->in_n <= EMM_PRE * 256 && P->in_n >= 4;
 	uint32_t pre[EMM_PRE];
 	if (prefetch && u_first < n) emm_load_image(in + u_first * in_stride, P->in_n, lane, pre);
 	for (int64_t u0 = u_first; u0 < n; u0 += u_step)
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 			{
 				uint32_t v[EMM_PRE];
 #pragma unroll
-				for (int k = 0; k < EMM_PRE; k++) v[k] = pre[k];
+				for (int k = 0; k < EMM_PRE; k++) v[k] = emm_image_dword(pre[k], in_n, lane, k);
 				/* unconditional, like the MFCC kernels' prefetch: a wave's last pass re-reads its own image (an L2 hit) */
 				emm_load_image(in + (u0 + u_step < n ? u0 + u_step : u0) * in_stride, in_n, lane, pre);
 #pragma unroll
