@@ -116,10 +116,16 @@ __device__ __forceinline__ uint4 edm_gather16(uint32_t d0, uint32_t d1, uint32_t
  * order, the (code-less) wave barrier only keeps the compiler from moving memory operations across. */
 __device__ __forceinline__ void edm_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
-/* The 13-byte feature rows of one group, one row per lane and pass (4 x 31 = 124 rows over 2 x 64 lanes), as 16 bytes with
- * the 3 padding bytes zeroed. A row is read with ONE unaligned 16-byte load (gfx950 under HSA runs with unaligned access
- * enabled; the compiler picks the instruction from the memcpy's alignment-1 source); only the very last row of the batch
- * must not touch the 3 bytes behind it (they may lie beyond the allocation) and is read byte by byte. */
+/*
+ * The 13-byte feature rows of a group (4 utterances x 31 rows = 124 rows, two per lane) as RAW 16-byte loads: row y of
+ * utterance u starts 13 bytes after row y - 1, so a load takes 3 bytes of the next row along -- except for the very last
+ * row of the batch, which is fetched 3 bytes early instead (the 16 bytes END with the row). Nothing here looks at the
+ * loaded values: what is needed of them (edm_fix_row: drop the foreign bytes, shift the early row into place) happens
+ * where they are USED, an iteration later. (The first version masked and byte-assembled right here; the compiler put a
+ * vmcnt(0) behind every load -- inside the code that was meant to prefetch.)
+ */
+__device__ __forceinline__ bool edm_row_is_last(int64_t base, int u, int y, int64_t n_utt) { return base + u == n_utt - 1 && y == ED_IN_H - 1; }
+
 __device__ __forceinline__ void edm_load_rows(const int8_t *feat, int64_t feat_stride, int64_t base, int nb, int64_t n_utt,
                                               int lane, uint4 (&rows)[2])
 {
@@ -128,25 +134,24 @@ __device__ __forceinline__ void edm_load_rows(const int8_t *feat, int64_t feat_s
 	{
 		const int r = lane + 64 * pass;
 		const int u = r / ED_IN_H, y = r - u * ED_IN_H;
-		uint4 d = make_uint4(0, 0, 0, 0);
-		if (r < EDM_G * ED_IN_H && u < nb)
-		{
-			const uint8_t *g = reinterpret_cast<const uint8_t *>(feat) + (base + u) * feat_stride + y * ED_IN_W;
-			if (base + u == n_utt - 1 && y == ED_IN_H - 1)
-			{
-				uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-				for (int j = 0; j < ED_IN_W; j++) w[j >> 2] |= (uint32_t)g[j] << (8 * (j & 3));
-				d = make_uint4(w[0], w[1], w[2], w[3]);
-			}
-			else
-			{
-				__builtin_memcpy(&d, g, 16);
-				d.w &= 0xffu; /* bytes 13..15 belong to the next row */
-			}
-		}
+		/* rows past the group / past the batch re-read the group's first row (in bounds) and are zeroed at the use */
+		const bool have = r < EDM_G * ED_IN_H && u < nb;
+		const uint8_t *g = reinterpret_cast<const uint8_t *>(feat) + (base + (have ? u : 0)) * feat_stride + (have ? y : 0) * ED_IN_W;
+		if (have && edm_row_is_last(base, u, y, n_utt)) g -= 3;
+		uint4 d;
+		__builtin_memcpy(&d, g, 16);
 		rows[pass] = d;
 	}
+}
+
+/* the 13 bytes of the row out of what edm_load_rows fetched for it, zero-padded to 16 */
+__device__ __forceinline__ uint4 edm_fix_row(uint4 d, int64_t base, int nb, int64_t n_utt, int r)
+{
+	const int u = r / ED_IN_H, y = r - u * ED_IN_H;
+	if (edm_row_is_last(base, u, y, n_utt)) /* fetched 3 bytes early */
+		d = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 24), __builtin_amdgcn_alignbit(d.z, d.y, 24), __builtin_amdgcn_alignbit(d.w, d.z, 24), d.w >> 24);
+	d.w &= 0xffu; /* bytes 13..15 belong to the next row */
+	return u < nb ? d : make_uint4(0, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_mfma_model_t *__restrict__ model,
@@ -209,7 +214,9 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 			if (r < EDM_G * ED_IN_H)
 			{
 				const int u = r / ED_IN_H, y = r - u * ED_IN_H;
-				*reinterpret_cast<uint4 *>(acts + u * EDM_UTT + y * 16) = rows[pass];
+				const int64_t b_cur = (g_lo + idx) * EDM_G;
+				*reinterpret_cast<uint4 *>(acts + u * EDM_UTT + y * 16) =
+				    edm_fix_row(rows[pass], b_cur, (int)((n_utt - b_cur) < EDM_G ? (n_utt - b_cur) : EDM_G), n_utt, r);
 			}
 		}
 		const uint32_t next = __builtin_amdgcn_readfirstlane(drawn);
