@@ -465,7 +465,7 @@ def main():
         # ---- the CNN alone on the features of the last step: the matrix-core figure north_star asks for
         def cnn_step(i):
             ctx.cnn_t(feat, nu, logits=logits, softmax=soft, argmax=am)
-        c_ms, cev_ms = timed_region(cnn_step, max(20, min(args.steps, 200)), 10, 1 if world == 1 else world)
+        c_ms, cev_ms = timed_region(cnn_step, max(100, min(args.steps, 200)), 20, 1 if world == 1 else world)  # 0.3 ms steps: 100 of them = 30 ms
         useful = nu * CNN_MACS_PER_UTT * 2 / (cev_ms * 1e-3) / 1e12
         issued = nu * CNN_MFMA_PER_UTT * 32768 * 2 / (cev_ms * 1e-3) / 1e12
         kws["cnn"] = dict(metric="int8 CNN alone (ed_cnn_mfma_kernel)", value=round(world * nu / (c_ms * 1e-3), 1), unit="inferences/s",
