@@ -25,7 +25,7 @@ c_void_p, c_int, c_int64, c_size_t, c_float, c_double, c_char_p = (
 class StreamOpts(ctypes.Structure):
     """edison_stream_opts"""
     _fields_ = [("hop", c_int), ("chunk_frames", c_int), ("mfcc_variant", c_int), ("filter", c_int),
-                ("filter_alpha", c_double), ("true_threshold", c_double)]
+                ("filter_alpha", c_double), ("true_threshold", c_double), ("launch_mode", c_int), ("reserved_", c_int)]
 
 
 class NetInfo(ctypes.Structure):
@@ -64,6 +64,7 @@ SIGNATURES = {
     "edison_net_layers_dev": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "edison_net_batch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "edison_net_layers": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "edison_dist_available": (c_int, []),
     "edison_dist_unique_id": (c_int, [c_void_p]),
     "edison_dist_init": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "edison_dist_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
@@ -71,6 +72,8 @@ SIGNATURES = {
     "edison_dist_shard_range": (c_int, [c_int64, c_int, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "edison_dist_allgather_logits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "edison_kws_batch_sharded_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_dist_allgather_logits_total": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "edison_kws_batch_sharded_total_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "edison_dev_alloc": (c_int, [c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
     "edison_dev_free": (c_int, [c_void_p, c_void_p]),
     "edison_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),

@@ -69,5 +69,24 @@ def build(force=False, verbose=False):
     return OUT
 
 
+EXAMPLES_BIN = os.path.join(os.path.dirname(HERE), "examples", "bin")
+
+
+def build_examples(force=False):
+    """The C hosts under examples/ that bench.py runs (plain C against include/edison_hip.h, linked to the library with
+    an rpath relative to the binary, so the pair travels with the tree): examples/bin/host_stream_latency."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "examples", "host_stream_latency.c")
+    exe = os.path.join(EXAMPLES_BIN, "host_stream_latency")
+    if not force and os.path.exists(exe) and os.path.getmtime(exe) > max(os.path.getmtime(src), os.path.getmtime(OUT)):
+        return exe
+    cc = shutil.which("gcc") or shutil.which("cc") or _hipcc()
+    os.makedirs(EXAMPLES_BIN, exist_ok=True)
+    subprocess.check_call([cc, "-O2", "-Wall", src, "-I", os.path.join(root, "include"), "-L", CSRC, "-ledison_hip",
+                           "-Wl,-rpath,$ORIGIN/../../edison_amd/csrc", "-o", exe])
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_examples(force="--force" in sys.argv))

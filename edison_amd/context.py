@@ -274,6 +274,14 @@ class Context:
     def allgather_logits_t(self, local_logits, n_local, out):
         self._check(self._L.edison_dist_allgather_logits(self._h, _t_ptr(local_logits), int(n_local), _t_ptr(out)))
 
+    def allgather_logits_total_t(self, local_logits, n_total, out):
+        """Shards cut by shard_range(n_total, rank, world): any n_total, one padded ncclAllGather inside."""
+        self._check(self._L.edison_dist_allgather_logits_total(self._h, _t_ptr(local_logits), int(n_total), _t_ptr(out)))
+
+    def kws_sharded_total_t(self, audio, n_total, utt_stride, logits_all, feat=None, logits=None, softmax=None, argmax=None):
+        self._check(self._L.edison_kws_batch_sharded_total_dev(self._h, _t_ptr(audio), int(n_total), int(utt_stride), _t_ptr(feat),
+                                                               _t_ptr(logits), _t_ptr(softmax), _t_ptr(argmax), _t_ptr(logits_all)))
+
     def kws_sharded_t(self, audio, n_local, utt_stride, logits_all, feat=None, logits=None, softmax=None, argmax=None):
         self._check(self._L.edison_kws_batch_sharded_dev(self._h, _t_ptr(audio), int(n_local), int(utt_stride), _t_ptr(feat),
                                                          _t_ptr(logits), _t_ptr(softmax), _t_ptr(argmax), _t_ptr(logits_all)))

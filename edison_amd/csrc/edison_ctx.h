@@ -65,6 +65,8 @@ struct edison_ctx
 	/* multi-GPU (edison_dist.hip): the RCCL communicator this context belongs to, NULL for a single-GPU context */
 	void *dist_comm;
 	int dist_rank, dist_world;
+	void *dist_scratch; /* padded send + receive blocks of edison_dist_allgather_logits_total (unequal shards) */
+	size_t dist_scratch_bytes;
 	char err[512];
 };
 

@@ -70,6 +70,13 @@ static int rccl_fail(edison_ctx *ctx, const char *what, int rc)
 	return EDISON_E_RUNTIME;
 }
 
+/* Can this process reach RCCL at all? Binds the library and nothing else: no bootstrap thread, no socket (a probe with
+ * edison_dist_unique_id would leave one of each behind on every rank that asks). */
+extern "C" int edison_dist_available(void)
+{
+	return rccl_bind();
+}
+
 extern "C" int edison_dist_unique_id(void *id128)
 {
 	if (!id128) return EDISON_E_ARGUMENT;
@@ -117,6 +124,13 @@ extern "C" int edison_dist_shutdown(edison_ctx *ctx)
 		(void)g_rccl.comm_destroy((ed_nccl_comm)ctx->dist_comm);
 		ctx->dist_comm = NULL;
 	}
+	if (ctx->dist_scratch)
+	{
+		(void)hipStreamSynchronize(ctx->stream);
+		(void)hipFree(ctx->dist_scratch);
+		ctx->dist_scratch = NULL;
+		ctx->dist_scratch_bytes = 0;
+	}
 	return EDISON_OK;
 }
 
@@ -138,6 +152,60 @@ extern "C" int edison_dist_allgather_logits(edison_ctx *ctx, const int8_t *local
 	return EDISON_OK;
 }
 
+static void shard_of(int64_t n_items, int rank, int world, int64_t *lo, int64_t *hi)
+{
+	const int64_t base = n_items / world, rem = n_items % world;
+	*lo = rank * base + (rank < rem ? rank : rem);
+	*hi = *lo + base + (rank < rem ? 1 : 0);
+}
+
+/* The same gather for a batch that the world size does not divide: every rank passes the TOTAL number of utterances, its
+ * own shard is edison_dist_shard_range(n_total_utt, rank, world) (the first n_total % world ranks hold one utterance
+ * more), and all_logits receives the n_total_utt rows in rank order without gaps. Still one ncclAllGather: the shards are
+ * padded to the largest one in a scratch block and the W received blocks are compacted by device copies on the same
+ * stream. Equal shards take the direct path. */
+extern "C" int edison_dist_allgather_logits_total(edison_ctx *ctx, const int8_t *local_logits, int64_t n_total_utt, int8_t *all_logits)
+{
+	if (!ctx || n_total_utt < 0) return EDISON_E_ARGUMENT;
+	const int world = ctx->dist_comm ? ctx->dist_world : 1, rank = ctx->dist_comm ? ctx->dist_rank : 0;
+	int64_t lo, hi;
+	shard_of(n_total_utt, rank, world, &lo, &hi);
+	if (n_total_utt == 0) return EDISON_OK;
+	if (!all_logits || (hi > lo && !local_logits)) return EDISON_E_ARGUMENT;
+	/* EDISON_DIST_FORCE_PADDED=1: take the padded road even where the shards are equal (the tests' way to run the pad /
+	 * gather / compact sequence through a real communicator on a box with one GPU) */
+	const char *force = getenv("EDISON_DIST_FORCE_PADDED");
+	if ((n_total_utt % world == 0 && !(force && force[0] == '1')) || !ctx->dist_comm)
+		return edison_dist_allgather_logits(ctx, local_logits, hi - lo, all_logits);
+	const int64_t m = n_total_utt / world + 1;                      /* the largest shard */
+	const size_t blk = (size_t)m * EDISON_NET_OUT, need = blk * (size_t)(world + 1);
+	if (need > ctx->dist_scratch_bytes)
+	{
+		ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->dist_scratch) ED_HIP(ctx, hipFree(ctx->dist_scratch));
+		ctx->dist_scratch = NULL;
+		ctx->dist_scratch_bytes = 0;
+		hipError_t e = hipMalloc(&ctx->dist_scratch, need);
+		if (e == hipErrorOutOfMemory) return ed_set_err(ctx, EDISON_E_NO_MEMORY, "edison_dist_allgather_logits_total: out of HBM");
+		ED_HIP(ctx, e);
+		ctx->dist_scratch_bytes = need;
+	}
+	int8_t *send = (int8_t *)ctx->dist_scratch, *recv = send + blk;
+	ED_HIP(ctx, hipMemsetAsync(send, 0, blk, ctx->stream));
+	if (hi > lo) ED_HIP(ctx, hipMemcpyAsync(send, local_logits, (size_t)(hi - lo) * EDISON_NET_OUT, hipMemcpyDeviceToDevice, ctx->stream));
+	int rc = g_rccl.all_gather(send, recv, blk, 0 /* ncclInt8 */, (ed_nccl_comm)ctx->dist_comm, ctx->stream);
+	if (rc != 0) return rccl_fail(ctx, "ncclAllGather", rc);
+	for (int r = 0; r < world; r++)
+	{
+		int64_t a, b;
+		shard_of(n_total_utt, r, world, &a, &b);
+		if (b > a)
+			ED_HIP(ctx, hipMemcpyAsync(all_logits + (size_t)a * EDISON_NET_OUT, recv + (size_t)r * blk, (size_t)(b - a) * EDISON_NET_OUT,
+			                           hipMemcpyDeviceToDevice, ctx->stream));
+	}
+	return EDISON_OK;
+}
+
 /* This rank's shard of the batched scoring path in one call: MFCC (variant B) -> int8 features -> CNN on n_local_utt
  * utterances, then the all-gather of the logits. softmax / argmax stay local (they follow from the logits). */
 extern "C" int edison_kws_batch_sharded_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_local_utt, int64_t utt_stride,
@@ -150,12 +218,28 @@ extern "C" int edison_kws_batch_sharded_dev(edison_ctx *ctx, const int16_t *audi
 	return edison_dist_allgather_logits(ctx, logits_local, n_local_utt, logits_all);
 }
 
+/* The same for a batch of n_total_utt utterances that the world size need not divide: `audio` holds THIS rank's shard
+ * (edison_dist_shard_range(n_total_utt, rank, world) utterances), logits_all receives all n_total_utt rows. */
+extern "C" int edison_kws_batch_sharded_total_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_total_utt, int64_t utt_stride,
+                                                  int8_t *feat, int8_t *logits_local, int8_t *softmax, int32_t *argmax,
+                                                  int8_t *logits_all)
+{
+	if (!ctx || !logits_all || n_total_utt < 0) return EDISON_E_ARGUMENT;
+	int64_t lo, hi;
+	shard_of(n_total_utt, ctx->dist_comm ? ctx->dist_rank : 0, ctx->dist_comm ? ctx->dist_world : 1, &lo, &hi);
+	if (hi > lo)
+	{
+		if (!logits_local) return EDISON_E_ARGUMENT;
+		int r = edison_kws_batch_dev(ctx, audio, hi - lo, utt_stride, feat, logits_local, softmax, argmax);
+		if (r != EDISON_OK) return r;
+	}
+	return edison_dist_allgather_logits_total(ctx, logits_local, n_total_utt, logits_all);
+}
+
 /* Contiguous shard [lo, hi) of `rank` out of n_items: the first n_items % world_size ranks take one item more. */
 extern "C" int edison_dist_shard_range(int64_t n_items, int rank, int world_size, int64_t *lo, int64_t *hi)
 {
 	if (n_items < 0 || world_size < 1 || rank < 0 || rank >= world_size || !lo || !hi) return EDISON_E_ARGUMENT;
-	const int64_t base = n_items / world_size, rem = n_items % world_size;
-	*lo = rank * base + (rank < rem ? rank : rem);
-	*hi = *lo + base + (rank < rem ? 1 : 0);
+	shard_of(n_items, rank, world_size, lo, hi);
 	return EDISON_OK;
 }

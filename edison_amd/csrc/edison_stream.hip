@@ -21,6 +21,8 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <immintrin.h>
 
 #include "edison_ctx.h"
 
@@ -30,6 +32,7 @@ struct edison_stream
 	int hop, chunk, tail; /* tail = 1024 - hop samples of history */
 	int variant;          /* EDISON_MFCC_B or EDISON_MFCC_C */
 	int filter;
+	int use_graph;        /* edison_stream_opts.launch_mode */
 	double alpha, one_minus_alpha, threshold;
 	int16_t *d_audio;     /* [tail + chunk*hop]                      */
 	int8_t *d_feat;       /* [(30 + chunk) * 13]                     */
@@ -255,6 +258,8 @@ extern "C" void edison_stream_default_opts(edison_stream_opts *o)
 	o->filter = 0;
 	o->filter_alpha = 0.9;   /* NET_OUT_MOVING_AVG_ALPHA for NET_TYPE_NNOM, app.c:38 */
 	o->true_threshold = 0.5; /* TRUE_THRESHOLD, app.c:34 */
+	const char *g = getenv("EDISON_STREAM_GRAPH");
+	o->launch_mode = (g && atoi(g)) ? EDISON_STREAM_LAUNCH_GRAPH : EDISON_STREAM_LAUNCH_DIRECT;
 }
 
 extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts *o, edison_stream **out)
@@ -279,6 +284,7 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 	s->model_epoch = ctx->model_epoch;
 	s->tables_epoch = ctx->tables_epoch;
 	s->filter = o->filter ? 1 : 0;
+	s->use_graph = o->launch_mode == EDISON_STREAM_LAUNCH_GRAPH;
 	s->alpha = o->filter_alpha;
 	s->one_minus_alpha = 1.0 - o->filter_alpha; /* the firmware's (1.0-NET_OUT_MOVING_AVG_ALPHA), folded in double */
 	s->threshold = o->true_threshold;
@@ -378,7 +384,15 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 			s->mapped = 1;
 		}
 		else
-			r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: host-mapped buffers unavailable");
+		{
+			/* no host-mapped memory on this system: the staged and the plain paths serve the host pushes */
+			(void)hipGetLastError();
+			if (s->m_audio) { (void)hipHostFree(s->m_audio); s->m_audio = NULL; }
+			if (s->m_feat) { (void)hipHostFree(s->m_feat); s->m_feat = NULL; }
+			if (s->m_out) { (void)hipHostFree(s->m_out); s->m_out = NULL; }
+			if (s->m_flag) { (void)hipHostFree((void *)s->m_flag); s->m_flag = NULL; }
+			s->mapped = 0;
+		}
 	}
 	if (r != EDISON_OK) { edison_stream_destroy(s); return r; }
 	*out = s;
@@ -413,9 +427,8 @@ extern "C" int edison_stream_push_dev(edison_stream *s, const int16_t *samples, 
 	{
 		/* the kernels of a push are launched directly: on this platform replaying the captured graph is SLOWER than its
 		 * three or four plain launches (1 h stream in 4096-frame pushes: 60.0 M frames/s with hipGraphLaunch, 67.2 M
-		 * without; one-frame pushes: 39 -> 32 us). EDISON_STREAM_GRAPH=1 replays the graph (A/B knob). */
-		static const int use_graph = getenv("EDISON_STREAM_GRAPH") ? atoi(getenv("EDISON_STREAM_GRAPH")) : 0;
-		if (!use_graph) { const int rd = enqueue_push(s); if (rd != EDISON_OK) return rd; }
+		 * without; one-frame pushes: 39 -> 32 us). launch_mode = EDISON_STREAM_LAUNCH_GRAPH replays the graph. */
+		if (!s->use_graph) { const int rd = enqueue_push(s); if (rd != EDISON_OK) return rd; }
 		else ED_HIP(ctx, hipGraphLaunch(s->exec, s->own));
 	}
 	s->last_push_staged = 0;
@@ -438,7 +451,7 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 	if (s->tables_epoch != ctx->tables_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: edison_mfcc_configure was called after this stream was created; create a new stream");
 	const size_t nnew = (size_t)s->chunk * s->hop;
 	static const int no_mapped = getenv("EDISON_STREAM_NO_MAPPED") ? atoi(getenv("EDISON_STREAM_NO_MAPPED")) : 0; /* A/B knob: the staged graph */
-	if (s->mapped && !no_mapped)
+	if (s->mapped && !no_mapped && !s->use_graph)
 	{
 		const size_t c = (size_t)s->chunk;
 		{ const int rs = stream_state_to(s, 1); if (rs != EDISON_OK) return rs; }
@@ -446,14 +459,25 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 		{ const int rd = enqueue_mapped_push(s); if (rd != EDISON_OK) return rd; }
 		{
 			/* wait for the answer: spin on the sequence number the command processor writes behind the last kernel; if
-			 * that stream operation is unavailable, or nothing arrives within 20 ms, synchronize the ordinary way (which
-			 * also surfaces a device error) */
+			 * that stream operation is unavailable, or nothing arrives within 20 ms (by the clock, looked at every 1024
+			 * spins), synchronize the ordinary way (which also surfaces a device error). The flag is read with acquire
+			 * semantics: the outputs copied below must not be read before it. */
 			const unsigned seq = ++s->flag_seq;
 			int waited = 0;
 			if (hipStreamWriteValue32(s->own, s->md_flag, seq, 0) == hipSuccess)
 			{
-				for (unsigned spins = 0; spins < 40000000u; spins++)
-					if (*s->m_flag == seq) { waited = 1; break; }
+				struct timespec t0, t1;
+				clock_gettime(CLOCK_MONOTONIC, &t0);
+				for (unsigned spins = 1;; spins++)
+				{
+					if (__atomic_load_n((const unsigned *)s->m_flag, __ATOMIC_ACQUIRE) == seq) { waited = 1; break; }
+					_mm_pause();
+					if ((spins & 1023u) == 0)
+					{
+						clock_gettime(CLOCK_MONOTONIC, &t1);
+						if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 20000000L) break;
+					}
+				}
 			}
 			else
 				(void)hipGetLastError();

@@ -43,6 +43,12 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+def dist_available():
+    """Can this process bind RCCL (edison_dist_available)? Creates nothing: no bootstrap thread, no socket."""
+    from . import _lib
+    return _lib.lib().edison_dist_available() == _lib.OK
+
+
 def dist_unique_id():
     """128 opaque bytes from rank 0's RCCL (edison_dist_unique_id); every rank needs the same ones for dist_init."""
     import ctypes
@@ -64,7 +70,20 @@ def init_context_comm(ctx, rank, world, device):
         payload = torch.frombuffer(bytearray(dist_unique_id()), dtype=torch.uint8).clone()
     payload = payload.to(device) if dist.get_backend() == "nccl" else payload
     dist.broadcast(payload, src=0)
-    ctx.dist_init(bytes(payload.cpu().numpy().tobytes()), rank, world)
+    # ncclCommInitRank is itself a collective; a rank that fails in it (or before it) must not leave the others believing
+    # in the communicator: every rank reports, the minimum decides, and a partial success is torn down everywhere
+    ok, err = 1, None
+    try:
+        ctx.dist_init(bytes(payload.cpu().numpy().tobytes()), rank, world)
+    except Exception as e:  # noqa: BLE001 -- reported below, after the other ranks have been told
+        ok, err = 0, e
+    flag = torch.tensor([ok], dtype=torch.int32)
+    flag = flag.to(device) if dist.get_backend() == "nccl" else flag
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        if ok:
+            ctx.dist_shutdown()
+        raise RuntimeError("edison_dist_init failed on %s" % ("this rank: %r" % (err,) if err else "another rank"))
 
 
 def shard_range_c(n_items, rank, world_size):

@@ -22,7 +22,7 @@ from .context import KEYWORDS, default_context
 
 class Stream:
     def __init__(self, ctx=None, hop=FRAME_LEN, chunk_frames=1, q15=False, output_filter=False, alpha=0.9,
-                 threshold=0.5):
+                 threshold=0.5, graph=None):
         self.ctx = ctx or default_context()
         self._L = _lib.lib()
         o = _lib.StreamOpts()
@@ -31,6 +31,8 @@ class Stream:
         o.mfcc_variant = _lib.MFCC_C if q15 else _lib.MFCC_B
         o.filter = 1 if output_filter else 0
         o.filter_alpha, o.true_threshold = float(alpha), float(threshold)
+        if graph is not None:    # None: the library's default (direct launches unless EDISON_STREAM_GRAPH=1)
+            o.launch_mode = 1 if graph else 0
         h = ctypes.c_void_p()
         self.ctx._check(self._L.edison_stream_create_ex(self.ctx._h, ctypes.byref(o), ctypes.byref(h)))
         self._h = h

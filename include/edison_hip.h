@@ -143,6 +143,7 @@ int edison_dev_download(edison_ctx *ctx, void *dst_host, const void *src_dev, si
  * program has (MPI, a file, a socket, torch.distributed); every rank then calls edison_dist_init on its context.
  * RCCL is bound at run time (librccl.so.1, or EDISON_RCCL_LIB); EDISON_E_NO_IMPL when it cannot be found. */
 #define EDISON_DIST_ID_BYTES 128
+int edison_dist_available(void); /* EDISON_OK when RCCL can be bound in this process (binds it, creates nothing) */
 int edison_dist_unique_id(void *id128);
 int edison_dist_init(edison_ctx *ctx, const void *id128, int rank, int world_size);
 int edison_dist_info(const edison_ctx *ctx, int *rank, int *world_size);
@@ -151,9 +152,17 @@ int edison_dist_shard_range(int64_t n_items, int rank, int world_size, int64_t *
 /* device pointers; every rank passes the same n_local_utt; rank r's rows land at all_logits + r * n_local_utt * 10.
  * Asynchronous on the context's stream. A context outside any communicator is a world of one (plain copy). */
 int edison_dist_allgather_logits(edison_ctx *ctx, const int8_t *local_logits, int64_t n_local_utt, int8_t *all_logits);
+/* a batch the world size does not divide: every rank passes the TOTAL n_total_utt, holds the shard
+ * edison_dist_shard_range(n_total_utt, rank, world) in local_logits, and receives all n_total_utt rows in rank order
+ * (shards padded to the largest one inside, still one ncclAllGather). The equal-shard call above must NOT be used with
+ * different n_local_utt on different ranks (it cannot tell; ncclAllGather would mis-place or overrun the rows). */
+int edison_dist_allgather_logits_total(edison_ctx *ctx, const int8_t *local_logits, int64_t n_total_utt, int8_t *all_logits);
 /* edison_kws_batch_dev on this rank's shard followed by the all-gather: BASELINE config 4 in one call per rank */
 int edison_kws_batch_sharded_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_local_utt, int64_t utt_stride,
                                  int8_t *feat, int8_t *logits_local, int8_t *softmax, int32_t *argmax, int8_t *logits_all);
+/* ... with shards cut by edison_dist_shard_range from n_total_utt (audio = this rank's shard only) */
+int edison_kws_batch_sharded_total_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_total_utt, int64_t utt_stride,
+                                       int8_t *feat, int8_t *logits_local, int8_t *softmax, int32_t *argmax, int8_t *logits_all);
 
 /* ---- the hot path, batched, device pointers ----------------------------------------------------------- */
 
@@ -275,7 +284,14 @@ typedef struct edison_stream_opts
 	int filter;
 	double filter_alpha;
 	double true_threshold;
+	int launch_mode;  /* EDISON_STREAM_LAUNCH_DIRECT (default): the kernels of a push are launched one by one;
+	                   * EDISON_STREAM_LAUNCH_GRAPH: every push replays the hipGraph captured at creation (device pushes: the
+	                   * MFCC / CNN / filter / shift nodes; host pushes: upload + those + download). Same results; on this
+	                   * platform the replay measures slower. Default from EDISON_STREAM_GRAPH=1. */
+	int reserved_;
 } edison_stream_opts;
+#define EDISON_STREAM_LAUNCH_DIRECT 0
+#define EDISON_STREAM_LAUNCH_GRAPH 1
 void edison_stream_default_opts(edison_stream_opts *o);
 int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts *o, edison_stream **out);
 /* Filtered outputs of the LAST push: filt [chunk][10] fp32 (netOutFilt after each inference), likely [chunk] int32

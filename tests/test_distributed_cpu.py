@@ -119,3 +119,69 @@ def test_unique_id_reaches_every_rank():
     for p in ps:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _run_bench(argv, env_extra=None, launcher=None, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + argv
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def _json_lines(text):
+    import json
+    out = []
+    for ln in text.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            out.append(json.loads(ln))
+    return out
+
+
+def test_bench_starts_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` with no launcher above it must start two ranks itself (BASELINE configs[3] is launched the
+    same way with 8). --dry-run rehearses that control flow on CPU: two child processes rendezvous over gloo, rank 0's
+    128-byte RCCL id reaches rank 1, the C-ABI's shard ranges tile the batch, W + K gather steps run between barriers,
+    and rank 0 alone prints ONE line -- with n_gpus = 2, dry_run = true and no throughput."""
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "4", "--warmup", "2"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None and d["config"]["parallelism"] == "dp2"
+    c = d["checks"]
+    assert c["ranks"] == 2 and c["gathered_logits_correct"] is True
+    assert c["shard_ranges_rank0"] == [[0, 4096], [0, 4097]]
+    if c["rccl_bindable"]:
+        assert c["rccl_id_reached_every_rank"] is True
+
+
+def test_bench_dry_run_under_torchrun():
+    """The driver's own launch form for N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N):
+    WORLD_SIZE comes from the launcher, bench.py must not start ranks of its own on top."""
+    port = str(_free_port())
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", port]
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"], launcher=launcher)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["checks"]["ranks"] == 2
+
+
+def test_bench_refuses_a_world_it_cannot_build():
+    """Fewer devices than --gpus: non-zero exit, a message, and NO JSON line (never `n_gpus: 1` for `--gpus 8`).
+    Likewise a WORLD_SIZE that contradicts --gpus."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this box really has 8 GPUs")
+    r = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1"])
+    assert r.returncode != 0 and _json_lines(r.stdout) == [] and "GPU(s) visible" in r.stderr
+    r = _run_bench(["--gpus", "8", "--dry-run"], env_extra=dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and _json_lines(r.stdout) == []
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """If a rank dies the parent stops the others and exits non-zero (here: rank 1 is told to fail before the rendezvous)."""
+    r = _run_bench(["--gpus", "2", "--dry-run"], env_extra=dict(EDISON_BENCH_FAIL_RANK="1"), timeout=120)
+    assert r.returncode != 0 and _json_lines(r.stdout) == []

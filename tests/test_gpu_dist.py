@@ -37,11 +37,29 @@ def test_world_of_one_through_rccl(oracle_mod, oracle_model):
         assert torch.equal(all1, lo)
         o = oracle_mod.cnn(oracle_model, feat.cpu().numpy())
         assert np.array_equal(all1.cpu().numpy(), o["logits"]) and np.array_equal(am.cpu().numpy(), o["argmax"])
-        x = torch.randint(-128, 128, (1000, 10), dtype=torch.int32, device=dev).to(torch.int8)
+        x = torch.randint(-128, 128, (1001, 10), dtype=torch.int32, device=dev).to(torch.int8)
         y = torch.zeros_like(x)
-        c.allgather_logits_t(x, 1000, y)
+        c.allgather_logits_t(x, 1001, y)
         torch.cuda.synchronize()
         assert torch.equal(x, y)
+        # the gather for batches the world size does not divide (edison_dist_allgather_logits_total): in a world of one
+        # every total divides, so EDISON_DIST_FORCE_PADDED=1 sends it down the padded road all the same -- zeroed send block
+        # of the largest shard + 1 row, ONE ncclAllGather into scratch, compaction copies -- through the real communicator
+        import os
+        os.environ["EDISON_DIST_FORCE_PADDED"] = "1"
+        try:
+            for n_odd in (1, 7, 1001):
+                y2 = torch.full((n_odd, 10), 55, dtype=torch.int8, device=dev)
+                c.allgather_logits_total_t(x[:n_odd].contiguous(), n_odd, y2)
+                torch.cuda.synchronize()
+                assert torch.equal(x[:n_odd], y2)
+            all2 = torch.full((n, 10), 66, dtype=torch.int8, device=dev)
+            c.kws_sharded_total_t(audio, n, 31744, all2, feat=feat, logits=lo, softmax=so, argmax=am)
+            torch.cuda.synchronize()
+            assert torch.equal(all2, all1)
+        finally:
+            del os.environ["EDISON_DIST_FORCE_PADDED"]
+        assert parallel.dist_available()
         with pytest.raises(Exception):
             c.dist_init(parallel.dist_unique_id(), 0, 1)   # a context joins one communicator only
         c.dist_shutdown()
