@@ -6,6 +6,11 @@
  *   DCT matrix    mfcc.c:102-117  sqrt(2/26) cosf(pi/26 (n + 0.5) k)
  * plus the twiddles of the device FFT (the firmware calls arm_rfft_fast_f32; its tables are not in the snapshot).
  */
+/* Every float operation below is rounded on its own, as the C source of mfcc.c says (the firmware compiles it at -O0,
+ * firmware/Makefile:42; the reference's file compiled on this host agrees: tests/test_oracle_refpins.py compares the tables
+ * with its create_mel_fbank / create_dct_matrix bit for bit). clang would otherwise fuse a * b + c into one fma. */
+#pragma STDC FP_CONTRACT OFF
+
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -18,6 +18,10 @@
  * reference itself it is switched off (#if'd "NNoM example") and feeds a 63 x 12 input that the shipped 31 x 13
  * network does not accept.
  */
+/* no fused multiply-adds: mfcc.c is compiled at -O0 for the MCU (firmware/Makefile:42) and plain C rounds every operation;
+ * with -march=x86-64-v3 gcc would contract a * b + c (tests/test_oracle_refpins.py: tables bit-identical to the reference's) */
+#pragma GCC optimize("fp-contract=off")
+
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
@@ -100,6 +104,28 @@ void oracle_f32_mfcc_free(oracle_f32_mfcc_t *m)
 }
 
 int oracle_f32_mfcc_n_out(const oracle_f32_mfcc_t *m) { return m->n_features - m->offset; }
+
+/* the restated tables, for the comparison with the reference's own create_dct_matrix / create_mel_fbank (oracle/_ref/
+ * libmfcc_f32_ref.so): dct [n_features][26]; first / last [26]; weights = the rows back to back; returns their count */
+int oracle_f32_mfcc_tables_get(const oracle_f32_mfcc_t *m, float *dct, int32_t *first, int32_t *last, float *weights, int cap)
+{
+	if (!m) return -1;
+	if (dct) memcpy(dct, m->dct, sizeof(float) * F32_NUM_FBANK * (size_t)m->n_features);
+	int pos = 0;
+	for (int b = 0; b < F32_NUM_FBANK; b++)
+	{
+		const int n = m->last[b] - m->first[b] + 1;
+		if (first) first[b] = m->first[b];
+		if (last) last[b] = m->last[b];
+		if (weights)
+		{
+			if (pos + n > cap) return -1;
+			memcpy(weights + pos, m->fbank[b], sizeof(float) * (size_t)n);
+		}
+		pos += n;
+	}
+	return pos;
+}
 
 /* radix-2 FFT in double, natural order in/out */
 static void fft_double(double *re, double *im, int n)

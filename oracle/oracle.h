@@ -75,6 +75,7 @@ oracle_f32_mfcc_t *oracle_f32_mfcc_new(int num_mfcc_features, int feature_offset
                                        float preempha);
 void oracle_f32_mfcc_free(oracle_f32_mfcc_t *m);
 int oracle_f32_mfcc_n_out(const oracle_f32_mfcc_t *m);
+int oracle_f32_mfcc_tables_get(const oracle_f32_mfcc_t *m, float *dct, int32_t *first, int32_t *last, float *weights, int cap);
 /* mfcc_compute on n_frames frames starting every frame_step samples: out int8 [n][n_out]; out_f32 (may be NULL) the
  * scaled sums before round/saturate; logmel (may be NULL) [n][26] */
 int oracle_f32_mfcc_run(const oracle_f32_mfcc_t *m, const int16_t *x, int64_t n_frames, int64_t frame_step, int8_t *out,

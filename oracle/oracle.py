@@ -22,6 +22,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_SO = os.path.join(_HERE, "_build", "liboracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libnnom_ref.so")
+Q15_REF_SO = os.path.join(_HERE, "_ref", "libcmsis_q15_ref.so")   # the reference's CMSIS-DSP Q15 FFT / split / sqrt routines
+F32_REF_SO = os.path.join(_HERE, "_ref", "libmfcc_f32_ref.so")    # the reference's firmware/src/audio/mfcc.c (table builders)
 DEFAULT_MODEL = os.path.join(os.path.dirname(_HERE), "edison_amd", "data", "kws_nnom.ednn")
 
 VARIANT_A, VARIANT_B = 0, 1
@@ -35,10 +37,12 @@ def build(force=False):
     """Compile the restatement (always possible: gcc only) and, when the reference is mounted, the reference."""
     if force or not os.path.exists(PORT_SO) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(PORT_SO)
-            for f in ("mfcc_ref.c", "mfcc_q15_ref.c", "mfcc_f32_ref.c", "kws_cnn_ref.c", "postproc_ref.c", "oracle.h")):
+            for f in ("mfcc_ref.c", "mfcc_q15_ref.c", "mfcc_f32_ref.c", "kws_cnn_ref.c", "postproc_ref.c", "ref_loader.c", "oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "-B", "port"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/firmware") and (force or not os.path.exists(REF_SO)):
-        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/firmware"):
+        for so, target in ((REF_SO, "ref"), (Q15_REF_SO, "q15ref"), (F32_REF_SO, "f32ref")):
+            if force or not os.path.exists(so):
+                subprocess.check_call(["make", "-C", _HERE, target], stdout=subprocess.DEVNULL)
 
 
 def use_native_build():
@@ -98,6 +102,8 @@ def port():
         L.oracle_f32_mfcc_free.restype = None
         L.oracle_f32_mfcc_free.argtypes = [ctypes.c_void_p]
         L.oracle_f32_mfcc_n_out.argtypes = [ctypes.c_void_p]
+        L.oracle_f32_mfcc_tables_get.restype = ctypes.c_int
+        L.oracle_f32_mfcc_tables_get.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int]
         L.oracle_f32_mfcc_run.restype = ctypes.c_int
         L.oracle_f32_mfcc_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -136,6 +142,118 @@ def ref():
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _open_lazy(path, names):
+    """A reference-compiled library that carries unresolved symbols of paths nobody calls: opened with lazy binding through
+    oracle/ref_loader.c (ctypes itself always binds NOW). names: {symbol: (restype, argtypes)} -> {symbol: callable}."""
+    L = port()
+    L.oracle_dl_open_lazy.restype = ctypes.c_void_p
+    L.oracle_dl_open_lazy.argtypes = [ctypes.c_char_p]
+    L.oracle_dl_sym.restype = ctypes.c_void_p
+    L.oracle_dl_sym.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    L.oracle_dl_error.restype = ctypes.c_char_p
+    if not os.path.exists(path):
+        build()
+    if not os.path.exists(path):
+        raise FileNotFoundError("%s is absent and /root/reference is not mounted" % os.path.relpath(path, os.path.dirname(_HERE)))
+    h = L.oracle_dl_open_lazy(path.encode())
+    if not h:
+        raise OSError("dlopen %s: %s" % (path, (L.oracle_dl_error() or b"?").decode()))
+    out = {}
+    for name, (restype, argtypes) in names.items():
+        addr = L.oracle_dl_sym(h, name.encode())
+        if not addr:
+            raise OSError("%s lacks %s" % (path, name))
+        out[name] = ctypes.CFUNCTYPE(restype, *argtypes)(addr)
+    return out
+
+
+_q15_ref = None
+_f32_ref = None
+
+
+def have_q15_ref():
+    return os.path.exists(Q15_REF_SO) or os.path.isdir("/root/reference/firmware")
+
+
+def have_f32_ref():
+    return os.path.exists(F32_REF_SO) or os.path.isdir("/root/reference/firmware")
+
+
+class CmsisQ15Ref:
+    """The reference's own CMSIS-DSP routines of variant C, compiled with the firmware's ARM_MATH_DSP branches
+    (oracle/ref_shim/cmsis_q15_ref_shim.c). Tables are the caller's (by pointer)."""
+
+    def __init__(self):
+        vp, ci, cl = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+        self._f = _open_lazy(Q15_REF_SO, {
+            "q15ref_cfft": (ci, [vp, ci, vp, cl]),
+            "q15ref_split_rfft": (ci, [vp, ci, vp, vp, vp, ci, cl]),
+            "q15ref_sqrt_q31": (ci, [vp, vp, cl]),
+        })
+
+    def cfft(self, x, tw):
+        """arm_cfft_q15(forward, no bit reversal) on [n_frames, 2 * n] int16 (re, im interleaved); returns a new array whose
+        element order is the routine's (bit-reversed)."""
+        b = np.ascontiguousarray(x, dtype=np.int16).copy()
+        n = b.shape[-1] // 2
+        tw = np.ascontiguousarray(tw, dtype=np.int16)
+        assert tw.size >= 2 * (3 * n // 4)
+        if self._f["q15ref_cfft"](_p(b), n, _p(tw), b.size // (2 * n)) != 0:
+            raise ValueError("arm_cfft_q15: unsupported length %d" % n)
+        return b
+
+    def split_rfft(self, z, A, B, modifier=1):
+        """arm_split_rfft_q15 on [n_frames, 2 * n_cplx] int16 in natural order -> [n_frames, 4 * n_cplx]."""
+        z = np.ascontiguousarray(z, dtype=np.int16).copy()
+        nc = z.shape[-1] // 2
+        A, B = np.ascontiguousarray(A, dtype=np.int16), np.ascontiguousarray(B, dtype=np.int16)
+        out = np.zeros(z.shape[:-1] + (4 * nc,), np.int16)
+        self._f["q15ref_split_rfft"](_p(z), nc, _p(A), _p(B), _p(out), int(modifier), z.size // (2 * nc))
+        return out
+
+    def sqrt_q31(self, x):
+        x = np.ascontiguousarray(x, dtype=np.int32)
+        out = np.zeros_like(x)
+        self._f["q15ref_sqrt_q31"](_p(x), _p(out), x.size)
+        return out
+
+
+def cmsis_q15_ref():
+    global _q15_ref
+    if _q15_ref is None:
+        _q15_ref = CmsisQ15Ref()
+    return _q15_ref
+
+
+class MfccF32Ref:
+    """The reference's own table builders of variant D (firmware/src/audio/mfcc.c:101-171), oracle/ref_shim/mfcc_f32_ref_shim.c."""
+
+    def __init__(self):
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        self._f = _open_lazy(F32_REF_SO, {"f32ref_dct_matrix": (ci, [ci, ci, vp]), "f32ref_mel_fbank": (ci, [ci, vp, vp, vp, ci])})
+
+    def dct_matrix(self, input_length, coefficient_count):
+        out = np.zeros((coefficient_count, input_length), np.float32)
+        if self._f["f32ref_dct_matrix"](int(input_length), int(coefficient_count), _p(out)) != 0:
+            raise RuntimeError("create_dct_matrix failed")
+        return out
+
+    def mel_fbank(self, frame_len_padded):
+        first, last = np.zeros(26, np.int32), np.zeros(26, np.int32)
+        w = np.zeros(8192, np.float32)
+        n = self._f["f32ref_mel_fbank"](int(frame_len_padded), _p(first), _p(last), _p(w), w.size)
+        if n < 0:
+            raise RuntimeError("create_mel_fbank failed")
+        return first, last, w[:n].copy()
+
+
+def mfcc_f32_ref():
+    global _f32_ref
+    if _f32_ref is None:
+        _f32_ref = MfccF32Ref()
+    return _f32_ref
 
 
 # ------------------------------------------------------------------------------------------- MFCC
@@ -256,7 +374,7 @@ class MfccF32:
         self.h = port().oracle_f32_mfcc_new(num_mfcc_features, feature_offset, frame_len, mfcc_dec_bits, preempha)
         if not self.h:
             raise ValueError("bad mfcc_create arguments")
-        self.frame_len, self.n_out = frame_len, port().oracle_f32_mfcc_n_out(self.h)
+        self.frame_len, self.n_out, self.feature_offset = frame_len, port().oracle_f32_mfcc_n_out(self.h), feature_offset
 
     def __call__(self, x, n_frames=None, frame_step=None, n_threads=1):
         """-> (int8 [n, n_out], float32 [n, n_out] before round/saturate, float32 log-mel [n, 26])"""
@@ -272,6 +390,15 @@ class MfccF32:
             assert (n - 1) * step + self.frame_len <= x.shape[0]
             port().oracle_f32_mfcc_run(self.h, _p(x), n, step, _p(out), _p(f32), _p(lm), int(n_threads))
         return out, f32, lm
+
+    def tables(self):
+        """The restated tables: dct [n_features, 26] f32, first [26], last [26], weights (rows back to back) f32."""
+        nf = port().oracle_f32_mfcc_n_out(self.h) + self.feature_offset
+        dct = np.zeros((nf, 26), np.float32)
+        first, last, w = np.zeros(26, np.int32), np.zeros(26, np.int32), np.zeros(8192, np.float32)
+        n = port().oracle_f32_mfcc_tables_get(self.h, _p(dct), _p(first), _p(last), _p(w), w.size)
+        assert n >= 0
+        return dct, first, last, w[:n].copy()
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -5,8 +5,11 @@
  * fast(): what mfcc_q15_kernels.hip executes: every (a*b)>>31 becomes one unsigned high multiply with one operand
  *         pre-doubled, valid as long as every intermediate stays in [0, 2^31).
  * The program walks ALL 2^31-1 positive inputs (a superset of re^2+im^2) and compares the full 32-bit results.
- *   gcc -O2 -fopenmp -o sqrt_q31_equiv sqrt_q31_equiv.c && ./sqrt_q31_equiv [stride]
+ *   gcc -O2 -fopenmp -o sqrt_q31_equiv sqrt_q31_equiv.c -ldl && ./sqrt_q31_equiv [stride] [oracle/_ref/libcmsis_q15_ref.so]
+ * With the library given (built by `make -C oracle q15ref` from the reference's CMSIS-DSP sources), the authority is the
+ * REFERENCE'S COMPILED arm_sqrt_q31 itself (q15ref_sqrt_q31_one), and the restated ref() below is checked against it too.
  */
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -52,13 +55,29 @@ static inline int32_t fast(int32_t in)
 	return (int32_t)v >> (sh >> 1);
 }
 
+typedef int32_t (*sqrt_fn)(int32_t);
+
 int main(int argc, char **argv)
 {
 	const int64_t stride = argc > 1 ? atoll(argv[1]) : 1;
-	int64_t bad = 0;
-#pragma omp parallel for schedule(static) reduction(+ : bad)
+	sqrt_fn cmsis = NULL;
+	if (argc > 2)
+	{
+		void *h = dlopen(argv[2], RTLD_LAZY | RTLD_LOCAL);
+		cmsis = h ? (sqrt_fn)dlsym(h, "q15ref_sqrt_q31_one") : NULL;
+		if (!cmsis) { fprintf(stderr, "cannot load q15ref_sqrt_q31_one from %s: %s\n", argv[2], dlerror()); return 2; }
+	}
+	int64_t bad = 0, bad_restatement = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad, bad_restatement)
 	for (int64_t x = 1; x < ((int64_t)1 << 31); x += stride)
-		if (ref((int32_t)x) != fast((int32_t)x)) bad++;
-	printf("stride %lld: %lld mismatches\n", (long long)stride, (long long)bad);
-	return bad != 0;
+	{
+		const int32_t want = cmsis ? cmsis((int32_t)x) : ref((int32_t)x);
+		if (want != fast((int32_t)x)) bad++;
+		if (cmsis && want != ref((int32_t)x)) bad_restatement++;
+	}
+	printf("stride %lld, authority = %s: %lld mismatches of the GPU formulation", (long long)stride,
+	       cmsis ? "reference object code (arm_sqrt_q31 compiled from the reference)" : "the restated sequence", (long long)bad);
+	if (cmsis) printf(", %lld of the restatement", (long long)bad_restatement);
+	printf("\n");
+	return (bad != 0) | (bad_restatement != 0);
 }

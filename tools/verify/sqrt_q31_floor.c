@@ -8,8 +8,11 @@
  *   1. t < d < 4c + 2 - t           =>  mag(x) == c                       (the kernel's fast path)
  *   2. d == 0                       =>  mag(x) is c or c - 1              (the kernel's bitmap, built by tables_q15.c)
  * Everything else goes through the full routine in the kernel. It also prints how many inputs each class holds.
- *   gcc -O2 -fopenmp -o sqrt_q31_floor sqrt_q31_floor.c -lm && ./sqrt_q31_floor
+ *   gcc -O2 -fopenmp -o sqrt_q31_floor sqrt_q31_floor.c -lm -ldl && ./sqrt_q31_floor [stride] [oracle/_ref/libcmsis_q15_ref.so]
+ * With the library given (`make -C oracle q15ref`), arm_sqrt_q31 is the REFERENCE'S COMPILED routine (q15ref_sqrt_q31_one)
+ * instead of the restated sequence below.
  */
+#include <dlfcn.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -36,17 +39,27 @@ static inline int32_t ref(int32_t in)
 	return v >> (sh / 2);
 }
 
-int main(void)
+typedef int32_t (*sqrt_fn)(int32_t);
+
+int main(int argc, char **argv)
 {
+	const int64_t stride = argc > 1 ? atoll(argv[1]) : 1;
+	sqrt_fn cmsis = NULL;
+	if (argc > 2)
+	{
+		void *h = dlopen(argv[2], RTLD_LAZY | RTLD_LOCAL);
+		cmsis = h ? (sqrt_fn)dlsym(h, "q15ref_sqrt_q31_one") : NULL;
+		if (!cmsis) { fprintf(stderr, "cannot load q15ref_sqrt_q31_one from %s: %s\n", argv[2], dlerror()); return 2; }
+	}
 	int64_t n_fast = 0, n_bitmap = 0, n_bitmap_minus = 0, n_slow = 0, bad = 0;
 #pragma omp parallel for schedule(static) reduction(+ : n_fast, n_bitmap, n_bitmap_minus, n_slow, bad)
-	for (int64_t x = 1; x < ((int64_t)1 << 31); x++)
+	for (int64_t x = 1; x < ((int64_t)1 << 31); x += stride)
 	{
 		int64_t c = (int64_t)floor(sqrt((double)x * 0.5));
 		while (2 * c * c > x) c--;
 		while (2 * (c + 1) * (c + 1) <= x) c++;
 		const int64_t d = x - 2 * c * c, t = c >> 11;
-		const int mag = ref((int32_t)x) >> 16;
+		const int mag = (cmsis ? cmsis((int32_t)x) : ref((int32_t)x)) >> 16;
 		/* the kernel's unsigned form of claim 1 */
 		const uint32_t u = (uint32_t)d + ~(uint32_t)t, bound = 4u * (uint32_t)c + 1u - 2u * (uint32_t)t;
 		const int fast = u < bound;
@@ -55,6 +68,8 @@ int main(void)
 		else if (d == 0) { n_bitmap++; if (mag == c - 1) n_bitmap_minus++; else if (mag != c) bad++; }
 		else n_slow++;
 	}
+	printf("stride %lld, authority = %s: ", (long long)stride,
+	       cmsis ? "reference object code (arm_sqrt_q31 compiled from the reference)" : "the restated sequence");
 	printf("fast path %lld, bitmap %lld (of which c-1: %lld), full routine %lld, violations %lld\n", (long long)n_fast,
 	       (long long)n_bitmap, (long long)n_bitmap_minus, (long long)n_slow, (long long)bad);
 	return bad != 0;
