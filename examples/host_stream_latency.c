@@ -37,8 +37,9 @@ int main(int argc, char **argv)
 	const int warm = 100;
 	if (pushes < 1 || pushes > 1000000 || hop < 2 || hop > EDISON_FRAME_LEN) { fprintf(stderr, "bad arguments\n"); return 2; }
 
-	edison_ctx *ctx = NULL;
-	if (edison_init(0, &ctx) != EDISON_OK) { fprintf(stderr, "edison_init failed (no gfx950 device?)\n"); return 1; }
+	/* the firmware's own bring-up call (ai.c:112): context on GPU 0 (EDISON_DEVICE) + the shipped model (EDISON_MODEL) */
+	if (aiInitialize() != 0) { fprintf(stderr, "aiInitialize failed (no gfx950 device / model?)\n"); return 1; }
+	edison_ctx *ctx = edison_global_ctx();
 	edison_stream_opts o;
 	edison_stream_default_opts(&o);
 	o.hop = hop;
@@ -78,7 +79,6 @@ int main(int argc, char **argv)
 	       lat[pushes / 2], lat[(size_t)(pushes * 0.9)], lat[(size_t)(pushes * 0.99)], pushes, hop, graph,
 	       aiGetKeywordFromIndex((uint32_t)(am < 0 ? 0 : am)));
 	edison_stream_destroy(s);
-	edison_shutdown(ctx);
 	free(audio);
 	free(lat);
 	return 0;
