@@ -392,11 +392,51 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
 #ifndef ED2_UNPACK_SB
 #define ED2_UNPACK_SB 0   /* 1: scheduling barrier between the unpack and the next pair's loads */
 #endif
+#ifndef ED2_LOG_BRANCH
+#define ED2_LOG_BRANCH 1  /* 1: ln() of the mel energies sits behind a wave-uniform branch; if-converted (the compiler's choice) variant B
+                           * executes the whole logf expansion, 15 vector instructions per pair, for a select that never takes it */
+#endif
+#ifndef ED2_ASM_QUEUE
+#define ED2_ASM_QUEUE 1   /* 1: the work-queue draw is one exec-masked ds_add_rtn_u32 written in asm. The builtin atomic goes through the
+                           * compiler's wave-aggregation scheme (v_mbcnt x 2, s_bcnt1, readfirstlane, two exec-mask blocks) and waits for
+                           * the LDS round trip on the spot */
+#endif
+#ifndef ED2_LATE_BARRIER
+#define ED2_LATE_BARRIER 0 /* 1: the workgroup barrier behind the table staging moves into a wave's FIRST iteration, in front of the first
+                            * use of the LDS tables (the split twiddles): a wave starts its first passes as soon as ITS OWN samples have
+                            * arrived instead of when the slowest of the 12 waves' have (48 KB per CU at ~10 B/clk = 2 us after launch) */
+#endif
+#ifndef ED2_STAGGER
+#define ED2_STAGGER 1     /* 1: no workgroup barrier behind the table staging. The first four waves of the workgroup (one per SIMD) stage
+                           * the tables and raise a counter in LDS; every wave checks that counter once, in front of its first use of the
+                           * tables (the split of its first pair), by which time it has long been raised. Wave groups 1 and 2 issue their
+                           * first sample loads a few hundred cycles later than group 0, so that group 0's samples are not queued behind
+                           * theirs: a SIMD starts computing ~1.5 us after launch instead of when the last of the CU's 48 KB has arrived. */
+#endif
+#ifndef ED2_LATE_DRAW
+#define ED2_LATE_DRAW 1   /* 1: a wave owns TWO pairs at a time (the one it computes and the one whose samples it prefetches) instead of
+                           * three: the draw is issued at the top of an iteration, read behind pass 1, and the prefetch of the drawn pair
+                           * goes out there. With the draw a whole iteration ahead, the last 24 pairs of a CU sat reserved in the youngest
+                           * (slowest) waves while the older ones had retired: loop ends 38 .. 46 us after launch (stamps). Needs
+                           * ED2_CVT_END and ED2_ASM_QUEUE. */
+#endif
+#ifndef ED2_STAGGER_SLEEP
+#define ED2_STAGGER_SLEEP 8 /* s_sleep units (64 cycles each) per wave group */
+#endif
+#ifndef ED2_CVT_END
+#define ED2_CVT_END 1     /* 1: the int16 -> float unpack of the NEXT pair runs at the bottom of an iteration, so the values carried
+                           * around the loop are the 32 floats the passes start from. With the unpack at the top the compiler sinks it
+                           * below the prefetch, gives the prefetch a second set of 16 registers and copies it back at the loop latch
+                           * (16 v_mov_b32 per pair). */
+#endif
 
 /* Diagnostic build only (-DED2_STAMP=1, tools/lab): s_memtime stamps at the phase boundaries of ed_mfcc2_kernel; per-wave
  * cycle sums per phase go to a debug buffer that nothing else reads. The product build contains no stamp. */
 #ifndef ED2_STAMP
 #define ED2_STAMP 0
+#endif
+#if ED2_LATE_DRAW && !(ED2_CVT_END && ED2_ASM_QUEUE)
+#error "ED2_LATE_DRAW needs ED2_CVT_END and ED2_ASM_QUEUE"
 #endif
 #if ED2_STAMP
 #define ED2_NPH 17
@@ -464,6 +504,8 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 	const float4 *melw4 = reinterpret_cast<const float4 *>(smem + ED_FIXTAB_FLOATS); /* [NLO+NHI][64] quads      */
 	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_TWTAB_FLOATS + wave * ED2_XBUF_FLOATS; /* wave-private */
 	unsigned *queue = reinterpret_cast<unsigned *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_TWTAB_FLOATS + ED2_WPB * ED2_XBUF_FLOATS);
+	const uint32_t queue_addr = (uint32_t)(sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_TWTAB_FLOATS + ED2_WPB * ED2_XBUF_FLOATS)); /* its LDS byte address (dynamic LDS starts at 0: the kernel has no static LDS) */
+	(void)queue_addr;
 #if ED2_STAMP
 	unsigned long long rt_entry;
 	asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_entry) :: "memory");
@@ -476,6 +518,13 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 	const uint32_t cnt = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_pairs) / gridDim.x) - s0;
 	uint32_t i_cur = wave, i_next = wave + ED2_WPB;
 	uint32_t rawA[8], rawB[8];
+#if ED2_STAGGER
+	/* queue and staging counter are initialised behind a barrier that costs nothing: no wave has asked memory for anything yet */
+	if (threadIdx.x == 0) { queue[0] = (ED2_LATE_DRAW ? 1 : 2) * ED2_WPB; queue[1] = 0; }
+	__syncthreads();
+	if (wave >= 4) __builtin_amdgcn_s_sleep(ED2_STAGGER_SLEEP);
+	if (wave >= 8) __builtin_amdgcn_s_sleep(ED2_STAGGER_SLEEP);
+#endif
 #if !ED2_TABLES_FIRST
 	if (i_cur < cnt)
 	{
@@ -547,6 +596,29 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 			if (ED2_MEL_SWAP && t >= ED_FIXTAB_FLOATS / 4 && mel_half) v = make_float4(v.z, v.w, v.x, v.y);
 			if (t < n4) dst[t] = v;
 		}
+#elif ED2_STAGGER
+		if (wave < 4)
+		{
+			/* thread t of the first 256 stages quads t, t + 256, t + 512: quad <-> lane mapping as above (256 % 64 == 0) */
+			constexpr int NT = (n4 + 255) / 256;
+			float4 tv[NT];
+#pragma unroll
+			for (int k = 0; k < NT; k++)
+			{
+				const int t = threadIdx.x + k * 256;
+				tv[k] = src[t < n4 ? t : 0];
+			}
+#pragma unroll
+			for (int k = 0; k < NT; k++)
+			{
+				const int t = threadIdx.x + k * 256;
+				float4 v = tv[k];
+				if (ED2_MEL_SWAP && t >= ED_FIXTAB_FLOATS / 4 && mel_half) v = make_float4(v.z, v.w, v.x, v.y);
+				if (t < n4) dst[t] = v;
+			}
+			/* this wave's stores are complete (release) before its count: a wave's DS operations execute in order */
+			if (lane == 0) __hip_atomic_fetch_add(queue + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
 #else
 		for (int t = threadIdx.x; t < n4; t += 64 * ED2_WPB)
 		{
@@ -555,9 +627,15 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 			dst[t] = v;
 		}
 #endif
-		if (threadIdx.x == 0) *queue = 2 * ED2_WPB;
+#if !ED2_STAGGER
+		if (threadIdx.x == 0) *queue = (ED2_LATE_DRAW ? 1 : 2) * ED2_WPB;
+#endif
 	}
+#if ED2_LATE_BARRIER || ED2_STAGGER
+	bool staged = false;
+#else
 	__syncthreads();
+#endif
 	/* where this lane puts its DCT input (float index into Lb2 = float2 u[16] | v[16]): rows 0/1 hold frame A's
 	 * u/v of the column's band, rows 2/3 frame B's */
 	const int l_idx = 2 * (16 * ((lane >> 4) & 1) + band) + (lane >> 5);
@@ -577,12 +655,24 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 	const unsigned long long tfirst = ed2_now();
 	unsigned long long tlast = tfirst;
 #endif
+	ed_f2 re[8], im[8];
+#if ED2_CVT_END
+	if (i_cur < cnt)
+	{
+#pragma unroll
+		for (int a = 0; a < 8; a++)
+		{
+			re[a] = ed_mk2((float)(int16_t)(rawA[a] & 0xffffu), (float)(int16_t)(rawB[a] & 0xffffu));
+			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
+		}
+	}
+#endif
 	while (i_cur < cnt)
 	{
 		const uint32_t fA = 2 * (s0 + i_cur);
 		const bool haveB = fA + 1 < n_frames;
 		/* ---- 1. unpack both frames, put the next pair's loads in flight, draw the pair after next */
-		ed_f2 re[8], im[8];
+#if !ED2_CVT_END
 #pragma unroll
 		for (int a = 0; a < 8; a++)
 		{
@@ -590,8 +680,9 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
 			if (ED2_SKIP & 256) { re[a] = ed_mk2(__uint_as_float(rawA[a]), __uint_as_float(rawB[a])); im[a] = re[a]; }
 		}
+#endif
 		if (ED2_UNPACK_SB) __builtin_amdgcn_sched_barrier(0);
-		if (!(ED2_ABLATE & 1))
+		if (!(ED2_ABLATE & 1) && !ED2_LATE_DRAW)
 		{
 			/* unconditional: a conditional load makes the frame registers a merge of two definitions and costs 16
 			 * copies per iteration; a wave's last iteration re-reads the slice's last pair instead (L2 hits) */
@@ -601,7 +692,12 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 			ed_load_frame<ALIGNED>(pb, lane, rawB);
 		}
 		uint32_t drawn = 0;
+#if ED2_ASM_QUEUE
+		if (lane == 0)
+			asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(drawn) : "v"(queue_addr), "v"(1u) : "memory");
+#else
 		if (lane == 0) drawn = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 		if (ED2_ABLATE & 1)
 		{
 #pragma unroll
@@ -637,6 +733,19 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 			re[q] = xr * wr - xi * wi;
 			im[q] = xr * wi + xi * wr;
 		}
+#if ED2_LATE_DRAW
+		{
+			/* the draw issued at the top has returned (~450 cycles of pass 1 ago): the drawn pair's samples go in flight now
+			 * and have the rest of the iteration to arrive. Unconditional (see above): past the end of the slice the last
+			 * pair is re-read from L2 and thrown away. */
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(drawn));
+			i_next = __builtin_amdgcn_readfirstlane(drawn);
+			const int16_t *pa, *pb;
+			ed_pair_ptrs<PLAIN>(args, s0 + (i_next < cnt ? i_next : cnt - 1), pa, pb);
+			ed_load_frame<ALIGNED>(pa, lane, rawA);
+			ed_load_frame<ALIGNED>(pb, lane, rawB);
+		}
+#endif
 		ED2_ST(1)
 #if ED2_T1_LDS
 		/* transpose 1 through LDS: (lane 8b+c, reg p) -> (lane 8p+c, reg b); slot 64b + 8p + c: the ds_write_b128 of a
@@ -695,6 +804,17 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		if (!(ED2_SKIP & 4)) ed_radix8_2(re, im);
 
 		ED2_ST(5)
+#if ED2_STAGGER
+		if (!staged)
+		{
+			/* first use of the LDS tables (split twiddles, then mel, DCT): all four staging waves must have counted */
+			while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(queue + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < 4u)
+				__builtin_amdgcn_s_sleep(1);
+			staged = true;
+		}
+#elif ED2_LATE_BARRIER
+		if (!staged) { __syncthreads(); staged = true; } /* first use of the LDS tables (split twiddles, then mel, DCT) */
+#endif
 		/* ---- 3. real-FFT split (see ed_mfcc_kernel); the partner values come per frame through ds_bpermute */
 		ed_f2 slo[4], shi[4];
 		ed_f2 pzr_[4], pzi_[4];
@@ -789,7 +909,11 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		ED2_ST(8)
 		const ed_f2 plo = alo0 + alo1, phi = ahi0 + ahi1;
 		float t = ed_fold_rows(ed_fold_halves(plo.x, plo.y), ed_fold_halves(phi.x, phi.y));
+#if ED2_LOG_BRANCH
+		if (do_log) { asm volatile(""); t = __logf(t + log_offset); } /* the empty asm keeps this a branch (wave-uniform) */
+#else
 		if (do_log) t = __logf(t + log_offset);
+#endif
 
 		ED2_ST(9)
 		/* ---- 6. DCT-II through cos symmetry, both frames: u = L[b] + L[31-b] (even rows), v = L[b] - L[31-b] (odd) */
@@ -823,8 +947,30 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 			if (args.feat) args.feat[at] = (int8_t)__float2int_rn(fminf(fmaxf(coef * args.feat_scale, -128.0f), 127.0f));
 		}
 		ED2_ST(11)
+#if ED2_CVT_END
+		/* the next pair's samples (requested at the top of this iteration) become the floats the next iteration starts from */
+#pragma unroll
+		for (int a = 0; a < 8; a++)
+		{
+			re[a] = ed_mk2((float)(int16_t)(rawA[a] & 0xffffu), (float)(int16_t)(rawB[a] & 0xffffu));
+			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
+			if (ED2_SKIP & 256) { re[a] = ed_mk2(__uint_as_float(rawA[a]), __uint_as_float(rawB[a])); im[a] = re[a]; }
+		}
+#endif
+#if ED2_LATE_DRAW
+		i_cur = i_next;
+#else
+#if ED2_ASM_QUEUE
+		/* the draw was issued ~2 800 cycles ago and every later LDS read of this wave has returned behind it (a wave's DS
+		 * operations complete in order); the compiler does not know about it, hence the explicit (free) wait */
+		asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(drawn));
+#endif
 		i_cur = i_next; i_next = __builtin_amdgcn_readfirstlane(drawn);
+#endif
 	}
+#if ED2_LATE_BARRIER && !ED2_STAGGER
+	if (!staged) __syncthreads(); /* a wave without a single pair: the workgroup still waits for its part of the tables */
+#endif
 #if ED2_STAMP
 	asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) :: "memory");
 	ph[12] = ed2_now() - tfirst; ph[13] = rt1 - rt0; ph[14] = rt_entry; ph[15] = rt0; ph[16] = rt1;

@@ -48,6 +48,15 @@ t_first = d[:, 14].min()
 print("launch timeline (us after the first wave's entry): last entry %.2f | loop start median %.2f max %.2f | loop end median %.2f max %.2f | loop length median %.2f max %.2f" % (
     (d[:, 14].max() - t_first) / 100, (np.median(d[:, 15]) - t_first) / 100, (d[:, 15].max() - t_first) / 100, (np.median(d[:, 16]) - t_first) / 100,
     (d[:, 16].max() - t_first) / 100, np.median(d[:, 16] - d[:, 15]) / 100, (d[:, 16] - d[:, 15]).max() / 100))
+# per workgroup (= per CU): when its last wave left the loop, when its first wave entered it
+nb = nw // a.wpb
+bend = (d[:nb * a.wpb, 16].reshape(nb, a.wpb).max(axis=1) - t_first) / 100
+bstart = (d[:nb * a.wpb, 15].reshape(nb, a.wpb).min(axis=1) - t_first) / 100
+print("per workgroup: last wave out of the loop, us, percentiles 0/5/25/50/75/95/100: %s" % " ".join("%.1f" % np.percentile(bend, q) for q in (0, 5, 25, 50, 75, 95, 100)))
+print("per workgroup: first wave into the loop, us, percentiles 0/5/50/95/100: %s" % " ".join("%.1f" % np.percentile(bstart, q) for q in (0, 5, 50, 95, 100)))
+print("per workgroup: busy span (last out - first in), us, percentiles 0/5/50/95/100: %s" % " ".join("%.1f" % np.percentile(bend - bstart, q) for q in (0, 5, 50, 95, 100)))
+print("  corr(first in, last out) = %.2f; by blockIdx %% 8 median last-out: %s" % (np.corrcoef(bstart, bend)[0, 1], " ".join("%.1f" % np.median(bend[np.arange(nb) % 8 == x]) for x in range(8))))
+print("  by (blockIdx // 8) %% 4 median last-out: %s" % " ".join("%.1f" % np.median(bend[(np.arange(nb) // 8) % 4 == x]) for x in range(4)))
 pairs = a.frames / 2 / len(d)
 print("waves %d, pairs per wave %.2f, stamped loop cycles per wave (median) %.0f, in-kernel clock %.3f GHz" % (
     len(d), pairs, np.median(d[:, 12]), np.median(d[:, 12] / d[:, 13]) * 0.1))
