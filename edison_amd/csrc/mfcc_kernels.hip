@@ -808,7 +808,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		if (!staged)
 		{
 			/* first use of the LDS tables (split twiddles, then mel, DCT): all four staging waves must have counted */
-			while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(queue + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < 4u)
+			while ((uint32_t)__builtin_amdgcn_readfirstlane(__hip_atomic_load(queue + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < 4u)
 				__builtin_amdgcn_s_sleep(1);
 			staged = true;
 		}
