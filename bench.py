@@ -43,7 +43,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.2
 # 32.0 cycles, profiles/r02_ubench_mfma_valu_coexec.txt) x 1024 SIMDs x 2.4 GHz x 2 op/MAC
 MFMA_I8_PEAK_TOPS = 1024 * 1024 * 2.4e9 * 2 / 1e12
 CNN_MACS_PER_UTT = 784752         # NNoM compile log / SURVEY.md A.2
-CNN_MFMA_PER_UTT = 167 / 4.0      # v_mfma_i32_32x32x32_i8 issued per utterance (cnn_mfma_kernels.hip; counter: profiles/r02_cnn_counters.txt)
+# MACs the issued MFMAs of ed_cnn_mfma_kernel can do, per utterance: per group of 4 utterances 146 v_mfma_i32_32x32x32_i8 (conv1-3)
+# and 20 v_mfma_i32_16x16x64_i8 (conv4, dense) -- cnn_mfma_kernels.hip; counters: profiles/r03_cnn_counters.txt
+CNN_MFMA_MACS_PER_UTT = (146 * 32768 + 20 * 16384) / 4.0
 MFCC_BYTES_PER_FRAME = 2048 + 52  # 1024 int16 in + 13 fp32 out
 MFCC_KERNEL = "ed_mfcc2_kernel<true, true, 2, 5>"          # the instantiation a plain 65 536-frame batch of variant B runs
 MFCC_KERNEL_KWS = "ed_mfcc2_kernel<true, false, 2, 5>"     # ... and the grouped one (31 frames per utterance)
@@ -657,12 +659,12 @@ def main():
             ctx.cnn_t(feat, nu, logits=logits, softmax=soft, argmax=am)
         c_ms, cev_ms = timed_region(cnn_step, max(100, min(args.steps, 200)), 20, 1 if world == 1 else world)  # 0.3 ms steps: 100 of them = 30 ms
         useful = nu * CNN_MACS_PER_UTT * 2 / (cev_ms * 1e-3) / 1e12
-        issued = nu * CNN_MFMA_PER_UTT * 32768 * 2 / (cev_ms * 1e-3) / 1e12
+        issued = nu * CNN_MFMA_MACS_PER_UTT * 2 / (cev_ms * 1e-3) / 1e12
         kws["cnn"] = dict(metric="int8 CNN alone (ed_cnn_mfma_kernel)", value=round(world * nu / (c_ms * 1e-3), 1), unit="inferences/s",
                           ms_per_step=round(c_ms, 4),
                           roofline=dict(bound="mfma_i8", kernel="ed_cnn_mfma_kernel", achieved=round(useful, 1), peak=round(MFMA_I8_PEAK_TOPS, 1),
                                         unit="TOP/s", frac=round(useful / MFMA_I8_PEAK_TOPS, 4), kernel_ms=round(cev_ms, 4),
-                                        what="achieved = real network MACs (784 752 per utterance) x 2; issued = MFMA instructions x 32 768 MAC x 2",
+                                        what="achieved = real network MACs (784 752 per utterance) x 2; issued = the MACs of the MFMA instructions issued (32 768 per 32x32x32, 16 384 per 16x16x64) x 2",
                                         issued=round(issued, 1), issued_frac=round(issued / MFMA_I8_PEAK_TOPS, 4),
                                         counters=cnn_counters_from_profiles()))
         # ---- the same graph through the GENERAL matrix-core kernel (what any other retrained graph runs on)

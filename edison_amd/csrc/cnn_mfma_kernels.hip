@@ -44,8 +44,19 @@
 #define EDM_G 4       /* utterances per wavefront group */
 #define EDM_WAVES 8
 #define EDM_THREADS (64 * EDM_WAVES)
-#define EDM_REGA 1120 /* in' [31][16] (496)  ->  p2 [5][7][32] (1120)  ->  c4 [3][32] (96)   */
-#define EDM_REGB 1872 /* p1 [13][9][16] (1872)  ->  c3 [3][5][64] (960)                        */
+/* Region A: in' = the 31 input rows padded to 16 bytes, EVEN rows then ODD rows (2 x 16 slots of 16 B = 512)  ->
+ *           p2 = conv2's pooled output [5][7] pixels as TWO PLANES of 16 channels (2 x 35 slots = 1120)  ->  c4 [3][32] (96)
+ * Region B: p1 [13][9][16] (1872)  ->  c3 = conv3's output [3][5] pixels as FOUR PLANES of 16 channels (4 x 15 slots = 960)
+ * Planes instead of pixel-major records: a B operand is 16 bytes (16 channels of one tap) per lane, and the lanes of a
+ * ds_read_b128 group are neighbouring columns = neighbouring pixels. With [pixel][32 or 64 channels] records they sat 32 / 64
+ * bytes apart and used every second / fourth 16-byte bank group: 2-way (conv1's row pairs, conv3) and 4-way (conv4) bank
+ * conflicts on every operand read, 39 % of all LDS cycles (profiles/r02_cnn_counters.txt). In a plane neighbouring pixels
+ * are neighbouring 16-byte slots. */
+#define EDM_REGA 1120
+#define EDM_REGB 1872
+#define EDM_IN_ODD 256   /* byte offset of the odd input rows inside region A */
+#define EDM_P2_PLANE 560 /* bytes per 16-channel plane of p2 */
+#define EDM_C3_PLANE 240 /* bytes per 16-channel plane of c3 */
 #define EDM_UTT (EDM_REGA + EDM_REGB)
 #define EDM_PARK 8    /* groups whose logits are parked before one softmax pass (8 x 4 = 32 lanes) */
 #define EDM_WAVE_LDS (EDM_G * EDM_UTT + EDM_PARK * EDM_G * 16 + 64)
@@ -59,13 +70,30 @@ __device__ __forceinline__ int edm_med3(int v, int lo, int hi) { return v < lo ?
 
 /* requantise 4 consecutive accumulators with ReLU and pack them into one HWC dword. The accumulators already hold the
  * seeds (bias << bias_lshift) + NN_ROUND(out_rshift): they are the C operand of each tile's first MFMA. */
+#ifndef EDM_SAT_PACK
+#define EDM_SAT_PACK 1
+#endif
 __device__ __forceinline__ uint32_t edm_pack_relu(int a0, int a1, int a2, int a3, int rs)
 {
+#if EDM_SAT_PACK
+	/* relu(ssat8(a >> rs)) = clamp(a >> rs, 0, 127) = clamp(a >> (rs - 1), 0, 255) >> 1 for rs >= 1 (arithmetic shifts compose
+	 * and 255 >> 1 = 127), and the clamp to 0..255 of two values at a time is what v_cvt_pk_i16_i32 (saturating to int16:
+	 * harmless in front of a tighter clamp) followed by v_sat_pk_u8_i16 does: 4 shifts + 2 + 2 + one merge + shift and mask
+	 * of the whole dword = 11 instructions, 7 of them in the cheap 4-byte encodings, against 4 shifts + 4 v_med3 + 3 merges
+	 * (7 in 8-byte encodings). The kernel is bound by vector issue beside the MFMAs, not by the MFMAs. */
+	typedef short s2 __attribute__((ext_vector_type(2)));
+	const s2 p01 = __builtin_amdgcn_cvt_pk_i16(a0 >> (rs - 1), a1 >> (rs - 1)), p23 = __builtin_amdgcn_cvt_pk_i16(a2 >> (rs - 1), a3 >> (rs - 1));
+	uint32_t q01, q23;
+	asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q01) : "v"(p01));
+	asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q23) : "v"(p23));
+	return (((q23 << 16) | q01) >> 1) & 0x7f7f7f7fu;
+#else
 	const uint32_t b0 = (uint32_t)edm_med3(a0 >> rs, 0, 127);
 	const uint32_t b1 = (uint32_t)edm_med3(a1 >> rs, 0, 127);
 	const uint32_t b2 = (uint32_t)edm_med3(a2 >> rs, 0, 127);
 	const uint32_t b3 = (uint32_t)edm_med3(a3 >> rs, 0, 127);
 	return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+#endif
 }
 
 /* the accumulator tile that starts a 32-row output tile: D register r of lane half h is row (r&3) + 8*(r>>2) + 4*h, so
@@ -215,7 +243,7 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 			{
 				const int u = r / ED_IN_H, y = r - u * ED_IN_H;
 				const int64_t b_cur = (g_lo + idx) * EDM_G;
-				*reinterpret_cast<uint4 *>(acts + u * EDM_UTT + y * 16) =
+				*reinterpret_cast<uint4 *>(acts + u * EDM_UTT + (y & 1) * EDM_IN_ODD + (y >> 1) * 16) =
 				    edm_fix_row(rows[pass], b_cur, (int)((n_utt - b_cur) < EDM_G ? (n_utt - b_cur) : EDM_G), n_utt, r);
 			}
 		}
@@ -248,14 +276,15 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 				const bool live = q < EDM_G * 13;
 				const int qq = live ? q : EDM_G * 13 - 1; /* idle columns recompute the last one and store nothing */
 				const int u = qq / 13, py = qq - u * 13;
-				const unsigned char *inb = acts + u * EDM_UTT + (2 * py) * 16;
+				const unsigned char *inb = acts + u * EDM_UTT + py * 16; /* row 2 py of the even plane; row 2 py + 1 of the odd plane is EDM_IN_ODD further */
 				v4i be[3], bo[3];
 #pragma unroll
 				for (int s = 0; s < 3; s++)
 				{
-					const int c = (2 * s + h) < 4 ? (2 * s + h) : 4; /* k-chunk = input row y + c; chunk 5 meets zero weights */
-					be[s] = edm_ld16(inb + c * 16);
-					bo[s] = edm_ld16(inb + (c + 1) * 16);
+					const int c = (2 * s + h) < 4 ? (2 * s + h) : 4; /* k-chunk = input row 2 py + c; chunk 5 meets zero weights */
+					/* row r lies in plane r & 1 at slot r >> 1 */
+					be[s] = edm_ld16(inb + (c & 1) * EDM_IN_ODD + (c >> 1) * 16);
+					bo[s] = edm_ld16(inb + ((c + 1) & 1) * EDM_IN_ODD + ((c + 1) >> 1) * 16);
 				}
 				unsigned char *p1 = acts + u * EDM_UTT + EDM_REGA + (py * 9) * 16;
 				/* software pipeline: the MFMAs of row tile rt + 1 are issued BEFORE the requantisation of row tile rt, so
@@ -313,7 +342,7 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 				const int qq = live[t % 3] ? q : EDM_G * 35 - 1;
 				const int u = qq / 35, r = qq - u * 35, py = r / 7, x = r - py * 7;
 				const unsigned char *p1 = acts + u * EDM_UTT + EDM_REGA + ((2 * py) * 9 + x) * 16;
-				p2[t % 3] = acts + u * EDM_UTT + (py * 7 + x) * 32;
+				p2[t % 3] = acts + u * EDM_UTT + (py * 7 + x) * 16; /* plane h is EDM_P2_PLANE * h further */
 #pragma unroll
 				for (int s = 0; s < 5; s++)
 				{
@@ -349,7 +378,7 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 						d[g] = edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
 						                     edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs2);
 					const uint4 rec = edm_gather16(d[0], d[1], d[2], d[3]); /* channels 16h .. 16h + 15 */
-					*reinterpret_cast<uint4 *>(live[t % 3] ? p2[t % 3] + 16 * h : dummy) = rec;
+					*reinterpret_cast<uint4 *>(live[t % 3] ? p2[t % 3] + EDM_P2_PLANE * h : dummy) = rec;
 				}
 				if (t + 1 < 5) { EDM_WEAVE(10, 7) }
 				__builtin_amdgcn_sched_barrier(0);
@@ -369,14 +398,14 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 				live[slot] = q < EDM_G * 15;
 				const int qq = live[slot] ? q : EDM_G * 15 - 1;
 				const int u = qq / 15, r = qq - u * 15, y = r / 5, x = r - y * 5;
-				const unsigned char *p2 = acts + u * EDM_UTT + (y * 7 + x) * 32 + 16 * h;
-				c3[slot] = acts + u * EDM_UTT + EDM_REGA + (y * 5 + x) * 64;
+				const unsigned char *p2 = acts + u * EDM_UTT + EDM_P2_PLANE * h + (y * 7 + x) * 16;
+				c3[slot] = acts + u * EDM_UTT + EDM_REGA + (y * 5 + x) * 16; /* plane j (channels 16 j ..) is EDM_C3_PLANE * j further */
 				a0[slot] = seed3a; a1[slot] = seed3b;
 #pragma unroll
 				for (int s = 0; s < 9; s++)
 				{
 					const int ky = s / 3, kx = s - 3 * ky;
-					const v4i b = edm_ld16(p2 + (ky * 7 + kx) * 32);
+					const v4i b = edm_ld16(p2 + (ky * 7 + kx) * 16);
 					a0[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(edm_ld16(afrag + a3_off + s * 1024), b, a0[slot], 0, 0, 0);
 					a1[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(edm_ld16(afrag + a3_off + (9 + s) * 1024), b, a1[slot], 0, 0, 0);
 				}
@@ -397,8 +426,8 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 						d1[g] = edm_pack_relu(x1[4 * g], x1[4 * g + 1], x1[4 * g + 2], x1[4 * g + 3], rs3);
 					}
 					const uint4 ra = edm_gather16(d0[0], d0[1], d0[2], d0[3]), rb = edm_gather16(d1[0], d1[1], d1[2], d1[3]);
-					*reinterpret_cast<uint4 *>(live[t & 1] ? c3[t & 1] + 16 * h : dummy) = ra;      /* channels 16h .. */
-					*reinterpret_cast<uint4 *>(live[t & 1] ? c3[t & 1] + 32 + 16 * h : dummy) = rb; /* channels 32 + 16h .. */
+					*reinterpret_cast<uint4 *>(live[t & 1] ? c3[t & 1] + EDM_C3_PLANE * h : dummy) = ra;       /* channels 16h ..: plane h */
+					*reinterpret_cast<uint4 *>(live[t & 1] ? c3[t & 1] + EDM_C3_PLANE * (2 + h) : dummy) = rb; /* channels 32 + 16h ..: plane 2 + h */
 				}
 				if (t + 1 < 2) { EDM_WEAVE(18, 6) }
 				__builtin_amdgcn_sched_barrier(0);
@@ -406,57 +435,52 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 		}
 		edm_wave_sync();
 
-		/* ---- conv4 3x3x64->32 + ReLU: 18 k-steps (tap, 32-channel half, 16-channel lane half); columns =
-		 *      (utt, x): 4 x 3 = 12 in one column tile */
+		/* ---- conv4 3x3x64->32 + ReLU on v_mfma_i32_16x16x64_i8: columns = (utt, x): 4 x 3 = 12 of a 16-column tile, two row
+		 *      tiles of 16 channels, 9 k-steps = taps (64 input channels each: lane quarter kq reads plane kq of c3). A
+		 *      32 x 32 x 32 tile was 5/8 padding here: 18 MFMAs of 32 cycles, now 18 of 16, and 8 accumulators to requantise
+		 *      instead of 16. Lane (col, kq) ends with channels 16 rt + 4 kq .. +3 of its pixel. */
 		{
-			const bool live = col < EDM_G * 3;
-			const int qq = live ? col : EDM_G * 3 - 1;
+			const int c16 = lane & 15, kq = lane >> 4;
+			const bool live = c16 < EDM_G * 3;
+			const int qq = live ? c16 : EDM_G * 3 - 1;
 			const int u = qq / 3, x = qq - u * 3;
-			const unsigned char *c3 = acts + u * EDM_UTT + EDM_REGA + x * 64 + 16 * h;
-			v16i acc = edm_seed_tile(&M.b4[4 * h]);
+			const unsigned char *c3 = acts + u * EDM_UTT + EDM_REGA + EDM_C3_PLANE * kq + x * 16;
+			v4i acc0 = *reinterpret_cast<const v4i *>(&M.b4[4 * kq]), acc1 = *reinterpret_cast<const v4i *>(&M.b4[16 + 4 * kq]);
 #pragma unroll
-			for (int s = 0; s < 18; s++)
+			for (int s = 0; s < 9; s++)
 			{
-				const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
-				const v4i b = edm_ld16(c3 + (ky * 5 + kx) * 64 + 32 * (s & 1));
-				acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(edm_ld16(afrag + a4_off + s * 1024), b, acc, 0, 0, 0);
+				const int ky = s / 3, kx = s - 3 * ky;
+				const v4i b = edm_ld16(c3 + (ky * 5 + kx) * 16);
+				acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(edm_ld16(afrag + a4_off + s * 1024), b, acc0, 0, 0, 0);
+				acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(edm_ld16(afrag + a4_off + (9 + s) * 1024), b, acc1, 0, 0, 0);
 			}
-			unsigned char *c4 = acts + u * EDM_UTT + x * 32;
+			unsigned char *c4 = acts + u * EDM_UTT + x * 32 + 4 * kq; /* c4 [3][32]: channel 16 rt + 4 kq of pixel x */
+			const uint32_t d0 = edm_pack_relu(acc0.x, acc0.y, acc0.z, acc0.w, rs4), d1 = edm_pack_relu(acc1.x, acc1.y, acc1.z, acc1.w, rs4);
+			if (live)
 			{
-				uint32_t d[4];
-#pragma unroll
-				for (int g = 0; g < 4; g++) d[g] = edm_pack_relu(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], rs4);
-				const uint4 rec = edm_gather16(d[0], d[1], d[2], d[3]);
-				if (live) *reinterpret_cast<uint4 *>(c4 + 16 * h) = rec;
+				*reinterpret_cast<uint32_t *>(c4) = d0;
+				*reinterpret_cast<uint32_t *>(c4 + 16) = d1;
 			}
 		}
 		edm_wave_sync();
 
-		/* ---- dense 96->10: one column tile, column = utterance (4 live). Lane (utt, h) holds logits 4h..4h+3 in
-		 *      registers 0-3 and 8+4h.. in registers 4-7 (only rows 8, 9 exist): parked as 10 int8 per utterance */
+		/* ---- dense 96->10, same tile shape: rows = 10 logits of 16, columns = utterances (4 live), K = 96 in two k-steps of
+		 *      64: bytes 0..95 of c4 and 32 bytes behind it that meet zero weights. Lane (utt, kq) holds logits 4 kq .. +3
+		 *      (kq = 2: 8, 9 and two padding rows; kq = 3: padding only): parked as 10 int8 per utterance */
 		{
-			const int uu = col < EDM_G ? col : EDM_G - 1;
-			const unsigned char *c4 = acts + uu * EDM_UTT + 16 * h;
-			v16i acc = {0};
+			const int c16 = lane & 15, kq = lane >> 4;
+			const int uu = c16 < EDM_G ? c16 : EDM_G - 1;
+			const unsigned char *c4 = acts + uu * EDM_UTT + 16 * kq;
+			v4i acc = {0, 0, 0, 0};
 #pragma unroll
-			for (int s = 0; s < 3; s++)
-				acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(edm_ld16(afrag + afc_off + s * 1024), edm_ld16(c4 + 32 * s), acc, 0, 0, 0);
-			if (col < EDM_G)
+			for (int s = 0; s < 2; s++)
+				acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(edm_ld16(afrag + afc_off + s * 1024), edm_ld16(c4 + 64 * s), acc, 0, 0, 0);
+			if (c16 < EDM_G && kq < 3)
 			{
-				uint32_t w = 0;
-#pragma unroll
-				for (int i = 0; i < 4; i++)
-					w |= (uint32_t)(uint8_t)edm_med3((acc[i] + M.bfc[4 * h + i]) >> rsfc, -128, 127) << (8 * i);
-				unsigned char *slot = park + (parked * EDM_G + col) * 16;
-				*reinterpret_cast<uint32_t *>(slot + 4 * h) = w;          /* logits 0-3 (h = 0) / 4-7 (h = 1) */
-				if (h == 0)
-				{
-					uint32_t w2 = 0;
-#pragma unroll
-					for (int i = 0; i < 2; i++)
-						w2 |= (uint32_t)(uint8_t)edm_med3((acc[4 + i] + M.bfc[8 + i]) >> rsfc, -128, 127) << (8 * i);
-					*reinterpret_cast<uint32_t *>(slot + 8) = w2;         /* logits 8, 9 */
-				}
+				const v4i bias = *reinterpret_cast<const v4i *>(&M.bfc[4 * kq]);
+				const uint32_t w = (uint32_t)(uint8_t)edm_med3((acc.x + bias.x) >> rsfc, -128, 127) | ((uint32_t)(uint8_t)edm_med3((acc.y + bias.y) >> rsfc, -128, 127) << 8) |
+				                   ((uint32_t)(uint8_t)edm_med3((acc.z + bias.z) >> rsfc, -128, 127) << 16) | ((uint32_t)(uint8_t)edm_med3((acc.w + bias.w) >> rsfc, -128, 127) << 24);
+				*reinterpret_cast<uint32_t *>(park + (parked * EDM_G + c16) * 16 + 4 * kq) = w; /* logits 4 kq .. 4 kq + 3 (10, 11: unused) */
 			}
 			if (lane == 0) park_group[parked] = (int)idx;
 			parked++;

@@ -174,15 +174,16 @@ typedef struct {
  *       16-byte-padded input rows (K = 80 -> 3 k-steps); A = w1[o][ky][xx - x] inside the 5-tap window, else 0
  *   a2  conv2: 32 rows, k = tap*16 + ci (K = 144 -> 5 k-steps, the last half zero)
  *   a3  conv3: 64 rows (2 row tiles), k = tap*32 + ci (9 k-steps)
- *   a4  conv4: 32 rows, k = tap*64 + ci (18 k-steps)
- *   afc dense: 10 rows padded to 32, k = 96 (3 k-steps)
+ *   a4  conv4: 32 rows, k = tap*64 + ci, as fragments of v_mfma_i32_16x16x64_i8 (lane l: row l & 15, k chunk l >> 4):
+ *       2 row tiles x 9 k-steps (one tap each) -- the layer has 12 columns per wave, a 32-column tile would be 5/8 padding
+ *   afc dense: 10 rows padded to 16, k = 96 padded to 128, the same 16 x 16 x 64 fragments (2 k-steps)
  */
 typedef struct {
 	int8_t a1[15][1024]; /* [row_tile*3 + kstep] */
 	int8_t a2[5][1024];
 	int8_t a3[18][1024]; /* [row_tile*9 + kstep] */
-	int8_t a4[18][1024];
-	int8_t afc[3][1024];
+	int8_t a4[18][1024]; /* [row_tile*9 + tap], 16 x 16 x 64 fragments */
+	int8_t afc[2][1024]; /* 16 x 16 x 64 fragments */
 	int32_t b1[ED_C1_O], b2[ED_C2_O], b3[ED_C3_O], b4[ED_C4_O], bfc[16]; /* accumulator seeds as above */
 	int32_t rs1, rs2, rs3, rs4, rsfc;
 	int32_t pad_[3];

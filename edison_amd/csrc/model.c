@@ -61,7 +61,15 @@ static int8_t a1_elem(const int8_t *w, int row, int k)
 static int8_t a2_elem(const int8_t *w, int row, int k) { return k < 144 ? w[row * 144 + k] : 0; } /* k = tap*16+ci */
 static int8_t a3_elem(const int8_t *w, int row, int k) { return w[row * 288 + k]; }                /* k = tap*32+ci */
 static int8_t a4_elem(const int8_t *w, int row, int k) { return w[row * 576 + k]; }                /* k = tap*64+ci */
-static int8_t afc_elem(const int8_t *w, int row, int k) { return row < ED_FC_O ? w[row * ED_FC_I + k] : 0; }
+static int8_t afc_elem(const int8_t *w, int row, int k) { return row < ED_FC_O && k < ED_FC_I ? w[row * ED_FC_I + k] : 0; }
+
+/* One A-operand fragment of v_mfma_i32_16x16x64_i8: lane l, byte j  <-  a(row0 + (l & 15), 64*kstep + 16*(l >> 4) + j). */
+static void fill_frag16(int8_t *frag, const int8_t *w, a_elem_fn a, int row0, int kstep)
+{
+	for (int l = 0; l < 64; l++)
+		for (int j = 0; j < 16; j++)
+			frag[l * 16 + j] = a(w, row0 + (l & 15), 64 * kstep + 16 * (l >> 4) + j);
+}
 
 int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, ed_cnn_mfma_model_t *out_mfma, char *err,
                    size_t err_cap)
@@ -131,8 +139,9 @@ int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, ed_
 		for (int s = 0; s < 5; s++) fill_frag(m->a2[s], payload + r[2].v[9], a2_elem, 0, s);
 		for (int rt = 0; rt < 2; rt++)
 			for (int s = 0; s < 9; s++) fill_frag(m->a3[rt * 9 + s], payload + r[4].v[9], a3_elem, 32 * rt, s);
-		for (int s = 0; s < 18; s++) fill_frag(m->a4[s], payload + r[5].v[9], a4_elem, 0, s);
-		for (int s = 0; s < 3; s++) fill_frag(m->afc[s], payload + r[6].v[9], afc_elem, 0, s);
+		for (int rt = 0; rt < 2; rt++)
+			for (int s = 0; s < 9; s++) fill_frag16(m->a4[rt * 9 + s], payload + r[5].v[9], a4_elem, 16 * rt, s);
+		for (int s = 0; s < 2; s++) fill_frag16(m->afc[s], payload + r[6].v[9], afc_elem, 0, s);
 		memcpy(m->b1, out->b1, sizeof(m->b1)); memcpy(m->b2, out->b2, sizeof(m->b2));
 		memcpy(m->b3, out->b3, sizeof(m->b3)); memcpy(m->b4, out->b4, sizeof(m->b4));
 		memcpy(m->bfc, out->bfc, sizeof(m->bfc));

@@ -179,16 +179,20 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 	const int tbl = up16(4 * n_koff) + up16(4 * n_seeds) + up16(8 * n_cols) + up16(8 * n_xtab) + up16(2 * mm->n_intab);
 	if (tbl > 24 * 1024) return EDISON_OK;
 	int batch = 0, waves = 0, frag_lds = 0, frag_mode = 0;
+	/* EDISON_NET_BATCH=b / EDISON_NET_MIN_WAVES=w: A/B knobs (tools/bench_net.py): force the per-wave batch, relax the wave floor */
+	const char *env_b = getenv("EDISON_NET_BATCH"), *env_w = getenv("EDISON_NET_MIN_WAVES");
+	const int force_b = env_b ? atoi(env_b) : 0, min_w = env_w ? atoi(env_w) : 0;
 	for (int mode = 2; mode >= 0 && !batch; mode -= 2)
 	{
 		const int64_t fl = mode == 2 ? (int64_t)frag_bytes : 0;
 		if (fl > 96 * 1024) continue;
 		for (int b = 4; b >= 1 && !batch; b >>= 1)
 		{
+			if (force_b > 0 && b != force_b) continue;
 			const int64_t per_wave = 2 * (int64_t)b * max_img + (int64_t)b * up16(max_x);
 			int64_t w = (lds_cap - tbl - fl) / per_wave;
 			if (w > 12) w = 12; /* the kernel is built for 768 threads: 168 VGPRs a wave */
-			if (w >= (b > 1 ? 8 : 4)) { batch = b; waves = (int)w; frag_lds = (int)fl; frag_mode = mode; }
+			if (w >= (min_w > 0 ? min_w : (b > 1 ? 8 : 4))) { batch = b; waves = (int)w; frag_lds = (int)fl; frag_mode = mode; }
 		}
 	}
 	if (!batch) return EDISON_OK;

@@ -35,12 +35,14 @@ if dur:
     print("kernel duration (median of %d, kernel trace without counters): %.1f us" % (len(dur), d / 1e3))
     n_mfma = c.get("SQ_INSTS_VALU_MFMA_I8", 0)
     busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
-    print("MFMA instructions per utterance: %.2f (v_mfma_i32_32x32x32_i8 = 32 768 MAC each)" % (n_mfma / 262144))
+    # per group of 4 utterances: 146 v_mfma_i32_32x32x32_i8 (32 768 MAC, 32 cycles) + 20 v_mfma_i32_16x16x64_i8 (16 384 MAC, 16 cycles)
+    issued_macs = n_mfma / 166.0 * (146 * 32768 + 20 * 16384)
+    print("MFMA instructions per utterance: %.2f (per group of 4: 146 x 32x32x32 + 20 x 16x16x64 = 166)" % (n_mfma / 262144))
     # SQ_VALU_MFMA_BUSY_CYCLES counts cycles (guide: = 32 x N for a 32-cycle MFMA), summed over the SIMDs
     print("matrix pipe busy cycles per SIMD: %.0f; kernel = %.0f cycles at 2.4 GHz -> pipe busy %.1f %% of the kernel (upper bound of the clock: the busier the lower)" % (
         busy / 1024, d * 2.4, 100 * busy / 1024 / (d * 2.4)))
     print("issued int8 MAC rate: %.2f POP/s (2 op per MAC) = %.1f %% of the 5.03 POP/s dense int8 peak (1024 MAC/clk/SIMD x 1024 SIMDs x 2.4 GHz)" % (
-        n_mfma * 32768 * 2 / (d * 1e-9) / 1e15, 100 * n_mfma * 32768 * 2 / (d * 1e-9) / 5.03e15))
+        issued_macs * 2 / (d * 1e-9) / 1e15, 100 * issued_macs * 2 / (d * 1e-9) / 5.03e15))
     print("useful int8 MAC rate (784 752 MAC per utterance): %.2f POP/s = %.1f %% of peak" % (
         262144 * 784752 * 2 / (d * 1e-9) / 1e15, 100 * 262144 * 784752 * 2 / (d * 1e-9) / 5.03e15))
     import json
