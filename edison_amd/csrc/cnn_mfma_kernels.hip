@@ -186,7 +186,7 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
                                                                  const int8_t *__restrict__ feat, int64_t n_utt,
                                                                  int64_t feat_stride, int8_t *__restrict__ logits,
                                                                  int8_t *__restrict__ softmax,
-                                                                 int32_t *__restrict__ argmax)
+                                                                 int32_t *__restrict__ argmax, unsigned *done_flag, unsigned done_seq)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const ed_cnn_mfma_model_t &M = *reinterpret_cast<const ed_cnn_mfma_model_t *>(smem);
@@ -540,29 +540,58 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 		}
 		idx = next;
 	}
+	/* one-group launches of the microphone path (edison_stream.hip): the wave that did the work tells the host itself, in
+	 * host-mapped memory, behind a system-scope fence -- a command-processor write behind the kernel costs ~2 us more
+	 * (tools/ubench/launch_lat). The launcher passes a flag only when the launch has exactly one group. */
+	if (done_flag && blockIdx.x == 0 && wave == 0)
+	{
+		__threadfence_system();
+		if (lane == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 }
 
-static int g_cnn_mfma_ready = 0;
+/* "the kernel's dynamic-LDS limit has been raised" is a property of the function ON A DEVICE: one flag per device, so that
+ * two contexts on different GPUs of one process both get it */
+static int g_cnn_mfma_ready[16] = {0};
 
 /* feat_stride = bytes between consecutive utterances' feature maps: 403 for packed utterances, 13 for the
  * sliding windows of a stream (window i = feature rows i..i+30 of one long [rows][13] buffer). */
+extern "C" int ed_launch_cnn_mfma_flag(const ed_cnn_mfma_model_t *dev_model, const int8_t *feat, int64_t n_utt,
+                                       int64_t feat_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu,
+                                       hipStream_t stream, unsigned *done_flag, unsigned done_seq, int *flag_written);
+
 extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const int8_t *feat, int64_t n_utt,
                                   int64_t feat_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu,
                                   hipStream_t stream)
 {
+	return ed_launch_cnn_mfma_flag(dev_model, feat, n_utt, feat_stride, logits, softmax, argmax, n_cu, stream, nullptr, 0, nullptr);
+}
+
+/* done_flag (device address of host-mapped memory) / done_seq: written by the kernel behind its outputs when the launch is a
+ * single group (n_utt <= 4); *flag_written tells the caller whether that is the case (else it must signal completion itself) */
+extern "C" int ed_launch_cnn_mfma_flag(const ed_cnn_mfma_model_t *dev_model, const int8_t *feat, int64_t n_utt,
+                                       int64_t feat_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu,
+                                       hipStream_t stream, unsigned *done_flag, unsigned done_seq, int *flag_written)
+{
+	if (flag_written) *flag_written = 0;
 	if (n_utt <= 0) return 0;
 	const size_t lds = sizeof(ed_cnn_mfma_model_t) + (size_t)EDM_WAVES * EDM_WAVE_LDS + 16 /* queue */;
-	if (!g_cnn_mfma_ready)
+	int dev_ = 0;
+	(void)hipGetDevice(&dev_);
+	dev_ &= 15;
+	if (!g_cnn_mfma_ready[dev_])
 	{
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ed_cnn_mfma_kernel),
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return (int)e;
-		g_cnn_mfma_ready = 1;
+		g_cnn_mfma_ready[dev_] = 1;
 	}
 	const int64_t n_groups = (n_utt + EDM_G - 1) / EDM_G;
 	int64_t blocks = (n_groups + EDM_WAVES - 1) / EDM_WAVES;
 	if (blocks > n_cu) blocks = n_cu; /* 157 KB of LDS: one workgroup per CU */
+	unsigned *flag = (done_flag && n_groups == 1) ? done_flag : nullptr;
 	hipLaunchKernelGGL(ed_cnn_mfma_kernel, dim3((unsigned)blocks), dim3(EDM_THREADS), lds, stream, dev_model, feat, n_utt,
-	                   feat_stride, logits, softmax, argmax);
+	                   feat_stride, logits, softmax, argmax, flag, done_seq);
+	if (flag && flag_written) *flag_written = 1;
 	return (int)hipGetLastError();
 }

@@ -811,7 +811,10 @@ extern "C" int ed_launch_net_mfma(const ed_net_plan_t *dev_plan, const ed_mm_pla
 	if (blocks > (int64_t)n_cu * per_cu) blocks = (int64_t)n_cu * per_cu;
 	const int resident = frag_mode == 2;
 	const void *fn = resident ? (const void *)ed_net_mfma_kernel<true> : (const void *)ed_net_mfma_kernel<false>;
-	static int max_lds_set[2] = {0, 0};
+	static int max_lds_set_dev[16][2]; /* per device: the attribute belongs to the function on the current device */
+	int dev_ = 0;
+	(void)hipGetDevice(&dev_);
+	int *max_lds_set = max_lds_set_dev[dev_ & 15];
 	if (lds_bytes > max_lds_set[resident])
 	{
 		/* more than 64 KB of dynamic LDS has to be asked for */

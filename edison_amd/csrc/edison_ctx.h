@@ -19,6 +19,10 @@ extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const in
                                   int64_t feat_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu,
                                   hipStream_t stream);
 
+extern "C" int ed_launch_cnn_mfma_flag(const ed_cnn_mfma_model_t *dev_model, const int8_t *feat, int64_t n_utt,
+                                       int64_t feat_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu,
+                                       hipStream_t stream, unsigned *done_flag, unsigned done_seq, int *flag_written);
+
 extern "C" int ed_launch_net(const ed_net_plan_t *dev_plan, const int8_t *dev_w, const int32_t *dev_seeds, int lds_bytes,
                              const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax,
                              int8_t *acts, int n_cu, hipStream_t stream);
@@ -103,5 +107,21 @@ int ed_ctx_mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, 
 int ed_ctx_mfcc_q15_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
                            int64_t frame_step, int n_coef, int16_t *mfcc_i16, float *mfcc_f32, int8_t *feat, int stages,
                            int16_t *fft, int16_t *spec, int16_t *mel);
+
+/* the same launches on an explicit stream instead of ctx->stream (edison_stream.hip's private streams) */
+int ed_ctx_kws_cnn_launch_on(edison_ctx *ctx, hipStream_t stream, const int8_t *feat, int64_t n_utt, int64_t feat_stride, int8_t *logits,
+                             int8_t *softmax, int32_t *argmax);
+/* ... and, where the specialised kernel runs a single group, let it write `seq` to the host-mapped `flag` behind its outputs;
+ * *flag_written = 0 when the caller has to signal completion itself */
+int ed_ctx_kws_cnn_launch_flag(edison_ctx *ctx, hipStream_t stream, const int8_t *feat, int64_t n_utt, int64_t feat_stride, int8_t *logits,
+                               int8_t *softmax, int32_t *argmax, unsigned *flag, unsigned seq, int *flag_written);
+int ed_ctx_net_launch_on(edison_ctx *ctx, hipStream_t stream, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax,
+                         int32_t *argmax);
+int ed_ctx_mfcc_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
+                          int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
+                          int stages, float *fft, float *spec, float *mel, float *logmel);
+int ed_ctx_mfcc_q15_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
+                              int64_t frame_step, int n_coef, int16_t *mfcc_i16, float *mfcc_f32, int8_t *feat, int stages,
+                              int16_t *fft, int16_t *spec, int16_t *mel);
 
 #endif

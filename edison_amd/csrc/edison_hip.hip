@@ -239,6 +239,15 @@ extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t b
 				if (e == hipSuccess) e = hipMemcpy(ctx->d_mm_frag, frag, (size_t)mm->frag_bytes, hipMemcpyHostToDevice);
 				if (e == hipSuccess) e = hipMemcpy(ctx->d_mm_seeds, mseeds, (size_t)mm->n_seeds * sizeof(int32_t), hipMemcpyHostToDevice);
 				if (e == hipSuccess) { ctx->mm_ok = 1; ctx->mm_lds = mm->lds_bytes; ctx->mm_batch = mm->batch; ctx->mm_waves = mm->waves; ctx->mm_frag_mode = mm->frag_mode; }
+				else
+				{
+					/* the matrix-core plan is an accelerator, not the model: if its upload fails the graph still loads and
+					 * runs on the layer-by-layer kernel */
+					(void)hipGetLastError();
+					if (ctx->d_mm_frag) { (void)hipFree(ctx->d_mm_frag); ctx->d_mm_frag = NULL; }
+					if (ctx->d_mm_seeds) { (void)hipFree(ctx->d_mm_seeds); ctx->d_mm_seeds = NULL; }
+					e = hipSuccess;
+				}
 			}
 			free(mm); free(frag); free(mseeds);
 		}
@@ -323,9 +332,19 @@ static int ensure_scratch(edison_ctx *ctx, size_t bytes)
 }
 
 /* ---------------------------------------------------------------------------------------- hot path, device */
+static int mfcc_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
+                          int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
+                          int stages, float *fft, float *spec, float *mel, float *logmel);
+
+/* on the context's current stream */
 static int mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
                        int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
-                       int stages, float *fft, float *spec, float *mel, float *logmel);
+                       int stages, float *fft, float *spec, float *mel, float *logmel)
+{
+	if (!ctx) return EDISON_E_ARGUMENT;
+	return mfcc_launch_on(ctx, ctx->stream, audio, n_frames, fpg, group_stride, frame_step, variant, n_coef, mfcc, feat, feat_scale,
+	                      stages, fft, spec, mel, logmel);
+}
 
 int ed_ctx_mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
                        int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
@@ -335,9 +354,19 @@ int ed_ctx_mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, 
 	                   stages, fft, spec, mel, logmel);
 }
 
-static int mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
-                       int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
-                       int stages, float *fft, float *spec, float *mel, float *logmel)
+/* the same on an explicit stream (edison_stream.hip: a stream object launches on its private stream without touching
+ * ctx->stream, which another thread's call on the context may be reading) */
+int ed_ctx_mfcc_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
+                          int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
+                          int stages, float *fft, float *spec, float *mel, float *logmel)
+{
+	return mfcc_launch_on(ctx, stream, audio, n_frames, fpg, group_stride, frame_step, variant, n_coef, mfcc, feat, feat_scale,
+	                      stages, fft, spec, mel, logmel);
+}
+
+static int mfcc_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
+                          int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
+                          int stages, float *fft, float *spec, float *mel, float *logmel)
 {
 	const int v = variant & 0xff;
 	if (!ctx || (!audio && n_frames > 0)) return EDISON_E_ARGUMENT;
@@ -347,8 +376,8 @@ static int mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, 
 		 * mfccToNetInput (app.c:680-683), feat = its NNoM branch (app.c:686-694, NNOM_INPUT_SCALE 1) */
 		if ((variant & EDISON_MFCC_USE_LOG) || stages || feat_scale != 1.0f)
 			return set_err(ctx, EDISON_E_NO_IMPL, "variant C: no log, feat_scale 1, stages through edison_mfcc_q15_stages");
-		return ed_ctx_mfcc_q15_launch(ctx, audio, n_frames, fpg, group_stride, frame_step, n_coef, NULL, mfcc, feat, 0,
-		                              NULL, NULL, NULL);
+		return ed_ctx_mfcc_q15_launch_on(ctx, stream, audio, n_frames, fpg, group_stride, frame_step, n_coef, NULL, mfcc, feat, 0,
+		                                 NULL, NULL, NULL);
 	}
 	if (v != EDISON_MFCC_A && v != EDISON_MFCC_B) return set_err(ctx, EDISON_E_ARGUMENT, "unknown MFCC variant");
 	if (n_coef < 1 || n_coef > EDISON_NUM_MEL) return set_err(ctx, EDISON_E_ARGUMENT, "n_coef must be 1..32");
@@ -363,7 +392,7 @@ static int mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, 
 	a.mel_NHI = ctx->mel_NHI[v];
 	a.mfcc = mfcc; a.feat = feat; a.feat_scale = feat_scale;
 	a.fft = fft; a.spec = spec; a.mel = mel; a.logmel = logmel;
-	int e = ed_launch_mfcc(&a, ctx->d_tab[v], stages, ctx->n_cu, ctx->stream);
+	int e = ed_launch_mfcc(&a, ctx->d_tab[v], stages, ctx->n_cu, stream);
 	if (e != 0)
 	{
 		snprintf(ctx->err, sizeof(ctx->err), "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -406,23 +435,41 @@ static int kws_shaped(const ed_net_plan_t *p)
  * keeps the layer-by-layer kernel, for A/B measurements), else the layer-by-layer kernel */
 int ed_ctx_net_launch(edison_ctx *ctx, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax)
 {
+	return ed_ctx_net_launch_on(ctx, ctx->stream, in, n, in_stride, logits, softmax, argmax);
+}
+
+int ed_ctx_net_launch_on(edison_ctx *ctx, hipStream_t stream, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax)
+{
 	static const int no_mfma = getenv("EDISON_NET_NO_MFMA") ? atoi(getenv("EDISON_NET_NO_MFMA")) : 0;
 	if (ctx->mm_ok && !no_mfma)
 		return ed_launch_net_mfma(ctx->d_net_plan, ctx->d_mm_plan, ctx->d_mm_frag, ctx->d_mm_seeds, ctx->mm_lds, ctx->mm_batch, ctx->mm_waves, ctx->mm_frag_mode, in, n,
-		                          in_stride, logits, softmax, argmax, ctx->n_cu, ctx->stream);
+		                          in_stride, logits, softmax, argmax, ctx->n_cu, stream);
 	return ed_launch_net(ctx->d_net_plan, ctx->d_net_w, ctx->d_net_seeds, ctx->net.lds_bytes, in, n, in_stride, logits, softmax, argmax,
-	                     NULL, ctx->n_cu, ctx->stream);
+	                     NULL, ctx->n_cu, stream);
 }
 
 int ed_ctx_kws_cnn_launch(edison_ctx *ctx, const int8_t *feat, int64_t n_utt, int64_t feat_stride, int8_t *logits,
                           int8_t *softmax, int32_t *argmax)
 {
+	return ed_ctx_kws_cnn_launch_on(ctx, ctx->stream, feat, n_utt, feat_stride, logits, softmax, argmax);
+}
+
+int ed_ctx_kws_cnn_launch_on(edison_ctx *ctx, hipStream_t stream, const int8_t *feat, int64_t n_utt, int64_t feat_stride, int8_t *logits,
+                             int8_t *softmax, int32_t *argmax)
+{
+	return ed_ctx_kws_cnn_launch_flag(ctx, stream, feat, n_utt, feat_stride, logits, softmax, argmax, NULL, 0, NULL);
+}
+
+int ed_ctx_kws_cnn_launch_flag(edison_ctx *ctx, hipStream_t stream, const int8_t *feat, int64_t n_utt, int64_t feat_stride, int8_t *logits,
+                               int8_t *softmax, int32_t *argmax, unsigned *flag, unsigned seq, int *flag_written)
+{
+	if (flag_written) *flag_written = 0;
 	if (!ctx->have_model) return set_err(ctx, EDISON_E_NO_MODEL, "no CNN model loaded (edison_model_load)");
 	if (!ctx->fast_model && !kws_shaped(&ctx->net))
 		return set_err(ctx, EDISON_E_SIZE, "the loaded model is not a 31x13x1 -> 10 softmax classifier; use edison_net_batch");
 	int e = ctx->fast_model
-	            ? ed_launch_cnn_mfma(ctx->d_model_mfma, feat, n_utt, feat_stride, logits, softmax, argmax, ctx->n_cu, ctx->stream)
-	            : ed_ctx_net_launch(ctx, feat, n_utt, feat_stride, logits, softmax, argmax);
+	            ? ed_launch_cnn_mfma_flag(ctx->d_model_mfma, feat, n_utt, feat_stride, logits, softmax, argmax, ctx->n_cu, stream, flag, seq, flag_written)
+	            : ed_ctx_net_launch_on(ctx, stream, feat, n_utt, feat_stride, logits, softmax, argmax);
 	if (e != 0)
 	{
 		snprintf(ctx->err, sizeof(ctx->err), "CNN kernel launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -540,10 +587,15 @@ extern "C" int edison_mfcc_rows(edison_ctx *ctx, const int16_t *audio, int64_t n
 	if (n_rows == 0 || frames_per_row == 0) return EDISON_OK;
 	if (n_coef < 1 || n_coef > EDISON_NUM_MEL) return set_err(ctx, EDISON_E_ARGUMENT, "n_coef must be 1..32");
 	if (n_rows > INT32_MAX / frames_per_row) return set_err(ctx, EDISON_E_SIZE, "edison_mfcc_rows: more than 2^31 frames in one call");
+	/* the staging buffer spans (n_rows - 1) * row_stride + the frames of one row: computed in 128 bits, refused beyond 2^46
+	 * samples (a wrapped size_t would allocate a small buffer and let the kernel read past it) */
+	const size_t span = audio_span(frames_per_row, frame_step);
+	const unsigned __int128 na128 = ((unsigned __int128)(n_rows - 1) * (unsigned __int128)row_stride + span) * sizeof(int16_t);
+	if (na128 > ((unsigned __int128)1 << 47)) return set_err(ctx, EDISON_E_SIZE, "edison_mfcc_rows: row_stride x n_rows too large");
 	ED_HIP(ctx, hipSetDevice(ctx->device));
 	dev_buf a, m, q;
 	const size_t n = (size_t)(n_rows * frames_per_row);
-	const size_t na = ((size_t)(n_rows - 1) * (size_t)row_stride + audio_span(frames_per_row, frame_step)) * sizeof(int16_t);
+	const size_t na = (size_t)na128;
 	ED_HIP(ctx, a.alloc(na));
 	if (mfcc) ED_HIP(ctx, m.alloc(n * n_coef * sizeof(float)));
 	if (feat) ED_HIP(ctx, q.alloc(n * n_coef));

@@ -284,8 +284,13 @@ typedef struct {
 	int32_t out_c, rs, lo_clamp;
 	int32_t in_n;               /* Softmax: classes                                                                    */
 	int32_t small;              /* 1: the 16 x 16 x 64 tiles (n_ks / n_rt then count those)                            */
-	int32_t pad_[4];
+	int32_t pad_[2];
 } ed_mm_run_t;
+#if defined(__cplusplus)
+static_assert(sizeof(ed_mm_run_t) == 128, "ed_mm_run_t: one 128-byte record per layer (two s_load_dwordx16)");
+#else
+_Static_assert(sizeof(ed_mm_run_t) == 128, "ed_mm_run_t: one 128-byte record per layer (two s_load_dwordx16)");
+#endif
 
 typedef struct {
 	int32_t ok;                 /* 0: this graph stays on the layer-by-layer kernel (why: the loader's error text)     */

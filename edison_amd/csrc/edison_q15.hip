@@ -13,6 +13,15 @@ int ed_ctx_mfcc_q15_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_fram
                            int64_t frame_step, int n_coef, int16_t *mfcc_i16, float *mfcc_f32, int8_t *feat, int stages,
                            int16_t *fft, int16_t *spec, int16_t *mel)
 {
+	if (!ctx) return EDISON_E_ARGUMENT;
+	return ed_ctx_mfcc_q15_launch_on(ctx, ctx->stream, audio, n_frames, fpg, group_stride, frame_step, n_coef, mfcc_i16, mfcc_f32, feat,
+	                                 stages, fft, spec, mel);
+}
+
+int ed_ctx_mfcc_q15_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
+                              int64_t frame_step, int n_coef, int16_t *mfcc_i16, float *mfcc_f32, int8_t *feat, int stages,
+                              int16_t *fft, int16_t *spec, int16_t *mel)
+{
 	if (!ctx || (!audio && n_frames > 0)) return EDISON_E_ARGUMENT;
 	if (n_coef < 1 || n_coef > EDISON_NUM_MEL) return ed_set_err(ctx, EDISON_E_ARGUMENT, "n_coef must be 1..32");
 	if (n_frames < 0 || n_frames >= ((int64_t)1 << 31) || frame_step < 0 || fpg < 1)
@@ -30,7 +39,7 @@ int ed_ctx_mfcc_q15_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_fram
 	a.frame_step = frame_step; a.n_coef = n_coef;
 	a.mfcc_i16 = mfcc_i16; a.mfcc_f32 = mfcc_f32; a.feat = feat;
 	a.fft = fft; a.spec = spec; a.mel = mel;
-	int e = ed_launch_mfcc_q15(&a, ctx->d_q15, ctx->q15_nlo, ctx->q15_nhi, stages, ctx->n_cu, ctx->stream);
+	int e = ed_launch_mfcc_q15(&a, ctx->d_q15, ctx->q15_nlo, ctx->q15_nhi, stages, ctx->n_cu, stream);
 	if (e != 0)
 	{
 		snprintf(ctx->err, sizeof(ctx->err), "Q15 MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)e));

@@ -140,59 +140,48 @@ __global__ __launch_bounds__(256) void ed_stream_filter_kernel(const int8_t *sof
 	}
 }
 
-static int enqueue_push_on_ctx_stream(edison_stream *s);
-static int enqueue_mapped_push(edison_stream *s);
+static int enqueue_mapped_push(edison_stream *s, unsigned seq, int *flag_written);
 
-/* enqueue the device operations of a push on the stream's private hipStream */
+/* enqueue the device operations of a push on the stream's private hipStream (passed explicitly: ctx->stream is not touched) */
 static int enqueue_push(edison_stream *s)
-{
-	hipStream_t saved = s->ctx->stream;
-	s->ctx->stream = s->own;
-	int r = enqueue_push_on_ctx_stream(s);
-	s->ctx->stream = saved;
-	return r;
-}
-
-static int enqueue_push_on_ctx_stream(edison_stream *s)
 {
 	edison_ctx *ctx = s->ctx;
 	/* 13 coefficients, int8 net input (scale 1): rows 30.. of the feature buffer */
-	int r = ed_ctx_mfcc_launch(ctx, s->d_audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
-	                           s->d_feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
+	int r = ed_ctx_mfcc_launch_on(ctx, s->own, s->d_audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
+	                              s->d_feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
 	if (r != EDISON_OK) return r;
 	/* window i of the push = rows i..i+30 of the feature buffer: a 13-byte utterance stride, nothing is copied */
-	r = ed_ctx_kws_cnn_launch(ctx, s->d_feat, s->chunk, EDISON_NUM_MFCC, s->d_logits, s->d_soft, s->d_argmax);
+	r = ed_ctx_kws_cnn_launch_on(ctx, s->own, s->d_feat, s->chunk, EDISON_NUM_MFCC, s->d_logits, s->d_soft, s->d_argmax);
 	if (r != EDISON_OK) return r;
 	if (s->filter)
 	{
-		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, ctx->stream, s->d_soft, s->chunk, s->alpha,
+		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, s->own, s->d_soft, s->chunk, s->alpha,
 		                   s->one_minus_alpha, s->threshold, s->d_filt_state, s->d_filt, s->d_likely, s->d_spotted);
 		if (hipGetLastError() != hipSuccess) return ed_set_err(ctx, EDISON_E_RUNTIME, "stream: filter launch failed");
 	}
-	hipLaunchKernelGGL(ed_stream_shift_kernel, dim3(1), dim3(256), 0, ctx->stream, s->d_audio, s->tail, s->chunk * s->hop,
+	hipLaunchKernelGGL(ed_stream_shift_kernel, dim3(1), dim3(256), 0, s->own, s->d_audio, s->tail, s->chunk * s->hop,
 	                   s->d_feat, s->chunk);
 	return hipGetLastError() == hipSuccess ? EDISON_OK : ed_set_err(ctx, EDISON_E_RUNTIME, "stream: shift launch failed");
 }
 
-/* the device work of a push against the host-mapped buffers, on the stream's private hipStream */
-static int enqueue_mapped_push(edison_stream *s)
+/* the device work of a push against the host-mapped buffers, on the stream's private hipStream. When the CNN is the last
+ * kernel (no output filter) and runs as one group, it writes the completion sequence number itself (*flag_written = 1). */
+static int enqueue_mapped_push(edison_stream *s, unsigned seq, int *flag_written)
 {
 	edison_ctx *ctx = s->ctx;
-	hipStream_t saved = ctx->stream;
-	ctx->stream = s->own;
 	unsigned char *o8 = s->md_out;
-	int r = ed_ctx_mfcc_launch(ctx, s->md_audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
-	                           s->md_feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
+	int r = ed_ctx_mfcc_launch_on(ctx, s->own, s->md_audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
+	                              s->md_feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
 	if (r == EDISON_OK)
-		r = ed_ctx_kws_cnn_launch(ctx, s->md_feat, s->chunk, EDISON_NUM_MFCC, (int8_t *)o8, (int8_t *)(o8 + s->off_soft), (int32_t *)(o8 + s->off_argmax));
+		r = ed_ctx_kws_cnn_launch_flag(ctx, s->own, s->md_feat, s->chunk, EDISON_NUM_MFCC, (int8_t *)o8, (int8_t *)(o8 + s->off_soft), (int32_t *)(o8 + s->off_argmax),
+		                               s->filter ? NULL : s->md_flag, seq, flag_written);
 	if (r == EDISON_OK && s->filter)
 	{
-		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, ctx->stream, (const int8_t *)(o8 + s->off_soft), s->chunk, s->alpha,
+		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, s->own, (const int8_t *)(o8 + s->off_soft), s->chunk, s->alpha,
 		                   s->one_minus_alpha, s->threshold, s->d_filt_state, (float *)(o8 + s->off_filt), (int32_t *)(o8 + s->off_likely),
 		                   (int32_t *)(o8 + s->off_spotted));
 		if (hipGetLastError() != hipSuccess) r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: filter launch failed");
 	}
-	ctx->stream = saved;
 	return r;
 }
 
@@ -456,15 +445,16 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 		const size_t c = (size_t)s->chunk;
 		{ const int rs = stream_state_to(s, 1); if (rs != EDISON_OK) return rs; }
 		memcpy(s->m_audio + s->tail, samples, nnew * sizeof(int16_t));
-		{ const int rd = enqueue_mapped_push(s); if (rd != EDISON_OK) return rd; }
+		const unsigned seq = ++s->flag_seq;
+		int kernel_writes_flag = 0;
+		{ const int rd = enqueue_mapped_push(s, seq, &kernel_writes_flag); if (rd != EDISON_OK) return rd; }
 		{
 			/* wait for the answer: spin on the sequence number the command processor writes behind the last kernel; if
 			 * that stream operation is unavailable, or nothing arrives within 20 ms (by the clock, looked at every 1024
 			 * spins), synchronize the ordinary way (which also surfaces a device error). The flag is read with acquire
 			 * semantics: the outputs copied below must not be read before it. */
-			const unsigned seq = ++s->flag_seq;
 			int waited = 0;
-			if (hipStreamWriteValue32(s->own, s->md_flag, seq, 0) == hipSuccess)
+			if (kernel_writes_flag || hipStreamWriteValue32(s->own, s->md_flag, seq, 0) == hipSuccess)
 			{
 				struct timespec t0, t1;
 				clock_gettime(CLOCK_MONOTONIC, &t0);

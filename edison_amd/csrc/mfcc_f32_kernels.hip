@@ -342,7 +342,10 @@ extern "C" int ed_launch_mfcc_f32_fast(const ed_mfcc_f32_args_t *args, const ed_
 {
 	if (args->n_frames <= 0) return 0;
 	const size_t lds = sizeof(float) * (EF2_TAB_FLOATS + EF2_WPB * EF2_XBUF_FLOATS) + 16;
-	static int ready = 0;
+	static int ready_dev[16]; /* per device: the attribute belongs to the function on the current device */
+	int dev_ = 0;
+	(void)hipGetDevice(&dev_);
+	int &ready = ready_dev[dev_ & 15];
 	if (!ready)
 	{
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ed_mfcc_f32_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

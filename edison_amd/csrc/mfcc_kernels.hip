@@ -983,15 +983,17 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 #endif
 }
 
-static int g_mfcc_blocks_per_cu[2] = {-1, -1};
-static int g_mfcc2_blocks_per_cu[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+/* occupancy-derived grid sizes and "dynamic-LDS limit raised" flags, per DEVICE (0 = not asked yet; the attribute belongs to
+ * the function on the current device, so two contexts on different GPUs of one process must each set it) */
+static int g_mfcc_blocks_per_cu[16][2];
+static int g_mfcc2_blocks_per_cu[16][8];
 
 template <int NLO, int NHI>
 static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
                                 hipStream_t stream, int *blocks_per_cu)
 {
 	const size_t lds = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED_TWTAB_FLOATS + ED_WPB * ED_XBUF_FLOATS);
-	if (*blocks_per_cu < 0)
+	if (*blocks_per_cu <= 0)
 	{
 		/* persistent grid = exactly what is resident; sized once from the fast kernel's occupancy */
 		int nb = 0;
@@ -1015,8 +1017,10 @@ static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables
 		const bool plain = args->frames_per_group >= args->n_frames;
 		const void *fn = aligned ? (plain ? (const void *)ed_mfcc2_kernel<true, true, NLO, NHI> : (const void *)ed_mfcc2_kernel<true, false, NLO, NHI>)
 		                         : (plain ? (const void *)ed_mfcc2_kernel<false, true, NLO, NHI> : (const void *)ed_mfcc2_kernel<false, false, NLO, NHI>);
-		int *bpc2 = &g_mfcc2_blocks_per_cu[(NLO == 2 ? 0 : 4) + (aligned ? 2 : 0) + (plain ? 1 : 0)];
-		if (*bpc2 < 0)
+		int dev_ = 0;
+		(void)hipGetDevice(&dev_);
+		int *bpc2 = &g_mfcc2_blocks_per_cu[dev_ & 15][(NLO == 2 ? 0 : 4) + (aligned ? 2 : 0) + (plain ? 1 : 0)];
+		if (*bpc2 <= 0)
 		{
 			/* more than 64 KB of dynamic LDS has to be asked for, once per kernel instance */
 			if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return (int)hipGetLastError();
@@ -1056,10 +1060,13 @@ extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t
                               hipStream_t stream)
 {
 	if (args->n_frames <= 0) return 0;
+	int dev_ = 0;
+	(void)hipGetDevice(&dev_);
+	dev_ &= 15;
 	/* the two table shapes tables.c produces */
 	if (args->mel_NLO == 2 && args->mel_NHI == 5)
-		return ed_launch_mfcc_shape<2, 5>(args, dev_tab, stages, n_cu, stream, &g_mfcc_blocks_per_cu[0]);
+		return ed_launch_mfcc_shape<2, 5>(args, dev_tab, stages, n_cu, stream, &g_mfcc_blocks_per_cu[dev_][0]);
 	if (args->mel_NLO == ED_MEL_NLO_MAX && args->mel_NHI == ED_MEL_NHI_MAX)
-		return ed_launch_mfcc_shape<ED_MEL_NLO_MAX, ED_MEL_NHI_MAX>(args, dev_tab, stages, n_cu, stream, &g_mfcc_blocks_per_cu[1]);
+		return ed_launch_mfcc_shape<ED_MEL_NLO_MAX, ED_MEL_NHI_MAX>(args, dev_tab, stages, n_cu, stream, &g_mfcc_blocks_per_cu[dev_][1]);
 	return (int)hipErrorInvalidValue;
 }

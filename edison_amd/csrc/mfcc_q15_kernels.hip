@@ -649,7 +649,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	}
 }
 
-static int g_q15_blocks_per_cu[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+static int g_q15_blocks_per_cu[16][8]; /* per device (0 = not asked yet): the LDS attribute belongs to the function on the current device */
 
 template <int NLO, int NHI>
 static int ed_launch_q15_shape(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int stages, int n_cu,
@@ -661,9 +661,9 @@ static int ed_launch_q15_shape(const ed_mfcc_q15_args_t *args, const ed_q15_tabl
 	                        : (aligned ? (const void *)ed_mfcc_q15_kernel<false, true, NLO, NHI> : (const void *)ed_mfcc_q15_kernel<false, false, NLO, NHI>);
 	const size_t lds = sizeof(u32) * EQ_LDS_DWORDS(ED_Q15_PAIRS(NLO), ED_Q15_PAIRS(NHI));
 	int *bpc = &blocks_per_cu[(stages ? 2 : 0) + (aligned ? 1 : 0)];
-	if (*bpc < 0)
+	if (*bpc <= 0)
 	{
-		/* more than 64 KB of dynamic LDS has to be asked for, once per kernel instance */
+		/* more than 64 KB of dynamic LDS has to be asked for, once per kernel instance and device */
 		if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError();
 		int nb = 0;
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * EQ_WPB, lds) != hipSuccess || nb < 1) nb = 1;
@@ -683,9 +683,12 @@ static int ed_launch_q15_shape(const ed_mfcc_q15_args_t *args, const ed_q15_tabl
 extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int mel_nlo, int mel_nhi,
                                   int stages, int n_cu, hipStream_t stream)
 {
+	int dev_ = 0;
+	(void)hipGetDevice(&dev_);
+	dev_ &= 15;
 	if (mel_nlo == 6 && mel_nhi == 18)
-		return ed_launch_q15_shape<6, 18>(args, dev_tab, stages, n_cu, stream, &g_q15_blocks_per_cu[0]);
+		return ed_launch_q15_shape<6, 18>(args, dev_tab, stages, n_cu, stream, &g_q15_blocks_per_cu[dev_][0]);
 	if (mel_nlo == ED_Q15_NLO_MAX && mel_nhi == ED_Q15_NHI_MAX)
-		return ed_launch_q15_shape<ED_Q15_NLO_MAX, ED_Q15_NHI_MAX>(args, dev_tab, stages, n_cu, stream, &g_q15_blocks_per_cu[4]);
+		return ed_launch_q15_shape<ED_Q15_NLO_MAX, ED_Q15_NHI_MAX>(args, dev_tab, stages, n_cu, stream, &g_q15_blocks_per_cu[dev_][4]);
 	return (int)hipErrorInvalidValue;
 }
