@@ -416,6 +416,8 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	u32 *zb = buf + EQ_BUF + EQ_NB * 32;
 	u32 *fid = zb + EQ_NB * 16;
 	unsigned *queue = s_tw12 + EQ_TW_DWORDS + EQ_WPB * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB);
+	/* its LDS byte address (the kernel has no static LDS: dynamic LDS starts at 0), for the asm draw */
+	const uint32_t queue_addr = (uint32_t)(sizeof(u32) * ((NLOP + NHIP) * 64 + 1024 + EQ_TW_DWORDS + EQ_WPB * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB)));
 
 	for (int i = threadIdx.x; i < (NLOP + NHIP) * 64; i += 64 * EQ_WPB) s_tap[i] = (&T->mel_tap2[0][0])[i];
 	for (int i = threadIdx.x; i < 1024; i += 64 * EQ_WPB) s_sqbit[i] = T->sqbit[i];
@@ -480,41 +482,44 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	const uint32_t cnt = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_frames) / gridDim.x) - s0;
 	uint32_t i_cur = (uint32_t)w, i_next = (uint32_t)w + EQ_WPB;
 	int slot = 0;
-	/* software prefetch: the samples of the wave's next frame are requested while this one is being transformed */
+	/* software prefetch: the samples of the wave's next frame are requested at the top of an iteration and go through STAGE 1
+	 * at its bottom (round 3), into the wave's transform buffer, which the mel stage has released by then: what an iteration
+	 * hands to the next one lies in LDS, not in registers. (With stage 1 at the top, the prefetch wrote a second set of 8
+	 * registers that the loop latch copied back: 8 v_mov_b32 per frame.) */
 	u32 raw[8];
-	if (i_cur < cnt) eq_load_frame<ALIGNED>(eq_frame_ptr(a, s0 + i_cur), lane, raw);
+	/* ---- stage 1 on sample pairs: butterflies j = 2 lane + 128 v (low halves) and j + 1 (high halves) */
+	auto stage1 = [&](const u32 (&x)[8]) {
+#pragma unroll
+		for (int v = 0; v < 2; v++)
+		{
+			u32 oA[4], oB[4];
+			if (!(EQ_ABLATE & 16))
+				eq_bf_first_real2(x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3], EQ_TW12(0, 2 * v, t1[2 * v]), EQ_TW12(0, 2 * v + 1, t1[2 * v + 1]), oA, oB);
+			else
+			{
+#pragma unroll
+				for (int q = 0; q < 4; q++) { oA[q] = x[4 * v + q] & 0xffffu; oB[q] = x[4 * v + q] >> 16; }
+			}
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+			{
+				const int p = 2 * lane + 128 * v + 256 * q; /* even: p and p + 1 share their pad */
+				buf[EQ_P(p)] = oA[q]; buf[EQ_P(p) + 1] = oB[q];
+			}
+		}
+	};
+	if (i_cur < cnt)
+	{
+		eq_load_frame<ALIGNED>(eq_frame_ptr(a, s0 + i_cur), lane, raw);
+		stage1(raw);
+	}
 	while (i_cur < cnt)
 	{
 		const uint32_t f = s0 + i_cur;
 		u32 e[16];
-
-		/* ---- stage 1 on sample pairs: butterflies j = 2 lane + 128 v (low halves) and j + 1 (high halves) */
-		{
-			u32 x[8];
-#pragma unroll
-			for (int i = 0; i < 8; i++) x[i] = raw[i];
-			/* unconditional (a conditional load would make raw[] a merge of two definitions: copies at the loop latch);
-			 * a wave's last iteration re-reads the slice's last frame, an L2 hit */
-			eq_load_frame<ALIGNED>(eq_frame_ptr(a, s0 + (i_next < cnt ? i_next : cnt - 1)), lane, raw);
-#pragma unroll
-			for (int v = 0; v < 2; v++)
-			{
-				u32 oA[4], oB[4];
-				if (!(EQ_ABLATE & 16))
-					eq_bf_first_real2(x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3], EQ_TW12(0, 2 * v, t1[2 * v]), EQ_TW12(0, 2 * v + 1, t1[2 * v + 1]), oA, oB);
-				else
-				{
-#pragma unroll
-					for (int q = 0; q < 4; q++) { oA[q] = x[4 * v + q] & 0xffffu; oB[q] = x[4 * v + q] >> 16; }
-				}
-#pragma unroll
-				for (int q = 0; q < 4; q++)
-				{
-					const int p = 2 * lane + 128 * v + 256 * q; /* even: p and p + 1 share their pad */
-					buf[EQ_P(p)] = oA[q]; buf[EQ_P(p) + 1] = oB[q];
-				}
-			}
-		}
+		/* the next frame's samples: unconditional (a wave's last iteration re-reads the slice's last frame, an L2 hit, and
+		 * never uses it) */
+		eq_load_frame<ALIGNED>(eq_frame_ptr(a, s0 + (i_next < cnt ? i_next : cnt - 1)), lane, raw);
 		eq_wave_sync();
 
 		if (!(EQ_ABLATE & 8))
@@ -600,7 +605,8 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 		uint32_t drawn = 0;
 		if (lane == 0)
 		{
-			drawn = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			/* one exec-masked ds_add_rtn_u32 (the builtin goes through the compiler's wave-aggregation code and waits on the spot) */
+			asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(drawn) : "v"(queue_addr), "v"(1u) : "memory");
 			fid[slot] = f;
 		}
 
@@ -631,6 +637,9 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 		}
 		eq_wave_sync();
 
+		/* ---- the next frame's stage 1 (see the prologue): the transform buffer is free from here on */
+		if (i_next < cnt) stage1(raw);
+
 		/* ---- dct2_q15, deferred: run it when 16 frames are parked or the wave has no frame left */
 		const bool last = i_next >= cnt;
 		if (slot == EQ_NB - 1 || last)
@@ -645,6 +654,9 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 		}
 		else
 			slot++;
+		/* the draw was issued a mel stage ago; a wave's DS operations complete in order and the mel stage's reads came
+		 * behind it, but the compiler does not know about the asm's result being in flight */
+		asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(drawn));
 		i_cur = i_next; i_next = __builtin_amdgcn_readfirstlane(drawn);
 	}
 }
