@@ -234,6 +234,12 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 		uint32_t drawn = 0;
 		if (lane == 0) drawn = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 
+		/* utterances in this group (4 but for the batch's last group -- and 1 for a one-window push of the microphone path):
+		 * column tiles that hold none of them are skipped under wave-uniform branches (conv1: 13 columns per utterance,
+		 * conv2: 35, conv3: 15), which is what a one-window launch's latency is made of */
+		const int64_t b_cur = (g_lo + idx) * EDM_G;
+		const int nb_cur = (int)((n_utt - b_cur) < EDM_G ? (n_utt - b_cur) : EDM_G);
+
 		/* ---- input: feat[u][31][13] -> in'[u][31][16] (3 zero bytes of padding per row) */
 #pragma unroll
 		for (int pass = 0; pass < 2; pass++)
@@ -242,9 +248,8 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 			if (r < EDM_G * ED_IN_H)
 			{
 				const int u = r / ED_IN_H, y = r - u * ED_IN_H;
-				const int64_t b_cur = (g_lo + idx) * EDM_G;
 				*reinterpret_cast<uint4 *>(acts + u * EDM_UTT + (y & 1) * EDM_IN_ODD + (y >> 1) * 16) =
-				    edm_fix_row(rows[pass], b_cur, (int)((n_utt - b_cur) < EDM_G ? (n_utt - b_cur) : EDM_G), n_utt, r);
+				    edm_fix_row(rows[pass], b_cur, nb_cur, n_utt, r);
 			}
 		}
 		const uint32_t next = __builtin_amdgcn_readfirstlane(drawn);
@@ -272,6 +277,7 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 #pragma unroll 1
 			for (int t = 0; t < 2; t++)
 			{
+				if (t * 32 >= nb_cur * 13) break; /* no live column in this tile */
 				const int q = t * 32 + col;
 				const bool live = q < EDM_G * 13;
 				const int qq = live ? q : EDM_G * 13 - 1; /* idle columns recompute the last one and store nothing */
@@ -336,52 +342,70 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 			v16i ae[2], ao[2];
 			unsigned char *p2[3];
 			bool live[3];
-			auto fetch = [&](int t) {
+			/* bs: which of the two fragment sets, ls: which of the three (live, p2) slots */
+			auto fetch = [&](int t, int bs, int ls) {
 				const int q = t * 32 + col;
-				live[t % 3] = q < EDM_G * 35;
-				const int qq = live[t % 3] ? q : EDM_G * 35 - 1;
+				live[ls] = q < nb_cur * 35;
+				const int qq = live[ls] ? q : nb_cur * 35 - 1;
 				const int u = qq / 35, r = qq - u * 35, py = r / 7, x = r - py * 7;
 				const unsigned char *p1 = acts + u * EDM_UTT + EDM_REGA + ((2 * py) * 9 + x) * 16;
-				p2[t % 3] = acts + u * EDM_UTT + (py * 7 + x) * 16; /* plane h is EDM_P2_PLANE * h further */
+				p2[ls] = acts + u * EDM_UTT + (py * 7 + x) * 16; /* plane h is EDM_P2_PLANE * h further */
 #pragma unroll
 				for (int s = 0; s < 5; s++)
 				{
 					const int tap = (2 * s + h) < 8 ? (2 * s + h) : 8; /* tap 9 meets zero weights */
 					const int ky = tap / 3, kx = tap - 3 * ky;
-					B0[t & 1][s] = edm_ld16(p1 + (ky * 9 + kx) * 16);
-					B1[t & 1][s] = edm_ld16(p1 + ((ky + 1) * 9 + kx) * 16);
+					B0[bs][s] = edm_ld16(p1 + (ky * 9 + kx) * 16);
+					B1[bs][s] = edm_ld16(p1 + ((ky + 1) * 9 + kx) * 16);
 				}
 			};
-			auto mma = [&](int t) {
-				ae[t & 1] = seed2; ao[t & 1] = seed2;
+			auto mma = [&](int bs) {
+				ae[bs] = seed2; ao[bs] = seed2;
 #pragma unroll
 				for (int s = 0; s < 5; s++)
 				{
-					ae[t & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A2[s], B0[t & 1][s], ae[t & 1], 0, 0, 0);
-					ao[t & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A2[s], B1[t & 1][s], ao[t & 1], 0, 0, 0);
+					ae[bs] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A2[s], B0[bs][s], ae[bs], 0, 0, 0);
+					ao[bs] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A2[s], B1[bs][s], ao[bs], 0, 0, 0);
 				}
 			};
-			fetch(0); fetch(1);
-			mma(0);
-			__builtin_amdgcn_sched_barrier(0);
+			auto requant = [&](int bs, int ls) {
+				const v16i &e = ae[bs], &o = ao[bs];
+				uint32_t d[4];
 #pragma unroll
-			for (int t = 0; t < 5; t++)
+				for (int g = 0; g < 4; g++)
+					d[g] = edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
+					                     edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs2);
+				const uint4 rec = edm_gather16(d[0], d[1], d[2], d[3]); /* channels 16h .. 16h + 15 */
+				*reinterpret_cast<uint4 *>(live[ls] ? p2[ls] + EDM_P2_PLANE * h : dummy) = rec;
+			};
+			if (nb_cur == EDM_G)
 			{
-				if (t + 1 < 5) mma(t + 1);
-				EDM_FENCE();
-				if (t + 2 < 5) fetch(t + 2); /* into the fragment registers tile t's MFMAs have consumed */
-				const v16i &e = ae[t & 1], &o = ao[t & 1];
-				{
-					uint32_t d[4];
-#pragma unroll
-					for (int g = 0; g < 4; g++)
-						d[g] = edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
-						                     edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs2);
-					const uint4 rec = edm_gather16(d[0], d[1], d[2], d[3]); /* channels 16h .. 16h + 15 */
-					*reinterpret_cast<uint4 *>(live[t % 3] ? p2[t % 3] + EDM_P2_PLANE * h : dummy) = rec;
-				}
-				if (t + 1 < 5) { EDM_WEAVE(10, 7) }
+				fetch(0, 0, 0); fetch(1, 1, 1);
+				mma(0);
 				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for (int t = 0; t < 5; t++)
+				{
+					if (t + 1 < 5) mma((t + 1) & 1);
+					EDM_FENCE();
+					if (t + 2 < 5) fetch(t + 2, t & 1, (t + 2) % 3); /* into the fragment registers tile t's MFMAs have consumed */
+					requant(t & 1, t % 3);
+					if (t + 1 < 5) { EDM_WEAVE(10, 7) }
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			}
+			else
+			{
+				/* a partial group (the batch's last one, or the single window of a microphone push): only the column tiles
+				 * that hold a live column, one after the other */
+				const int n_t2 = (nb_cur * 35 + 31) >> 5;
+#pragma unroll 1
+				for (int t = 0; t < n_t2; t++)
+				{
+					fetch(t, 0, 0);
+					mma(0);
+					requant(0, 0);
+				}
 			}
 		}
 		edm_wave_sync();
@@ -395,8 +419,8 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 			bool live[2];
 			auto issue = [&](int t, int slot) {
 				const int q = t * 32 + col;
-				live[slot] = q < EDM_G * 15;
-				const int qq = live[slot] ? q : EDM_G * 15 - 1;
+				live[slot] = q < nb_cur * 15;
+				const int qq = live[slot] ? q : nb_cur * 15 - 1;
 				const int u = qq / 15, r = qq - u * 15, y = r / 5, x = r - y * 5;
 				const unsigned char *p2 = acts + u * EDM_UTT + EDM_P2_PLANE * h + (y * 7 + x) * 16;
 				c3[slot] = acts + u * EDM_UTT + EDM_REGA + (y * 5 + x) * 16; /* plane j (channels 16 j ..) is EDM_C3_PLANE * j further */
@@ -410,28 +434,32 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 					a1[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(edm_ld16(afrag + a3_off + (9 + s) * 1024), b, a1[slot], 0, 0, 0);
 				}
 			};
-			issue(0, 0);
+			auto requant3 = [&](int slot) {
+				const v16i &x0 = a0[slot], &x1 = a1[slot];
+				uint32_t d0[4], d1[4];
 #pragma unroll
-			for (int t = 0; t < 2; t++)
-			{
-				if (t + 1 < 2) issue(t + 1, (t + 1) & 1);
-				EDM_FENCE();
-				const v16i &x0 = a0[t & 1], &x1 = a1[t & 1];
+				for (int g = 0; g < 4; g++)
 				{
-					uint32_t d0[4], d1[4];
-#pragma unroll
-					for (int g = 0; g < 4; g++)
-					{
-						d0[g] = edm_pack_relu(x0[4 * g], x0[4 * g + 1], x0[4 * g + 2], x0[4 * g + 3], rs3);
-						d1[g] = edm_pack_relu(x1[4 * g], x1[4 * g + 1], x1[4 * g + 2], x1[4 * g + 3], rs3);
-					}
-					const uint4 ra = edm_gather16(d0[0], d0[1], d0[2], d0[3]), rb = edm_gather16(d1[0], d1[1], d1[2], d1[3]);
-					*reinterpret_cast<uint4 *>(live[t & 1] ? c3[t & 1] + EDM_C3_PLANE * h : dummy) = ra;       /* channels 16h ..: plane h */
-					*reinterpret_cast<uint4 *>(live[t & 1] ? c3[t & 1] + EDM_C3_PLANE * (2 + h) : dummy) = rb; /* channels 32 + 16h ..: plane 2 + h */
+					d0[g] = edm_pack_relu(x0[4 * g], x0[4 * g + 1], x0[4 * g + 2], x0[4 * g + 3], rs3);
+					d1[g] = edm_pack_relu(x1[4 * g], x1[4 * g + 1], x1[4 * g + 2], x1[4 * g + 3], rs3);
 				}
-				if (t + 1 < 2) { EDM_WEAVE(18, 6) }
+				const uint4 ra = edm_gather16(d0[0], d0[1], d0[2], d0[3]), rb = edm_gather16(d1[0], d1[1], d1[2], d1[3]);
+				*reinterpret_cast<uint4 *>(live[slot] ? c3[slot] + EDM_C3_PLANE * h : dummy) = ra;       /* channels 16h ..: plane h */
+				*reinterpret_cast<uint4 *>(live[slot] ? c3[slot] + EDM_C3_PLANE * (2 + h) : dummy) = rb; /* channels 32 + 16h ..: plane 2 + h */
+			};
+			issue(0, 0);
+			if (nb_cur * 15 > 32) /* uniform: the second column tile holds a live column */
+			{
+				issue(1, 1);
+				EDM_FENCE();
+				requant3(0);
+				EDM_WEAVE(18, 6)
 				__builtin_amdgcn_sched_barrier(0);
+				requant3(1);
 			}
+			else
+				requant3(0);
+			__builtin_amdgcn_sched_barrier(0);
 		}
 		edm_wave_sync();
 
