@@ -187,3 +187,40 @@ def test_stream_host_and_device_pushes_share_one_state(ctx, hop, chunk, filt):
                 assert np.array_equal(got["filtered"].view(np.uint32), want["filtered"].view(np.uint32)), i
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("hop,chunk,filt", [(512, 1, False), (1024, 3, True), (512, 40, False)])
+def test_stream_launch_modes_agree(ctx, hop, chunk, filt):
+    """edison_stream_opts.launch_mode: EDISON_STREAM_LAUNCH_GRAPH replays the hipGraph captured at creation (what BASELINE
+    configs[4] names), EDISON_STREAM_LAUNCH_DIRECT (the default) launches the same kernels one by one -- for one-window host
+    pushes with the CNN kernel signalling completion itself. Same samples through both, host pushes and device pushes:
+    every output of every push identical, state carried across pushes included."""
+    import torch
+    from edison_amd.stream import Stream
+    rng = np.random.default_rng(3 * hop + chunk)
+    n_push = 8
+    audio = np.clip(rng.normal(0, 2500, n_push * chunk * hop), -32768, 32767).astype(np.int16)
+    res = {}
+    for graph in (False, True):
+        st = Stream(ctx, hop=hop, chunk_frames=chunk, output_filter=filt, graph=graph)
+        outs = [st.push(audio[i * chunk * hop:(i + 1) * chunk * hop]) for i in range(n_push)]
+        res[graph] = {k: np.concatenate([np.asarray(o[k]).reshape(chunk, -1) for o in outs]) for k in outs[0] if k != "keywords"}
+        st.close()
+    for k in res[False]:
+        assert np.array_equal(res[False][k], res[True][k]), k
+    # device pushes
+    dev = torch.device("cuda", ctx.device)
+    ctx.use_torch_stream()
+    a = torch.from_numpy(audio).to(dev)
+    got = {}
+    for graph in (False, True):
+        st = Stream(ctx, hop=hop, chunk_frames=chunk, graph=graph)
+        so = torch.zeros((n_push * chunk, 10), dtype=torch.int8, device=dev)
+        am = torch.zeros((n_push * chunk,), dtype=torch.int32, device=dev)
+        for i in range(n_push):
+            st.push_t(a[i * chunk * hop:(i + 1) * chunk * hop], softmax=so[i * chunk:(i + 1) * chunk], argmax=am[i * chunk:(i + 1) * chunk])
+        torch.cuda.synchronize()
+        got[graph] = (so.cpu().numpy(), am.cpu().numpy())
+        st.close()
+    assert np.array_equal(got[False][0], got[True][0]) and np.array_equal(got[False][1], got[True][1])
+    assert np.array_equal(got[False][0], res[False]["softmax"])
