@@ -198,6 +198,20 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 	unsigned char *dummy = park + EDM_PARK * EDM_G * 16 + 32 + 16 * (lane >> 5);      /* where idle columns store: no branch */
 	unsigned *queue = reinterpret_cast<unsigned *>(smem + sizeof(ed_cnn_mfma_model_t) + EDM_WAVES * EDM_WAVE_LDS);
 
+	/* this workgroup's contiguous slice of the utterance groups; its waves draw from it */
+	const int64_t n_groups = (n_utt + EDM_G - 1) / EDM_G;
+	const int64_t g_lo = (int64_t)blockIdx.x * n_groups / gridDim.x;
+	const uint32_t cnt = (uint32_t)((int64_t)(blockIdx.x + 1) * n_groups / gridDim.x - g_lo);
+	/* The feature rows of the wave's first group go in flight BEFORE the weight staging (round 3): loads return in issue order,
+	 * so the staging below waits behind them anyway, and for a one-window push of the microphone path these rows come over
+	 * the bus from host-mapped memory (~2 us) -- with the rows requested after the staging barrier the two latencies added up.
+	 * The rows of a wave's next group are fetched while it works on the current one. */
+	uint4 rows[2];
+	if ((uint32_t)wave < cnt)
+	{
+		const int64_t b0 = (g_lo + wave) * EDM_G;
+		edm_load_rows(feat, feat_stride, b0, (int)((n_utt - b0) < EDM_G ? (n_utt - b0) : EDM_G), n_utt, lane, rows);
+	}
 	{ /* stage the weight fragments once per workgroup */
 		const v4i *src = reinterpret_cast<const v4i *>(model);
 		v4i *dst = reinterpret_cast<v4i *>(smem);
@@ -215,19 +229,7 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 	const int rs3 = __builtin_amdgcn_readfirstlane(M.rs3), rs4 = __builtin_amdgcn_readfirstlane(M.rs4);
 	const int rsfc = __builtin_amdgcn_readfirstlane(M.rsfc);
 
-	/* this workgroup's contiguous slice of the utterance groups; its waves draw from it */
-	const int64_t n_groups = (n_utt + EDM_G - 1) / EDM_G;
-	const int64_t g_lo = (int64_t)blockIdx.x * n_groups / gridDim.x;
-	const uint32_t cnt = (uint32_t)((int64_t)(blockIdx.x + 1) * n_groups / gridDim.x - g_lo);
 	int parked = 0;
-
-	/* the rows of a wave's next group are fetched while it works on the current one */
-	uint4 rows[2];
-	if ((uint32_t)wave < cnt)
-	{
-		const int64_t b0 = (g_lo + wave) * EDM_G;
-		edm_load_rows(feat, feat_stride, b0, (int)((n_utt - b0) < EDM_G ? (n_utt - b0) : EDM_G), n_utt, lane, rows);
-	}
 	for (uint32_t idx = wave; idx < cnt;)
 	{
 		/* the group after this one: drawn now, its index is needed only after the input rows are in LDS */
