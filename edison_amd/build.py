@@ -20,6 +20,14 @@ HIP_SOURCES = ["edison_hip.hip", "edison_q15.hip", "edison_f32.hip", "edison_net
                "cnn_net_kernels.hip", "cnn_net_mfma_kernels.hip"]
 HEADERS = ["edison_internal.h", "edison_ctx.h", "mfcc_fft.h", os.path.join("..", "..", "include", "edison_hip.h")]
 ARCH = "gfx950"
+# per-file code-generation flags. -amdgpu-sched-strategy=max-ilp: the machine scheduler orders the straight-line blocks of the two
+# MFCC kernels for instruction-level parallelism instead of occupancy (which the launch bounds fix anyway: 160 / 155 VGPRs either
+# way); measured interleaved in one process (tools/lab/ab_mfcc.py, round 3): float kernel +1.3 ... +2.4 %, Q15 kernel +0.4 %,
+# CNN kernel -0.2 % (not applied there); outputs bit-identical.
+PER_FILE_FLAGS = {
+    "mfcc_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "mfcc_q15_kernels.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+}
 
 
 def _hipcc():
@@ -57,7 +65,7 @@ def build(force=False, verbose=False):
         # cycles of vector issue against 2.3-2.6 for a back-to-back VOP2 add / mul / fmac and 3.7-4.0 for a VOP3 v_fma_f32: packing
         # pays when whole register PAIRS stay pairs (the two-frame MFCC kernel is written that way by hand), not when the
         # compiler's SLP pass packs adjacent scalar ops and pays v_mov's to build the pairs (-15 % on the one-frame kernel)
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-fno-slp-vectorize"] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-fno-slp-vectorize"] + common + PER_FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

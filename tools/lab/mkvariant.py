@@ -25,7 +25,7 @@ def one(spec):
         src = os.path.join(ROOT, alt) if alt else os.path.join(B.CSRC, base)
         obj = os.path.join(odir, base + ".o")
         cmd = [B._hipcc(), "--offload-arch=" + B.ARCH, "-std=c++17", "-fno-slp-vectorize", "-O3", "-fPIC", "-I" + B.CSRC,
-               "-Wno-unused-value"] + flags.split() + ["-x", "hip", "-c", src, "-o", obj]
+               "-Wno-unused-value"] + B.PER_FILE_FLAGS.get(base, []) + flags.split() + ["-x", "hip", "-c", src, "-o", obj]
         subprocess.check_call(cmd)
         replaced.add(base + ".o"); objs.append(obj)
     for o in sorted(os.listdir(os.path.join(B.CSRC, "build"))):
