@@ -73,6 +73,12 @@ struct edison_stream
 	unsigned *md_flag;
 	unsigned flag_seq;
 	const int16_t *md_audio; int8_t *md_feat; unsigned char *md_out; /* their device addresses */
+	/* Direct-launch device pushes run on the CALLER's stream (round 3): no event pair around the push, the CNN writes the
+	 * caller's output buffers itself -- a push is one copy and three launches instead of eleven API calls (the loop over a
+	 * long recording in 4096-frame pushes was bound by the host's calls, not by the GPU). q_last / q_pending: the stream the
+	 * last such push went to; whatever next touches the stream's state on another HIP stream waits for it first. */
+	hipStream_t q_last;
+	int q_pending;
 	int state_host;       /* 1: the newest tail samples / 30 feature rows are in m_audio / m_feat, 0: in d_audio / d_feat */
 	int last_push_mapped;
 	int64_t frames_seen;
@@ -142,26 +148,41 @@ __global__ __launch_bounds__(256) void ed_stream_filter_kernel(const int8_t *sof
 
 static int enqueue_mapped_push(edison_stream *s, unsigned seq, int *flag_written);
 
-/* enqueue the device operations of a push on the stream's private hipStream (passed explicitly: ctx->stream is not touched) */
-static int enqueue_push(edison_stream *s)
+/* enqueue the device operations of a push on hipStream q (passed explicitly: ctx->stream is not touched); the CNN writes
+ * logits / softmax / argmax where it is told to (the stream's own block, or the caller's buffers) */
+static int enqueue_push_on(edison_stream *s, hipStream_t q, int8_t *logits, int8_t *softmax, int32_t *argmax)
 {
 	edison_ctx *ctx = s->ctx;
 	/* 13 coefficients, int8 net input (scale 1): rows 30.. of the feature buffer */
-	int r = ed_ctx_mfcc_launch_on(ctx, s->own, s->d_audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
+	int r = ed_ctx_mfcc_launch_on(ctx, q, s->d_audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
 	                              s->d_feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
 	if (r != EDISON_OK) return r;
 	/* window i of the push = rows i..i+30 of the feature buffer: a 13-byte utterance stride, nothing is copied */
-	r = ed_ctx_kws_cnn_launch_on(ctx, s->own, s->d_feat, s->chunk, EDISON_NUM_MFCC, s->d_logits, s->d_soft, s->d_argmax);
+	r = ed_ctx_kws_cnn_launch_on(ctx, q, s->d_feat, s->chunk, EDISON_NUM_MFCC, logits, softmax, argmax);
 	if (r != EDISON_OK) return r;
 	if (s->filter)
 	{
-		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, s->own, s->d_soft, s->chunk, s->alpha,
+		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, q, softmax, s->chunk, s->alpha,
 		                   s->one_minus_alpha, s->threshold, s->d_filt_state, s->d_filt, s->d_likely, s->d_spotted);
 		if (hipGetLastError() != hipSuccess) return ed_set_err(ctx, EDISON_E_RUNTIME, "stream: filter launch failed");
 	}
-	hipLaunchKernelGGL(ed_stream_shift_kernel, dim3(1), dim3(256), 0, s->own, s->d_audio, s->tail, s->chunk * s->hop,
+	hipLaunchKernelGGL(ed_stream_shift_kernel, dim3(1), dim3(256), 0, q, s->d_audio, s->tail, s->chunk * s->hop,
 	                   s->d_feat, s->chunk);
 	return hipGetLastError() == hipSuccess ? EDISON_OK : ed_set_err(ctx, EDISON_E_RUNTIME, "stream: shift launch failed");
+}
+
+static int enqueue_push(edison_stream *s) { return enqueue_push_on(s, s->own, s->d_logits, s->d_soft, s->d_argmax); }
+
+/* Work that a direct device push left on the caller's stream must be behind us before the private stream (or another caller
+ * stream `q`) touches the stream's state: one event pair, paid only at such a change of streams. */
+static int drain_q(edison_stream *s, hipStream_t q)
+{
+	edison_ctx *ctx = s->ctx;
+	if (!s->q_pending || s->q_last == q) return EDISON_OK;
+	if (hipEventRecord(s->ev_in, s->q_last) == hipSuccess) ED_HIP(ctx, hipStreamWaitEvent(q, s->ev_in, 0));
+	else (void)hipGetLastError(); /* the caller destroyed that stream (which drains it) */
+	s->q_pending = 0;
+	return EDISON_OK;
 }
 
 /* the device work of a push against the host-mapped buffers, on the stream's private hipStream. When the CNN is the last
@@ -188,6 +209,7 @@ static int enqueue_mapped_push(edison_stream *s, unsigned seq, int *flag_written
 extern "C" void edison_stream_destroy(edison_stream *s)
 {
 	if (!s) return;
+	if (s->own && s->ev_in) (void)drain_q(s, s->own);
 	if (s->own) (void)hipStreamSynchronize(s->own);
 	if (s->exec) (void)hipGraphExecDestroy(s->exec);
 	if (s->graph) (void)hipGraphDestroy(s->graph);
@@ -213,6 +235,7 @@ extern "C" int edison_stream_reset(edison_stream *s)
 {
 	if (!s) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
+	{ const int rq = drain_q(s, s->own); if (rq != EDISON_OK) return rq; }
 	ED_HIP(ctx, hipMemsetAsync(s->d_audio, 0, sizeof(int16_t) * (size_t)(s->tail + s->chunk * s->hop), s->own));
 	ED_HIP(ctx, hipMemsetAsync(s->d_feat, 0, (size_t)(30 + s->chunk) * EDISON_NUM_MFCC, s->own));
 	if (s->filter) ED_HIP(ctx, hipMemsetAsync(s->d_filt_state, 0, sizeof(float) * EDISON_NET_OUT, s->own));
@@ -229,6 +252,7 @@ static int stream_state_to(edison_stream *s, int host)
 {
 	edison_ctx *ctx = s->ctx;
 	if (!s->m_audio || s->state_host == host) return EDISON_OK;
+	{ const int rq = drain_q(s, s->own); if (rq != EDISON_OK) return rq; }
 	const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
 	if (s->tail) ED_HIP(ctx, hipMemcpyAsync(host ? (void *)s->m_audio : (void *)s->d_audio, host ? (void *)s->d_audio : (void *)s->m_audio, sizeof(int16_t) * (size_t)s->tail, kind, s->own));
 	ED_HIP(ctx, hipMemcpyAsync(host ? (void *)s->m_feat : (void *)s->d_feat, host ? (void *)s->d_feat : (void *)s->m_feat, 30 * EDISON_NUM_MFCC, kind, s->own));
@@ -409,7 +433,25 @@ extern "C" int edison_stream_push_dev(edison_stream *s, const int16_t *samples, 
 	const size_t nnew = (size_t)s->chunk * s->hop;
 	{ const int rs = stream_state_to(s, 0); if (rs != EDISON_OK) return rs; }
 	s->last_push_mapped = 0;
-	/* the caller produced `samples` on the context's stream: the private stream waits for that point ... */
+	if (!s->use_graph)
+	{
+		/* direct launches, on the caller's stream: one copy + MFCC + CNN (+ filter) + shift, the CNN writing the caller's
+		 * buffers; the private stream is idle here (everything it ever does ends in a synchronisation) */
+		hipStream_t q = ctx->stream;
+		{ const int rq = drain_q(s, q); if (rq != EDISON_OK) return rq; }
+		ED_HIP(ctx, hipMemcpyAsync(s->d_audio + s->tail, samples, nnew * sizeof(int16_t), hipMemcpyDeviceToDevice, q));
+		/* the output filter reads the softmax from the stream's own block */
+		int8_t *so = s->filter ? s->d_soft : softmax;
+		{ const int rd = enqueue_push_on(s, q, logits, so, argmax); if (rd != EDISON_OK) return rd; }
+		if (s->filter && softmax) ED_HIP(ctx, hipMemcpyAsync(softmax, s->d_soft, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToDevice, q));
+		s->q_last = q;
+		s->q_pending = 1;
+		s->last_push_staged = 0;
+		s->frames_seen += s->chunk;
+		return EDISON_OK;
+	}
+	/* graph replay: on the private stream (a graph is captured on one stream), ordered against the caller's with events.
+	 * The caller produced `samples` on the context's stream: the private stream waits for that point ... */
 	ED_HIP(ctx, hipEventRecord(s->ev_in, ctx->stream));
 	ED_HIP(ctx, hipStreamWaitEvent(s->own, s->ev_in, 0));
 	ED_HIP(ctx, hipMemcpyAsync(s->d_audio + s->tail, samples, nnew * sizeof(int16_t), hipMemcpyDeviceToDevice, s->own));
@@ -417,8 +459,7 @@ extern "C" int edison_stream_push_dev(edison_stream *s, const int16_t *samples, 
 		/* the kernels of a push are launched directly: on this platform replaying the captured graph is SLOWER than its
 		 * three or four plain launches (1 h stream in 4096-frame pushes: 60.0 M frames/s with hipGraphLaunch, 67.2 M
 		 * without; one-frame pushes: 39 -> 32 us). launch_mode = EDISON_STREAM_LAUNCH_GRAPH replays the graph. */
-		if (!s->use_graph) { const int rd = enqueue_push(s); if (rd != EDISON_OK) return rd; }
-		else ED_HIP(ctx, hipGraphLaunch(s->exec, s->own));
+		ED_HIP(ctx, hipGraphLaunch(s->exec, s->own));
 	}
 	s->last_push_staged = 0;
 	if (logits) ED_HIP(ctx, hipMemcpyAsync(logits, s->d_logits, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToDevice, s->own));
@@ -485,6 +526,7 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 		return EDISON_OK;
 	}
 	{ const int rs = stream_state_to(s, 0); if (rs != EDISON_OK) return rs; }
+	{ const int rq = drain_q(s, s->own); if (rq != EDISON_OK) return rq; } /* device pushes may have left work on the caller's stream */
 	s->last_push_mapped = 0;
 	if (s->exec_h)
 	{
@@ -535,6 +577,7 @@ static int stream_filter_out(edison_stream *s, float *filt, int32_t *likely, int
 		ED_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_out, 0));
 		return EDISON_OK;
 	}
+	{ const int rq = drain_q(s, s->own); if (rq != EDISON_OK) return rq; }
 	if (host && s->last_push_staged)
 	{
 		/* the staged push already brought them to the host */
