@@ -172,6 +172,17 @@ class Context:
             d["layers"].append({k: getattr(li, k) for k, _ in _lib.NetLayerInfo._fields_})
         return d
 
+    def net_specialize(self):
+        """Compile (hipRTC) or fetch from the cache the loaded graph's OWN matrix-core kernel: edison_net_specialize. Returns
+        1 (compiled now) or 2 (from the cache); raises EdisonError (NO_IMPL) when the graph has no matrix-core plan or hipRTC
+        is not installed -- the graph then stays on the general kernel."""
+        self._check(self._L.edison_net_specialize(self._h))
+        return self.net_specialized()
+
+    def net_specialized(self):
+        """0: general kernel, 1: the graph's own kernel compiled by this process, 2: ... loaded from the on-disk cache."""
+        return int(self._L.edison_net_specialized(self._h))
+
     def net(self, x):
         """model_run + first-maximum argmax for n inputs [n][in_h*in_w*in_c] int8 (nnom.c:975-1040, nnom_utils.c:275-284)."""
         info = self.net_info()
@@ -302,3 +313,19 @@ def default_context():
         import os
         _default = Context(int(os.environ.get("EDISON_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     return _default
+
+
+def net_spec_source(blob):
+    """The constants edison_net_specialize() puts in front of the general kernel's source for this .ednn blob (host only, no
+    GPU): edison_net_spec_source. Raises EdisonError (NO_IMPL) for a graph without a matrix-core plan."""
+    L = _lib.lib()
+    buf = ctypes.create_string_buffer(bytes(blob), len(blob))
+    need = ctypes.c_size_t(0)
+    r = L.edison_net_spec_source(ctypes.cast(buf, ctypes.c_void_p), len(blob), None, 0, ctypes.byref(need))
+    if r != _lib.E_SIZE:
+        raise _lib.EdisonError(r, "edison_net_spec_source")
+    out = ctypes.create_string_buffer(need.value)
+    r = L.edison_net_spec_source(ctypes.cast(buf, ctypes.c_void_p), len(blob), ctypes.cast(out, ctypes.c_void_p), need.value, ctypes.byref(need))
+    if r != 0:
+        raise _lib.EdisonError(r, "edison_net_spec_source")
+    return out.value.decode()

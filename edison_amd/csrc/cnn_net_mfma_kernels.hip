@@ -23,17 +23,26 @@
  * once (the positions of a fused pooling window share an A fragment; two output tiles side by side), or 16 x 16 x 64
  * for layers with at most 16 columns per wave, where a 32-column tile would be mostly padding.
  */
+/* -DEMM_JIT=1: this text is being compiled by hipRTC at run time (edison_net_specialize, edison_net_jit.hip) for one graph:
+ * device code only, the headers come from the library's own copy of them, the kernel gets a C name */
+#ifndef EMM_JIT
+#define EMM_JIT 0
+#endif
+#if EMM_JIT
+#include "edison_hip.h"
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/edison_hip.h"
+#endif
 #include "edison_internal.h"
 
 /* diagnostic build only (-DEMM_STAMP=1, tools/lab): workgroup-level cycle stamps per phase into a debug buffer */
 #ifndef EMM_STAMP
 #define EMM_STAMP 0
 #endif
-#if EMM_STAMP
+#if EMM_STAMP && !EMM_JIT
 __device__ unsigned long long *g_emm_dbg = nullptr;
 extern "C" void ed_set_net_debug_buffer(void *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_emm_dbg), &p, sizeof(p)); }
 #define EMM_ST(i) { unsigned long long n_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n_) :: "memory"); stamp_[i] += n_ - tl_; tl_ = n_; }
@@ -44,6 +53,34 @@ extern "C" void ed_set_net_debug_buffer(void *p) { (void)hipMemcpyToSymbol(HIP_S
  * accumulators stay the seeds), 4 no expansion, 8 no input load, 16 no softmax / outputs */
 #ifndef EMM_SKIP
 #define EMM_SKIP 0
+#endif
+/* -DEMM_SPEC=1 -DEMM_SPEC_HEADER='"file"': a kernel for ONE graph -- the plans' scalars and layer records come from the
+ * generated header (net_spec.c) as C++ constants, the layer loop is unrolled and the per-layer bookkeeping folds away */
+#ifndef EMM_SPEC
+#define EMM_SPEC 0
+#endif
+#if EMM_SPEC
+#include EMM_SPEC_HEADER
+#define EMM_PF(f) (EMM_SP_##f)
+#define EMM_MF(f) (EMM_SM_##f)
+#define EMM_RUN(li) (EMM_SR[li])
+#define EMM_NETL(li) (EMM_SPL[li])
+#define EMM_MML(li) (EMM_SML[li])
+#define EMM_UNROLL_LAYERS _Pragma("unroll")
+#define EMM_CONST constexpr
+#else
+#define EMM_PF(f) (P->f)
+#define EMM_MF(f) (M->f)
+#define EMM_RUN(li) (M->R[li])
+#define EMM_NETL(li) (P->L[li])
+#define EMM_MML(li) (M->L[li])
+#define EMM_UNROLL_LAYERS
+#define EMM_CONST const
+#endif
+#if EMM_SPEC
+#define EMM_NL_EXPR EMM_SPEC_NL
+#else
+#define EMM_NL_EXPR (P->n_layers)
 #endif
 #define EMM_MAX_THREADS 768 /* 12 waves: 168 VGPRs each (four accumulator tiles + the pipeline's operands need ~150) */
 
@@ -134,21 +171,6 @@ __device__ __forceinline__ uint32_t emm_image_dword(uint32_t raw, int in_n, int 
 }
 
 struct emm_layout { int hp, wp, py, px, img; }; /* how an activation tensor lies in LDS: padded dims, origin, bytes per image */
-
-__device__ __forceinline__ emm_layout emm_in_layout(const ed_mm_layer_t *__restrict__ ML, const ed_net_layer_t *__restrict__ PL, int n_layers, int li)
-{
-	emm_layout l;
-	if (li < n_layers)
-	{
-		l.hp = ML[li].in_hp; l.wp = ML[li].in_wp; l.py = ML[li].in_py; l.px = ML[li].in_px; l.img = ML[li].in_img;
-	}
-	else
-	{
-		const ed_net_layer_t &L = PL[n_layers - 1];
-		l.hp = L.out_h; l.wp = L.out_w; l.py = 0; l.px = 0; l.img = ((L.out_n + 15) & ~15) + 16;
-	}
-	return l;
-}
 
 __device__ __forceinline__ void emm_zero(lds8 *buf, int bytes, int lane)
 {
@@ -463,32 +485,30 @@ __device__ __forceinline__ void emm_layer_dispatch(const emm_mm_args &A, int lan
 }
 
 template <bool FRAG_LDS>
-__global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_net_plan_t *__restrict__ P, const ed_mm_plan_t *__restrict__ M,
-                                                                 const int8_t *__restrict__ frag, const int32_t *__restrict__ seeds,
-                                                                 const int8_t *__restrict__ in, int64_t n, int64_t in_stride,
-                                                                 int8_t *__restrict__ logits, int8_t *__restrict__ softmax,
-                                                                 int32_t *__restrict__ argmax)
+__device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P, const ed_mm_plan_t *__restrict__ M,
+                                             const int8_t *__restrict__ frag, const int32_t *__restrict__ seeds,
+                                             const int8_t *__restrict__ in, int64_t n, int64_t in_stride,
+                                             int8_t *__restrict__ logits, int8_t *__restrict__ softmax,
+                                             int32_t *__restrict__ argmax)
 {
 	extern __shared__ __attribute__((aligned(16))) int8_t emm_lds_generic[];
 	lds8 *emm_lds = (lds8 *)emm_lds_generic;
-	const int n_layers = P->n_layers, batch = M->batch, buf_bytes = M->buf_bytes;
+	EMM_CONST int n_layers = EMM_NL_EXPR, batch = EMM_MF(batch), buf_bytes = EMM_MF(buf_bytes);
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int n_threads = blockDim.x, n_waves = n_threads >> 6;
 	/* small tables, copied once per workgroup: chunk offsets of every layer | seeds | column, expansion, input tables; then
 	 * the weight fragments (when resident); then one slice per wave: two ping-pong activation buffers and the expansion
 	 * buffer */
 	lds8 *tbl = emm_lds;
-	const int n_koff = M->n_koff, n_seeds = M->n_seeds, n_coltab = M->n_cols;
+	EMM_CONST int n_koff = EMM_MF(n_koff), n_seeds = EMM_MF(n_seeds), n_coltab = EMM_MF(n_cols);
 	lds32 *koff_all = reinterpret_cast<lds32 *>(tbl);
 	lds32 *seeds_l = reinterpret_cast<lds32 *>(tbl + ((4 * n_koff + 15) & ~15));
-	const ed_net_layer_t *__restrict__ PL = P->L;
-	const ed_mm_layer_t *__restrict__ MLs = M->L;
 	lds32 *coltab_l = reinterpret_cast<lds32 *>(reinterpret_cast<lds8 *>(seeds_l) + ((4 * n_seeds + 15) & ~15));
-	const int n_xtab = M->n_xtab, n_intab = M->n_intab;
+	EMM_CONST int n_xtab = EMM_MF(n_xtab), n_intab = EMM_MF(n_intab);
 	lds32 *xtab_l = reinterpret_cast<lds32 *>(reinterpret_cast<lds8 *>(coltab_l) + ((8 * n_coltab + 15) & ~15));
 	EMM_LDS uint16_t *intab_l = reinterpret_cast<EMM_LDS uint16_t *>(reinterpret_cast<lds8 *>(xtab_l) + ((8 * n_xtab + 15) & ~15));
-	lds8 *fragl = tbl + M->tbl_bytes;
-	lds8 *slice = fragl + M->frag_lds + wave * (2 * buf_bytes + M->x_bytes);
+	lds8 *fragl = tbl + EMM_MF(tbl_bytes);
+	lds8 *slice = fragl + EMM_MF(frag_lds) + wave * (2 * buf_bytes + EMM_MF(x_bytes));
 	lds8 *bufs[2] = {slice, slice + buf_bytes};
 	lds8 *xbuf = slice + 2 * buf_bytes;
 	{
@@ -500,11 +520,11 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 		if (FRAG_LDS)
 		{
 			const v4i *src = reinterpret_cast<const v4i *>(frag);
-			for (int i = threadIdx.x; i < M->frag_bytes / 16; i += n_threads) EMM_ST128(fragl + 16 * i, src[i]);
+			for (int i = threadIdx.x; i < EMM_MF(frag_bytes) / 16; i += n_threads) EMM_ST128(fragl + 16 * i, src[i]);
 		}
 	}
 	__syncthreads(); /* the only workgroup barrier: from here on every wave is on its own */
-	const int out_n = P->out_n, logits_layer = P->logits_layer, has_softmax = P->has_softmax;
+	EMM_CONST int out_n = EMM_PF(out_n), logits_layer = EMM_PF(logits_layer), has_softmax = EMM_PF(has_softmax);
 
 #if EMM_STAMP
 	unsigned long long stamp_[48], tl_;
@@ -514,17 +534,18 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 	/* One image per wave and at most 512 bytes of it: the next image's dwords are requested from HBM before this one's layers
 	 * run (two registers; more would spill), so that the wave never waits a memory latency per input. */
 	const int64_t u_first = ((int64_t)blockIdx.x * n_waves + wave) * batch, u_step = (int64_t)gridDim.x * n_waves * batch;
-	const bool prefetch = n_intab && batch == 1 && P->in_n <= EMM_PRE * 256 && P->in_n >= 4;
+	EMM_CONST bool prefetch = n_intab && batch == 1 && EMM_PF(in_n) <= EMM_PRE * 256 && EMM_PF(in_n) >= 4;
 	uint32_t pre[EMM_PRE];
-	if (prefetch && u_first < n) emm_load_image(in + u_first * in_stride, P->in_n, lane, pre);
+	if (prefetch && u_first < n) emm_load_image(in + u_first * in_stride, EMM_PF(in_n), lane, pre);
 	for (int64_t u0 = u_first; u0 < n; u0 += u_step)
 	{
-		const int nb = (int)((n - u0) < batch ? (n - u0) : batch);
+		const int nb = batch == 1 ? 1 : (int)((n - u0) < batch ? (n - u0) : batch);
 		EMM_ST(47)
 		/* ---- the inputs into layer 0's layout */
 		{
-			const emm_layout l0 = emm_in_layout(MLs, PL, n_layers, 0);
-			const int in_h = P->in_h, in_w = P->in_w, in_c = P->in_c, in_n = P->in_n;
+			const ed_mm_layer_t ml0 = EMM_MML(0);
+			const emm_layout l0 = {ml0.in_hp, ml0.in_wp, ml0.in_py, ml0.in_px, ml0.in_img};
+			EMM_CONST int in_h = EMM_PF(in_h), in_w = EMM_PF(in_w), in_c = EMM_PF(in_c), in_n = EMM_PF(in_n);
 			if (l0.hp != in_h || l0.wp != in_w) /* uniform: a zero border to keep */
 			{
 				emm_zero(bufs[0], batch * l0.img, lane);
@@ -599,12 +620,13 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 		}
 		EMM_ST(0)
 		int cur = 0;
+		EMM_UNROLL_LAYERS
 		for (int li = 0; li < n_layers; li++)
 		{
 			/* one wave-uniform run record per layer, worked out by the planner: two scalar loads (copies in LDS cost a
 			 * ds_read + v_readfirstlane per field; deriving it here from the layer records took a chain of dependent
 			 * scalar loads and ~100 scalar instructions per layer and input) */
-			const ed_mm_run_t R = M->R[li];
+			const ed_mm_run_t R = EMM_RUN(li);
 			if (R.kind == ED_RUN_SKIP) continue; /* a MaxPool taken in the epilogue of the layer in front of it */
 			const lds8 *a = bufs[cur];
 			lds8 *o = bufs[cur ^ 1];
@@ -637,8 +659,8 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 					else
 					{
 						/* no table (ED_MM_MAX_XTAB): the rare path reads the layer records and divides */
-						const ed_net_layer_t L = PL[li];
-						const ed_mm_layer_t ML = MLs[li];
+						const ed_net_layer_t L = EMM_NETL(li);
+						const ed_mm_layer_t ML = EMM_MML(li);
 						const int dense = L.type == ED_NET_DENSE, out_w = dense ? 1 : L.out_w;
 						const int in_c = dense ? L.in_n : L.in_c, seg = (dense ? 1 : L.kw) * in_c, sw = dense ? 1 : L.sw;
 						const float inv_rec = __builtin_amdgcn_rcpf((float)R.rec_per_img), inv_row = __builtin_amdgcn_rcpf((float)(out_w * ML.cpr)), inv_cpr = __builtin_amdgcn_rcpf((float)ML.cpr);
@@ -675,7 +697,7 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 			}
 			else if (R.kind == ED_RUN_POOL4)
 			{
-				const ed_net_layer_t L = PL[li];
+				const ed_net_layer_t L = EMM_NETL(li);
 				/* four channels per thread: byte-wise signed maximum of dwords */
 				const int c4n = L.in_c >> 2, per_img = L.out_h * L.out_w * c4n;
 				const float inv_img = __builtin_amdgcn_rcpf((float)per_img), inv_c4 = __builtin_amdgcn_rcpf((float)c4n), inv_ow = __builtin_amdgcn_rcpf((float)L.out_w);
@@ -703,7 +725,7 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 			}
 			else if (R.kind == ED_RUN_POOL1)
 			{
-				const ed_net_layer_t L = PL[li];
+				const ed_net_layer_t L = EMM_NETL(li);
 				const int per_img = L.out_n;
 				for (int i = lane; i < nb * per_img; i += 64)
 				{
@@ -797,6 +819,27 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
 #endif
 }
 
+#if EMM_JIT
+/* the kernel of ONE graph: same arguments as the general one (P is not read, of M only the tables) */
+extern "C" __global__ __launch_bounds__(64 * EMM_SM_waves) void ed_net_mfma_spec(const ed_net_plan_t *__restrict__ P, const ed_mm_plan_t *__restrict__ M,
+                                                                             const int8_t *__restrict__ frag, const int32_t *__restrict__ seeds,
+                                                                             const int8_t *__restrict__ in, int64_t n, int64_t in_stride,
+                                                                             int8_t *__restrict__ logits, int8_t *__restrict__ softmax,
+                                                                             int32_t *__restrict__ argmax)
+{
+	emm_net_body<EMM_SM_frag_mode == 2>(P, M, frag, seeds, in, n, in_stride, logits, softmax, argmax);
+}
+#else
+template <bool FRAG_LDS>
+__global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_net_plan_t *__restrict__ P, const ed_mm_plan_t *__restrict__ M,
+                                                                 const int8_t *__restrict__ frag, const int32_t *__restrict__ seeds,
+                                                                 const int8_t *__restrict__ in, int64_t n, int64_t in_stride,
+                                                                 int8_t *__restrict__ logits, int8_t *__restrict__ softmax,
+                                                                 int32_t *__restrict__ argmax)
+{
+	emm_net_body<FRAG_LDS>(P, M, frag, seeds, in, n, in_stride, logits, softmax, argmax);
+}
+
 extern "C" int ed_launch_net_mfma(const ed_net_plan_t *dev_plan, const ed_mm_plan_t *dev_mm, const int8_t *dev_frag,
                                   const int32_t *dev_seeds, int lds_bytes, int batch, int waves, int frag_mode, const int8_t *in, int64_t n,
                                   int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu, hipStream_t stream)
@@ -826,3 +869,4 @@ extern "C" int ed_launch_net_mfma(const ed_net_plan_t *dev_plan, const ed_mm_pla
 	                 (void *)&logits, (void *)&softmax, (void *)&argmax};
 	return (int)hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(64 * waves), kargs, (size_t)lds_bytes, stream);
 }
+#endif /* !EMM_JIT */

@@ -63,6 +63,11 @@ struct edison_ctx
 	ed_mm_plan_t *d_mm_plan;
 	int8_t *d_mm_frag;
 	int32_t *d_mm_seeds;
+	/* ... and the graph's OWN kernel (edison_net_jit.hip: the same source compiled by hipRTC with this plan as constants) */
+	ed_mm_plan_t *h_mm_plan; /* host copy of the matrix-core plan: what the specialisation is generated from */
+	void *spec_mod, *spec_fn; /* hipModule_t / hipFunction_t */
+	int spec_epoch;           /* the model load (model_epoch) it was compiled for */
+	int spec_state;           /* 1: compiled by this process, 2: loaded from the on-disk cache */
 	/* growable device scratch for the host-pointer entry points and the fused KWS path */
 	void *scratch;
 	size_t scratch_bytes;
@@ -117,6 +122,10 @@ int ed_ctx_kws_cnn_launch_flag(edison_ctx *ctx, hipStream_t stream, const int8_t
                                int8_t *softmax, int32_t *argmax, unsigned *flag, unsigned seq, int *flag_written);
 int ed_ctx_net_launch_on(edison_ctx *ctx, hipStream_t stream, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax,
                          int32_t *argmax);
+/* edison_net_jit.hip */
+int ed_ctx_net_spec_launch(edison_ctx *ctx, hipStream_t stream, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax,
+                           int32_t *argmax);
+void ed_ctx_net_spec_drop(edison_ctx *ctx);
 int ed_ctx_mfcc_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
                           int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
                           int stages, float *fft, float *spec, float *mel, float *logmel);

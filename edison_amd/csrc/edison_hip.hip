@@ -131,6 +131,8 @@ extern "C" void edison_shutdown(edison_ctx *ctx)
 	if (ctx->d_net_plan) (void)hipFree(ctx->d_net_plan);
 	if (ctx->d_net_w) (void)hipFree(ctx->d_net_w);
 	if (ctx->d_net_seeds) (void)hipFree(ctx->d_net_seeds);
+	ed_ctx_net_spec_drop(ctx);
+	free(ctx->h_mm_plan);
 	if (ctx->d_mm_plan) (void)hipFree(ctx->d_mm_plan);
 	if (ctx->d_mm_frag) (void)hipFree(ctx->d_mm_frag);
 	if (ctx->d_mm_seeds) (void)hipFree(ctx->d_mm_seeds);
@@ -223,6 +225,9 @@ extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t b
 		/* the matrix-core plan of the same graph (any graph: model_net_mm.c); without one the graph stays on the
 		 * layer-by-layer kernel */
 		ctx->mm_ok = 0;
+		ed_ctx_net_spec_drop(ctx); /* the previous graph's own kernel (the device is idle: synchronised above) */
+		free(ctx->h_mm_plan);
+		ctx->h_mm_plan = NULL;
 		if (ctx->d_mm_frag) { (void)hipFree(ctx->d_mm_frag); ctx->d_mm_frag = NULL; }
 		if (ctx->d_mm_seeds) { (void)hipFree(ctx->d_mm_seeds); ctx->d_mm_seeds = NULL; }
 		if (e == hipSuccess)
@@ -238,7 +243,12 @@ extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t b
 				if (e == hipSuccess) e = hipMemcpy(ctx->d_mm_plan, mm, sizeof(ed_mm_plan_t), hipMemcpyHostToDevice);
 				if (e == hipSuccess) e = hipMemcpy(ctx->d_mm_frag, frag, (size_t)mm->frag_bytes, hipMemcpyHostToDevice);
 				if (e == hipSuccess) e = hipMemcpy(ctx->d_mm_seeds, mseeds, (size_t)mm->n_seeds * sizeof(int32_t), hipMemcpyHostToDevice);
-				if (e == hipSuccess) { ctx->mm_ok = 1; ctx->mm_lds = mm->lds_bytes; ctx->mm_batch = mm->batch; ctx->mm_waves = mm->waves; ctx->mm_frag_mode = mm->frag_mode; }
+				if (e == hipSuccess)
+				{
+					ctx->mm_ok = 1; ctx->mm_lds = mm->lds_bytes; ctx->mm_batch = mm->batch; ctx->mm_waves = mm->waves; ctx->mm_frag_mode = mm->frag_mode;
+					ctx->h_mm_plan = mm; /* kept: edison_net_specialize() generates the graph's own kernel from it */
+					mm = NULL;
+				}
 				else
 				{
 					/* the matrix-core plan is an accelerator, not the model: if its upload fails the graph still loads and
@@ -262,6 +272,10 @@ extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t b
 	free(plan); free(h); free(hm); free(w); free(seeds);
 	if (r != EDISON_OK) return r;
 	ED_HIP(ctx, e);
+	/* EDISON_NET_SPECIALIZE=1: every load compiles (or finds in the cache) the graph's own kernel. A failure there is not a
+	 * failed load: the graph runs on the general kernel and edison_net_specialized() says so. */
+	static const int auto_spec = getenv("EDISON_NET_SPECIALIZE") ? atoi(getenv("EDISON_NET_SPECIALIZE")) : 0;
+	if (auto_spec && ctx->mm_ok) (void)edison_net_specialize(ctx);
 	return EDISON_OK;
 }
 
@@ -441,6 +455,8 @@ int ed_ctx_net_launch(edison_ctx *ctx, const int8_t *in, int64_t n, int64_t in_s
 int ed_ctx_net_launch_on(edison_ctx *ctx, hipStream_t stream, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax)
 {
 	static const int no_mfma = getenv("EDISON_NET_NO_MFMA") ? atoi(getenv("EDISON_NET_NO_MFMA")) : 0;
+	if (ctx->mm_ok && !no_mfma && ctx->spec_fn && ctx->spec_epoch == ctx->model_epoch)
+		return ed_ctx_net_spec_launch(ctx, stream, in, n, in_stride, logits, softmax, argmax);
 	if (ctx->mm_ok && !no_mfma)
 		return ed_launch_net_mfma(ctx->d_net_plan, ctx->d_mm_plan, ctx->d_mm_frag, ctx->d_mm_seeds, ctx->mm_lds, ctx->mm_batch, ctx->mm_waves, ctx->mm_frag_mode, in, n,
 		                          in_stride, logits, softmax, argmax, ctx->n_cu, stream);

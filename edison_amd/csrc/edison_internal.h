@@ -326,6 +326,10 @@ typedef struct {
 int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *plan, ed_mm_plan_t *mm, int8_t **frag,
                    int32_t **seeds);
 
+/* The text that specialises ed_net_mfma_kernel for one graph (net_spec.c): returns the bytes it needs without the final 0. */
+size_t ed_emit_net_spec(const ed_net_plan_t *P, const ed_mm_plan_t *M, char *out, size_t cap);
+uint64_t ed_net_spec_hash(const ed_net_plan_t *P, const ed_mm_plan_t *M);
+
 /* ------------------------------------------------------------------ kernel launchers (HIP side)           */
 typedef struct {
 	const int16_t *audio;

@@ -128,6 +128,20 @@ int edison_net_batch_dev(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *l
 int edison_net_layers_dev(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *acts);
 int edison_net_batch(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *logits, int8_t *softmax, int32_t *argmax);
 int edison_net_layers(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *acts);
+/* The loaded graph's OWN kernel. NNoM fixes shapes, buffers and per-layer kernels once, in model_compile()
+ * (nnom.c:758-900); edison_net_specialize() goes one step further and compiles the general matrix-core kernel's source with
+ * this graph's plan as constants (hipRTC, ~1.5 s; code objects are cached on disk: $EDISON_JIT_CACHE, else
+ * $XDG_CACHE_HOME/edison_amd, else $HOME/.cache/edison_amd; "off" disables the cache). From then on every entry point that
+ * runs the general kernel for this load (edison_net_batch*, and edison_cnn_* / edison_kws_* / edison_stream_* for graphs
+ * other than kws_conv) runs the graph's own: same arithmetic, bit-identical outputs, kws_conv graph 198 -> 236 M inputs/s.
+ * EDISON_E_NO_IMPL: the graph has no matrix-core plan, or libhiprtc.so is not installed -- the graph stays on the general
+ * kernel. EDISON_NET_SPECIALIZE=1 in the environment makes every edison_model_load* do this by itself.
+ * edison_net_specialized: 0 general kernel, 1 own kernel compiled by this process, 2 own kernel taken from the cache.
+ * edison_net_spec_source (host only, no context): the generated constants of an .ednn blob, for inspection / offline builds;
+ * EDISON_E_SIZE with *need = bytes wanted when cap is too small. */
+int edison_net_specialize(edison_ctx *ctx);
+int edison_net_specialized(edison_ctx *ctx);
+int edison_net_spec_source(const void *ednn_blob, size_t blob_bytes, char *out, size_t cap, size_t *need);
 
 /* ---- device memory helpers (so a C caller needs nothing but this library) ---------------------------- */
 int edison_dev_alloc(edison_ctx *ctx, size_t bytes, void **dptr);

@@ -1,0 +1,123 @@
+"""GPU tests of edison_net_specialize (csrc/edison_net_jit.hip, net_spec.c): the loaded graph's OWN kernel -- the general
+matrix-core kernel's source compiled by hipRTC with the graph's plan as constants. Same arithmetic, so every comparison is
+bit for bit: against the reference-generated fixtures (tests/golden/net_golden.npz, NNoM 0.3.0 + CMSIS-NN built around the
+generated headers), against the numpy restatement on seeded batches, and against the general kernel on the same context."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = ["same_stride", "odd_no_softmax", "square", "kws_small", "tiny_conv", "low_latency_small", "even_same"]
+
+
+def _header(name):
+    return os.path.join(GOLDEN, "alt_models", name + ".h")
+
+
+def _blob(name):
+    from edison_amd import nnom_import
+    with open(_header(name)) as f:
+        shape, layers = nnom_import.parse_weights_h(f.read())
+    return nnom_import.build_blob(shape, layers)
+
+
+@pytest.fixture()
+def jit_cache(tmp_path, monkeypatch):
+    d = tmp_path / "jit"
+    monkeypatch.setenv("EDISON_JIT_CACHE", str(d))
+    return d
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_own_kernel_matches_reference_fixtures_and_general_kernel(built_lib, jit_cache, name):
+    from edison_amd.context import Context
+    from oracle import net_ref
+    g = np.load(os.path.join(GOLDEN, "net_golden.npz"))
+    c = Context(0, model_path=None)
+    c.load_weights_h(_header(name))
+    info = c.net_info()
+    n_in = info["in_h"] * info["in_w"] * info["in_c"]
+    rng = np.random.default_rng(77)
+    x = rng.integers(-128, 128, (3001, n_in)).astype(np.int8)      # more than one pass of the persistent grid, ragged end
+    x[:300] = rng.integers(-12, 13, (300, n_in))
+    x[300], x[301], x[302] = 0, 127, -128
+    assert c.net_specialized() == 0
+    general = c.net(x)
+    assert c.net_specialize() == 1 and c.net_specialized() == 1     # compiled here (the cache directory was empty)
+    assert len(list(jit_cache.glob("net_gfx950_*.hsaco"))) == 1
+    own = c.net(x)
+    ref = net_ref.run(_blob(name), x)
+    for k in ("logits", "argmax"):
+        assert np.array_equal(own[k], general[k]) and np.array_equal(own[k], ref[k]), k
+    if info["has_softmax"]:
+        assert np.array_equal(own["softmax"], general["softmax"])
+    # the reference's own outputs for this graph
+    xg, acts = g["in_" + name], g["acts_" + name]
+    last = info["layers"][-1]
+    final = acts[:, last["acts_offset"]:last["acts_offset"] + info["n_out"]]
+    out = c.net(xg)
+    if info["has_softmax"]:
+        pre = info["layers"][-2]
+        assert np.array_equal(out["softmax"], final)
+        assert np.array_equal(out["logits"], acts[:, pre["acts_offset"]:pre["acts_offset"] + info["n_out"]])
+    else:
+        assert np.array_equal(out["logits"], final)
+    assert np.array_equal(out["argmax"], np.argmax(final, axis=1))
+    assert c.net_specialize() == 1                                  # a second call changes nothing
+    c.close()
+    # a new context finds the code object in the cache
+    c2 = Context(0, model_path=None)
+    c2.load_weights_h(_header(name))
+    assert c2.net_specialize() == 2
+    again = c2.net(x)
+    assert np.array_equal(again["logits"], ref["logits"]) and np.array_equal(again["argmax"], ref["argmax"])
+    c2.close()
+
+
+def test_reload_drops_the_own_kernel_and_other_entry_points_use_it(built_lib, jit_cache, oracle_mod, oracle_model, monkeypatch):
+    """The shipped kws_conv graph kept off its hand-written kernel (EDISON_NET_FORCE_GENERAL) runs on the general kernel,
+    then on its own; a model load in between invalidates the own kernel of the previous graph."""
+    from edison_amd.context import Context
+    monkeypatch.setenv("EDISON_NET_FORCE_GENERAL", "1")
+    c = Context(0)
+    rng = np.random.default_rng(5)
+    feat = rng.integers(-128, 128, (2500, 403)).astype(np.int8)
+    o = oracle_mod.cnn(oracle_model, feat)
+    a = c.net(feat)
+    assert c.net_specialize() in (1, 2)
+    b = c.net(feat)
+    for k in ("logits", "softmax", "argmax"):
+        assert np.array_equal(a[k], o[k]) and np.array_equal(b[k], o[k]), k
+    c.load_weights_h(_header("kws_small"))
+    assert c.net_specialized() == 0                                 # another graph: the old code object is gone
+    assert c.net_specialize() in (1, 2) and c.net_specialized() in (1, 2)
+    c.close()
+
+
+def test_cache_can_be_switched_off_and_damaged_entries_are_replaced(built_lib, tmp_path, monkeypatch):
+    from edison_amd.context import Context
+    monkeypatch.setenv("EDISON_JIT_CACHE", "off")
+    c = Context(0, model_path=None)
+    c.load_weights_h(_header("tiny_conv"))
+    assert c.net_specialize() == 1
+    c.close()
+    d = tmp_path / "jit2"
+    monkeypatch.setenv("EDISON_JIT_CACHE", str(d))
+    c = Context(0, model_path=None)
+    c.load_weights_h(_header("tiny_conv"))
+    assert c.net_specialize() == 1
+    c.close()
+    (entry,) = list(d.glob("*.hsaco"))
+    entry.write_bytes(b"not a code object")
+    c = Context(0, model_path=None)
+    c.load_weights_h(_header("tiny_conv"))
+    with pytest.raises(Exception):
+        c.net_specialize()                                          # reported, the entry removed ...
+    assert c.net_specialized() == 0 and not entry.exists()
+    assert c.net_specialize() == 1                                  # ... and the next call compiles again
+    x = np.zeros((3, c.net_info()["in_h"] * c.net_info()["in_w"] * c.net_info()["in_c"]), np.int8)
+    c.net(x)
+    c.close()

@@ -412,3 +412,89 @@ int main(int argc, char **argv)
     # the advisor's first shape exceeds the capacity by construction: it must be the refusal
     r = subprocess.run([str(exe), str(tmp_path / "weights.ednn")], capture_output=True, text=True)
     assert r.stdout.startswith("-3 "), r.stdout
+
+
+# ---- the graph's own kernel (edison_net_specialize): what can be checked without a GPU
+def _alt_blob(name):
+    from edison_amd import nnom_import
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alt_models", name + ".h")) as f:
+        shape, layers = nnom_import.parse_weights_h(f.read())
+    return nnom_import.build_blob(shape, layers)
+
+
+def _hiprtc_compile(src, headers, opts):
+    """hipRTC through ctypes, the calls csrc/edison_net_jit.hip makes; returns (status, log, code-object bytes)."""
+    import ctypes
+    try:
+        R = ctypes.CDLL("libhiprtc.so")
+    except OSError:
+        try:
+            R = ctypes.CDLL("/opt/rocm/lib/libhiprtc.so")
+        except OSError:
+            pytest.skip("libhiprtc.so is not installed")
+    prog = ctypes.c_void_p()
+    hs = (ctypes.c_char_p * len(headers))(*[h[1] for h in headers])
+    hn = (ctypes.c_char_p * len(headers))(*[h[0] for h in headers])
+    R.hiprtcCreateProgram.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int,
+                                      ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p)]
+    assert R.hiprtcCreateProgram(ctypes.byref(prog), src, b"cnn_net_mfma_kernels.hip", len(headers), hs, hn) == 0
+    arr = (ctypes.c_char_p * len(opts))(*opts)
+    R.hiprtcCompileProgram.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
+    r = R.hiprtcCompileProgram(prog, len(opts), arr)
+    n = ctypes.c_size_t()
+    R.hiprtcGetProgramLogSize.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    R.hiprtcGetProgramLogSize(prog, ctypes.byref(n))
+    log = ctypes.create_string_buffer(n.value + 1)
+    R.hiprtcGetProgramLog.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    R.hiprtcGetProgramLog(prog, log)
+    R.hiprtcGetCodeSize.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    R.hiprtcGetCodeSize(prog, ctypes.byref(n))
+    code = ctypes.create_string_buffer(max(n.value, 1))
+    R.hiprtcGetCode.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    if r == 0:
+        R.hiprtcGetCode(prog, code)
+    return r, log.value.decode(errors="replace"), code.raw[:n.value]
+
+
+def test_net_spec_source_and_the_embedded_kernel_text(built_lib):
+    """edison_net_spec_source: the plan of a graph as C++ constants; the library carries the kernel's text and headers."""
+    import ctypes
+    from edison_amd import _lib
+    from edison_amd.context import net_spec_source
+    text = net_spec_source(open(_lib.DEFAULT_MODEL, "rb").read())
+    assert "#define EMM_SPEC_NL 8" in text and "#define EMM_SP_in_h 31" in text and "#define EMM_SP_in_w 13" in text
+    assert "#define EMM_SP_out_n 10" in text and "static constexpr ed_mm_run_t EMM_SR[EMM_SPEC_NL]" in text
+    assert text == net_spec_source(open(_lib.DEFAULT_MODEL, "rb").read())           # deterministic: the cache key hangs on it
+    assert text != net_spec_source(_alt_blob("kws_small"))
+    with pytest.raises(_lib.EdisonError):
+        net_spec_source(b"not a model")
+    L = _lib.lib()
+    for sym, path in (("ed_jit_src_kernel", "edison_amd/csrc/cnn_net_mfma_kernels.hip"), ("ed_jit_src_edison_hip_h", "include/edison_hip.h"),
+                      ("ed_jit_src_edison_internal_h", "edison_amd/csrc/edison_internal.h")):
+        n = ctypes.c_size_t.in_dll(L, sym + "_len").value
+        data = ctypes.string_at(ctypes.addressof((ctypes.c_ubyte * 1).in_dll(L, sym)), n)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        assert data == open(os.path.join(root, path), "rb").read(), sym            # the library is in step with the tree
+
+
+@pytest.mark.parametrize("name", ["(shipped)", "same_stride", "odd_no_softmax", "square", "kws_small", "tiny_conv", "low_latency_small", "even_same"])
+def test_own_kernel_compiles_for_every_fixture_graph(built_lib, name):
+    """The run-time compilation of edison_net_specialize, done here through hipRTC with the same text, headers and options
+    (it needs no GPU): every fixture graph's own kernel builds, exports ed_net_mfma_spec and spills nothing to scratch."""
+    import ctypes
+    from edison_amd import _lib
+    from edison_amd.context import net_spec_source
+    L = _lib.lib()
+    def text(sym):
+        n = ctypes.c_size_t.in_dll(L, sym + "_len").value
+        return ctypes.string_at(ctypes.addressof((ctypes.c_ubyte * 1).in_dll(L, sym)), n)
+    blob = open(_lib.DEFAULT_MODEL, "rb").read() if name == "(shipped)" else _alt_blob(name)
+    stdint = (b"#pragma once\ntypedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
+              b"typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;\n"
+              b"typedef unsigned long uintptr_t;\n")
+    headers = [(b"stdint.h", stdint), (b"stddef.h", b"#pragma once\n"), (b"edison_hip.h", text("ed_jit_src_edison_hip_h")),
+               (b"edison_internal.h", text("ed_jit_src_edison_internal_h")), (b"emm_spec.h", net_spec_source(blob).encode())]
+    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-fno-slp-vectorize", b"-DEMM_JIT=1", b"-DEMM_SPEC=1", b'-DEMM_SPEC_HEADER="emm_spec.h"']
+    r, log, code = _hiprtc_compile(text("ed_jit_src_kernel"), headers, opts)
+    assert r == 0, log[:2000]
+    assert b"ed_net_mfma_spec" in code and len(code) > 4096
