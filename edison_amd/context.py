@@ -173,14 +173,14 @@ class Context:
         return d
 
     def net_specialize(self):
-        """Compile (hipRTC) or fetch from the cache the loaded graph's OWN matrix-core kernel: edison_net_specialize. Returns
-        1 (compiled now) or 2 (from the cache); raises EdisonError (NO_IMPL) when the graph has no matrix-core plan or hipRTC
-        is not installed -- the graph then stays on the general kernel."""
+        """Compile or fetch from the cache the loaded graph's OWN matrix-core kernel: edison_net_specialize. Returns 1 (compiled
+        now by a hipcc child process), 2 (from the cache) or 3 (compiled now by hipRTC in this process); raises EdisonError
+        (NO_IMPL) when the graph has no matrix-core plan or no compiler is installed -- the graph then stays on the general kernel."""
         self._check(self._L.edison_net_specialize(self._h))
         return self.net_specialized()
 
     def net_specialized(self):
-        """0: general kernel, 1: the graph's own kernel compiled by this process, 2: ... loaded from the on-disk cache."""
+        """0: general kernel; the graph's own kernel: 1 compiled now by hipcc, 2 from the on-disk cache, 3 compiled now by hipRTC."""
         return int(self._L.edison_net_specialized(self._h))
 
     def net(self, x):

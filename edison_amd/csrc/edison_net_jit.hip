@@ -9,17 +9,28 @@
  * the layer loop unrolls, every choice is made by the compiler, nothing spills. Same arithmetic, bit-identical outputs
  * (tests/test_gpu_net_jit.py); kws_conv graph: 198 -> 236 M inputs/s on one box.
  *
- * The kernel text and the two headers it includes are compiled into the library (build.py: net_jit_sources.c), hipRTC is
- * found with dlopen at the first call, code objects are cached on disk by (graph hash, source hash):
- * $EDISON_JIT_CACHE, else $XDG_CACHE_HOME/edison_amd, else $HOME/.cache/edison_amd; EDISON_JIT_CACHE=off disables the cache.
- * Without hipRTC, or when the compilation fails, the call reports it and the graph stays on the general kernel -- which is
- * the same algorithm on the same device, not a fallback to other code.
+ * The kernel text and the two headers it includes are compiled into the library (build.py: net_jit_sources.c). Two compilers,
+ * EDISON_JIT_COMPILER=hipcc|hiprtc picks one, the default tries them in this order:
+ *   hipcc   a child process ($EDISON_HIPCC, $ROCM_PATH/bin/hipcc, /opt/rocm/bin/hipcc, hipcc on PATH) on a temporary copy of
+ *           the text: the installed ROCm's compiler, the one that built the library itself;
+ *   hiprtc  in-process (dlopen). A process that already carries ANOTHER ROCm's compiler library gets that one -- a PyTorch
+ *           wheel bundles libamd_comgr.so of ROCm 7.0, and the same text comes out 30 % longer with 14 spilled scalars
+ *           (211 M inputs/s instead of 236 M on kws_conv) -- which is why the child process goes first.
+ * Code objects are cached on disk by (graph hash, source hash, compiler): $EDISON_JIT_CACHE, else $XDG_CACHE_HOME/edison_amd,
+ * else $HOME/.cache/edison_amd; EDISON_JIT_CACHE=off disables the cache. Without a compiler, or when the compilation fails,
+ * the call reports it and the graph stays on the general kernel -- the same algorithm on the same device, not other code.
  */
 #include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <spawn.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
+
+extern char **environ;
 
 #include "edison_ctx.h"
 
@@ -67,7 +78,7 @@ static uint64_t fnv(uint64_t h, const void *p, size_t n)
 }
 
 /* "" = no cache */
-static void cache_path(char *out, size_t cap, uint64_t graph, uint64_t source)
+static void cache_path(char *out, size_t cap, uint64_t graph, uint64_t source, const char *compiler)
 {
 	out[0] = 0;
 	const char *dir = getenv("EDISON_JIT_CACHE");
@@ -83,7 +94,7 @@ static void cache_path(char *out, size_t cap, uint64_t graph, uint64_t source)
 	}
 	else return;
 	(void)mkdir(base, 0700);
-	snprintf(out, cap, "%s/net_gfx950_%016llx_%016llx.hsaco", base, (unsigned long long)graph, (unsigned long long)source);
+	snprintf(out, cap, "%s/net_gfx950_%016llx_%016llx_%s.hsaco", base, (unsigned long long)graph, (unsigned long long)source, compiler);
 }
 
 static char *read_file(const char *path, size_t *n)
@@ -108,6 +119,130 @@ static void write_file_atomic(const char *path, const char *data, size_t n)
 	if (!f) return;
 	const int ok = fwrite(data, 1, n, f) == n;
 	if (fclose(f) != 0 || !ok || rename(tmp, path) != 0) (void)remove(tmp);
+}
+
+static int write_text(const char *dir, const char *name, const void *data, size_t n)
+{
+	char p[700];
+	snprintf(p, sizeof(p), "%s/%s", dir, name);
+	FILE *f = fopen(p, "wb");
+	if (!f) return 0;
+	const int ok = fwrite(data, 1, n, f) == n;
+	return fclose(f) == 0 && ok;
+}
+
+static int find_hipcc(char *out, size_t cap)
+{
+	const char *env = getenv("EDISON_HIPCC");
+	if (env && env[0]) { snprintf(out, cap, "%s", env); return access(out, X_OK) == 0; }
+	if (getenv("ROCM_PATH") && getenv("ROCM_PATH")[0])
+	{
+		snprintf(out, cap, "%s/bin/hipcc", getenv("ROCM_PATH"));
+		if (access(out, X_OK) == 0) return 1;
+	}
+	snprintf(out, cap, "/opt/rocm/bin/hipcc");
+	if (access(out, X_OK) == 0) return 1;
+	const char *path = getenv("PATH");
+	while (path && *path)
+	{
+		const char *end = strchr(path, ':');
+		const size_t len = end ? (size_t)(end - path) : strlen(path);
+		if (len && len + 8 < cap)
+		{
+			snprintf(out, cap, "%.*s/hipcc", (int)len, path);
+			if (access(out, X_OK) == 0) return 1;
+		}
+		path = end ? end + 1 : NULL;
+	}
+	return 0;
+}
+
+/* The installed compiler as a child process on a temporary copy of the text. 1: *code / *code_bytes hold the code object
+ * (malloc'd), 0: no hipcc on this machine, -1: it ran and failed (text in ctx->err). */
+static int compile_with_hipcc(edison_ctx *ctx, const char *spec, char **code, size_t *code_bytes)
+{
+	char hipcc[512];
+	if (!find_hipcc(hipcc, sizeof(hipcc))) return 0;
+	const char *tmp = getenv("TMPDIR") && getenv("TMPDIR")[0] ? getenv("TMPDIR") : "/tmp";
+	char dir[600];
+	snprintf(dir, sizeof(dir), "%s/edison_jit_XXXXXX", tmp);
+	if (!mkdtemp(dir)) { snprintf(ctx->err, sizeof(ctx->err), "edison_net_specialize: cannot create a directory under %s", tmp); return -1; }
+	char src[700], out[700], log[700], inc[700];
+	snprintf(src, sizeof(src), "%s/cnn_net_mfma_kernels.hip", dir);
+	snprintf(out, sizeof(out), "%s/own.hsaco", dir);
+	snprintf(log, sizeof(log), "%s/hipcc.log", dir);
+	snprintf(inc, sizeof(inc), "-I%s", dir);
+	int r = -1;
+	if (write_text(dir, "cnn_net_mfma_kernels.hip", ed_jit_src_kernel, ed_jit_src_kernel_len) &&
+	    write_text(dir, "edison_hip.h", ed_jit_src_edison_hip_h, ed_jit_src_edison_hip_h_len) &&
+	    write_text(dir, "edison_internal.h", ed_jit_src_edison_internal_h, ed_jit_src_edison_internal_h_len) &&
+	    write_text(dir, "emm_spec.h", spec, strlen(spec)))
+	{
+		/* device code only, a plain ELF code object (no offload bundle) */
+		const char *argv[] = {hipcc, "--offload-arch=gfx950", "--cuda-device-only", "--no-gpu-bundle-output", "-O3", "-std=c++17", "-fno-slp-vectorize",
+		                      "-DEMM_JIT=1", "-DEMM_SPEC=1", "-DEMM_SPEC_HEADER=\"emm_spec.h\"", "-include", "hip/hip_runtime.h", inc, "-x", "hip", "-c", src, "-o", out, NULL};
+		posix_spawn_file_actions_t fa;
+		posix_spawn_file_actions_init(&fa);
+		posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+		posix_spawn_file_actions_addopen(&fa, 1, log, O_WRONLY | O_CREAT | O_TRUNC, 0600);
+		posix_spawn_file_actions_adddup2(&fa, 1, 2);
+		pid_t pid = 0;
+		int status = 0;
+		const int sp = posix_spawn(&pid, hipcc, &fa, NULL, (char *const *)argv, environ);
+		posix_spawn_file_actions_destroy(&fa);
+		if (sp != 0) snprintf(ctx->err, sizeof(ctx->err), "edison_net_specialize: cannot start %s: %s", hipcc, strerror(sp));
+		else
+		{
+			while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+			*code = WIFEXITED(status) && WEXITSTATUS(status) == 0 ? read_file(out, code_bytes) : NULL;
+			if (*code) r = 1;
+			else
+			{
+				size_t ln = 0;
+				char *text = read_file(log, &ln);
+				snprintf(ctx->err, sizeof(ctx->err), "edison_net_specialize: %s failed (status %d): %.*s", hipcc, status, (int)(ln < 300 ? ln : 300), text ? text : "");
+				free(text);
+			}
+		}
+	}
+	else snprintf(ctx->err, sizeof(ctx->err), "edison_net_specialize: cannot write the kernel text under %s", dir);
+	static const char *files[] = {"cnn_net_mfma_kernels.hip", "edison_hip.h", "edison_internal.h", "emm_spec.h", "own.hsaco", "hipcc.log"};
+	for (size_t k = 0; k < sizeof(files) / sizeof(files[0]); k++)
+	{
+		char f[700];
+		snprintf(f, sizeof(f), "%s/%s", dir, files[k]);
+		(void)remove(f);
+	}
+	(void)rmdir(dir);
+	return r;
+}
+
+/* hipRTC in this process. 1 / 0 (no libhiprtc.so) / -1 as above. */
+static int compile_with_hiprtc(edison_ctx *ctx, const char *spec, char **code, size_t *code_bytes)
+{
+	rtc_api rtc;
+	if (!rtc_load(&rtc)) return 0;
+	const char *headers[] = {k_stdint_h, k_stddef_h, (const char *)ed_jit_src_edison_hip_h, (const char *)ed_jit_src_edison_internal_h, spec};
+	const char *names[] = {"stdint.h", "stddef.h", "edison_hip.h", "edison_internal.h", "emm_spec.h"};
+	const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DEMM_JIT=1", "-DEMM_SPEC=1", "-DEMM_SPEC_HEADER=\"emm_spec.h\""};
+	rtc_program prog = NULL;
+	int r = rtc.CreateProgram(&prog, (const char *)ed_jit_src_kernel, "cnn_net_mfma_kernels.hip", 5, headers, names);
+	if (r == 0) r = rtc.CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+	if (r != 0)
+	{
+		size_t ln = 0;
+		char *log = NULL;
+		if (prog && rtc.GetProgramLogSize(prog, &ln) == 0 && ln > 1 && (log = (char *)malloc(ln + 1)) != NULL && rtc.GetProgramLog(prog, log) == 0) log[ln] = 0;
+		snprintf(ctx->err, sizeof(ctx->err), "edison_net_specialize: hipRTC error %d: %.400s", r, log ? log : "(no log)");
+		free(log);
+		if (prog) (void)rtc.DestroyProgram(&prog);
+		return -1;
+	}
+	*code = NULL;
+	if (rtc.GetCodeSize(prog, code_bytes) == 0 && *code_bytes > 0 && (*code = (char *)malloc(*code_bytes)) != NULL && rtc.GetCode(prog, *code) != 0) { free(*code); *code = NULL; }
+	(void)rtc.DestroyProgram(&prog);
+	if (!*code) { (void)ed_set_err(ctx, EDISON_E_RUNTIME, "edison_net_specialize: hipRTC returned no code object"); return -1; }
+	return 1;
 }
 
 void ed_ctx_net_spec_drop(edison_ctx *ctx)
@@ -140,39 +275,33 @@ extern "C" int edison_net_specialize(edison_ctx *ctx)
 	source = fnv(source, ed_jit_src_edison_internal_h, ed_jit_src_edison_internal_h_len);
 	source = fnv(source, k_stdint_h, sizeof(k_stdint_h));
 
+	const char *want = getenv("EDISON_JIT_COMPILER");
+	const int try_hipcc = !want || !want[0] || !strcmp(want, "hipcc"), try_rtc = !want || !want[0] || !strcmp(want, "hiprtc");
+	if (!try_hipcc && !try_rtc) { free(spec); return ed_set_err(ctx, EDISON_E_ARGUMENT, "EDISON_JIT_COMPILER: hipcc or hiprtc"); }
 	char path[600];
-	cache_path(path, sizeof(path), graph, source);
 	size_t code_bytes = 0;
-	char *code = path[0] ? read_file(path, &code_bytes) : NULL;
-	int from_cache = code != NULL;
+	char *code = NULL;
+	int state = 0; /* 1: hipcc, 2: cache, 3: hipRTC */
+	/* the cache: an entry made by the compiler that would be tried first, then the other's */
+	for (int k = 0; k < 2 && !code; k++)
+	{
+		const int is_hipcc = k == 0;
+		if (is_hipcc ? !try_hipcc : !try_rtc) continue;
+		cache_path(path, sizeof(path), graph, source, is_hipcc ? "hipcc" : "hiprtc");
+		if (path[0] && (code = read_file(path, &code_bytes)) != NULL) state = 2;
+	}
 	if (!code)
 	{
-		rtc_api rtc;
-		if (!rtc_load(&rtc))
+		int r = try_hipcc ? compile_with_hipcc(ctx, spec, &code, &code_bytes) : 0;
+		if (r == 1) state = 1;
+		if (r == 0 && try_rtc && (r = compile_with_hiprtc(ctx, spec, &code, &code_bytes)) == 1) state = 3;
+		if (r != 1)
 		{
 			free(spec);
-			return ed_set_err(ctx, EDISON_E_NO_IMPL, "edison_net_specialize: libhiprtc.so not found (the graph stays on the general kernel)");
-		}
-		const char *headers[] = {k_stdint_h, k_stddef_h, (const char *)ed_jit_src_edison_hip_h, (const char *)ed_jit_src_edison_internal_h, spec};
-		const char *names[] = {"stdint.h", "stddef.h", "edison_hip.h", "edison_internal.h", "emm_spec.h"};
-		const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DEMM_JIT=1", "-DEMM_SPEC=1", "-DEMM_SPEC_HEADER=\"emm_spec.h\""};
-		rtc_program prog = NULL;
-		int r = rtc.CreateProgram(&prog, (const char *)ed_jit_src_kernel, "cnn_net_mfma_kernels.hip", 5, headers, names);
-		if (r == 0) r = rtc.CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
-		if (r != 0)
-		{
-			size_t ln = 0;
-			char *log = NULL;
-			if (prog && rtc.GetProgramLogSize(prog, &ln) == 0 && ln > 1 && (log = (char *)malloc(ln + 1)) != NULL && rtc.GetProgramLog(prog, log) == 0) log[ln] = 0;
-			snprintf(ctx->err, sizeof(ctx->err), "edison_net_specialize: hipRTC error %d: %.400s", r, log ? log : "(no log)");
-			free(log);
-			if (prog) (void)rtc.DestroyProgram(&prog);
-			free(spec);
+			if (r == 0) return ed_set_err(ctx, EDISON_E_NO_IMPL, "edison_net_specialize: neither hipcc nor libhiprtc.so found (the graph stays on the general kernel)");
 			return EDISON_E_RUNTIME;
 		}
-		if (rtc.GetCodeSize(prog, &code_bytes) == 0 && code_bytes > 0 && (code = (char *)malloc(code_bytes)) != NULL && rtc.GetCode(prog, code) != 0) { free(code); code = NULL; }
-		(void)rtc.DestroyProgram(&prog);
-		if (!code) { free(spec); return ed_set_err(ctx, EDISON_E_RUNTIME, "edison_net_specialize: hipRTC returned no code object"); }
+		cache_path(path, sizeof(path), graph, source, state == 1 ? "hipcc" : "hiprtc");
 		if (path[0]) write_file_atomic(path, code, code_bytes);
 	}
 	free(spec);
@@ -185,7 +314,7 @@ extern "C" int edison_net_specialize(edison_ctx *ctx)
 	if (e != hipSuccess)
 	{
 		if (mod) (void)hipModuleUnload(mod);
-		if (from_cache && path[0]) (void)remove(path); /* a damaged cache entry: the next call compiles again */
+		if (state == 2 && path[0]) (void)remove(path); /* a damaged cache entry: the next call compiles again */
 		snprintf(ctx->err, sizeof(ctx->err), "edison_net_specialize: loading the code object failed: %s", hipGetErrorString(e));
 		(void)hipGetLastError();
 		return EDISON_E_RUNTIME;
@@ -195,11 +324,12 @@ extern "C" int edison_net_specialize(edison_ctx *ctx)
 	ctx->spec_mod = (void *)mod;
 	ctx->spec_fn = (void *)fn;
 	ctx->spec_epoch = ctx->model_epoch;
-	ctx->spec_state = from_cache ? 2 : 1;
+	ctx->spec_state = state;
 	return EDISON_OK;
 }
 
-/* 0: the loaded graph runs on the general kernel, 1: on its own kernel compiled by this process, 2: ... loaded from the cache */
+/* 0: the loaded graph runs on the general kernel; on its own kernel: 1 compiled just now by the hipcc child process, 2 taken
+ * from the cache, 3 compiled just now by hipRTC in this process */
 extern "C" int edison_net_specialized(edison_ctx *ctx)
 {
 	return ctx && ctx->spec_fn && ctx->spec_epoch == ctx->model_epoch ? ctx->spec_state : 0;

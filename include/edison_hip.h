@@ -130,13 +130,15 @@ int edison_net_batch(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *logit
 int edison_net_layers(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *acts);
 /* The loaded graph's OWN kernel. NNoM fixes shapes, buffers and per-layer kernels once, in model_compile()
  * (nnom.c:758-900); edison_net_specialize() goes one step further and compiles the general matrix-core kernel's source with
- * this graph's plan as constants (hipRTC, ~1.5 s; code objects are cached on disk: $EDISON_JIT_CACHE, else
+ * this graph's plan as constants (~2 s; code objects are cached on disk: $EDISON_JIT_CACHE, else
  * $XDG_CACHE_HOME/edison_amd, else $HOME/.cache/edison_amd; "off" disables the cache). From then on every entry point that
  * runs the general kernel for this load (edison_net_batch*, and edison_cnn_* / edison_kws_* / edison_stream_* for graphs
  * other than kws_conv) runs the graph's own: same arithmetic, bit-identical outputs, kws_conv graph 198 -> 236 M inputs/s.
- * EDISON_E_NO_IMPL: the graph has no matrix-core plan, or libhiprtc.so is not installed -- the graph stays on the general
+ * EDISON_E_NO_IMPL: the graph has no matrix-core plan, or neither hipcc nor libhiprtc.so is installed -- the graph stays on the general
  * kernel. EDISON_NET_SPECIALIZE=1 in the environment makes every edison_model_load* do this by itself.
- * edison_net_specialized: 0 general kernel, 1 own kernel compiled by this process, 2 own kernel taken from the cache.
+ * edison_net_specialized: 0 general kernel; own kernel: 1 compiled just now by a hipcc child process (the installed ROCm's
+ * compiler, tried first), 2 taken from the cache, 3 compiled just now by hipRTC in this process (EDISON_JIT_COMPILER=hipcc|hiprtc
+ * picks one).
  * edison_net_spec_source (host only, no context): the generated constants of an .ednn blob, for inspection / offline builds;
  * EDISON_E_SIZE with *need = bytes wanted when cap is too small. */
 int edison_net_specialize(edison_ctx *ctx);

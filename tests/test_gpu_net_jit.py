@@ -46,7 +46,7 @@ def test_own_kernel_matches_reference_fixtures_and_general_kernel(built_lib, jit
     x[300], x[301], x[302] = 0, 127, -128
     assert c.net_specialized() == 0
     general = c.net(x)
-    assert c.net_specialize() == 1 and c.net_specialized() == 1     # compiled here (the cache directory was empty)
+    assert c.net_specialize() in (1, 3) and c.net_specialized() in (1, 3)   # compiled here (the cache directory was empty)
     assert len(list(jit_cache.glob("net_gfx950_*.hsaco"))) == 1
     own = c.net(x)
     ref = net_ref.run(_blob(name), x)
@@ -66,7 +66,7 @@ def test_own_kernel_matches_reference_fixtures_and_general_kernel(built_lib, jit
     else:
         assert np.array_equal(out["logits"], final)
     assert np.array_equal(out["argmax"], np.argmax(final, axis=1))
-    assert c.net_specialize() == 1                                  # a second call changes nothing
+    assert c.net_specialize() in (1, 3)                             # a second call changes nothing
     c.close()
     # a new context finds the code object in the cache
     c2 = Context(0, model_path=None)
@@ -87,13 +87,13 @@ def test_reload_drops_the_own_kernel_and_other_entry_points_use_it(built_lib, ji
     feat = rng.integers(-128, 128, (2500, 403)).astype(np.int8)
     o = oracle_mod.cnn(oracle_model, feat)
     a = c.net(feat)
-    assert c.net_specialize() in (1, 2)
+    assert c.net_specialize() in (1, 2, 3)
     b = c.net(feat)
     for k in ("logits", "softmax", "argmax"):
         assert np.array_equal(a[k], o[k]) and np.array_equal(b[k], o[k]), k
     c.load_weights_h(_header("kws_small"))
     assert c.net_specialized() == 0                                 # another graph: the old code object is gone
-    assert c.net_specialize() in (1, 2) and c.net_specialized() in (1, 2)
+    assert c.net_specialize() in (1, 2, 3) and c.net_specialized() in (1, 2, 3)
     c.close()
 
 
@@ -102,13 +102,13 @@ def test_cache_can_be_switched_off_and_damaged_entries_are_replaced(built_lib, t
     monkeypatch.setenv("EDISON_JIT_CACHE", "off")
     c = Context(0, model_path=None)
     c.load_weights_h(_header("tiny_conv"))
-    assert c.net_specialize() == 1
+    assert c.net_specialize() in (1, 3)
     c.close()
     d = tmp_path / "jit2"
     monkeypatch.setenv("EDISON_JIT_CACHE", str(d))
     c = Context(0, model_path=None)
     c.load_weights_h(_header("tiny_conv"))
-    assert c.net_specialize() == 1
+    assert c.net_specialize() in (1, 3)
     c.close()
     (entry,) = list(d.glob("*.hsaco"))
     entry.write_bytes(b"not a code object")
@@ -117,7 +117,30 @@ def test_cache_can_be_switched_off_and_damaged_entries_are_replaced(built_lib, t
     with pytest.raises(Exception):
         c.net_specialize()                                          # reported, the entry removed ...
     assert c.net_specialized() == 0 and not entry.exists()
-    assert c.net_specialize() == 1                                  # ... and the next call compiles again
+    assert c.net_specialize() in (1, 3)                             # ... and the next call compiles again
     x = np.zeros((3, c.net_info()["in_h"] * c.net_info()["in_w"] * c.net_info()["in_c"]), np.int8)
     c.net(x)
+    c.close()
+
+
+@pytest.mark.parametrize("compiler,state", [("hipcc", 1), ("hiprtc", 3)])
+def test_both_compilers_give_the_same_answers(built_lib, jit_cache, monkeypatch, compiler, state):
+    """EDISON_JIT_COMPILER: the installed hipcc as a child process, or hipRTC inside this process (which, beside PyTorch, is the
+    compiler library the wheel bundles: other code, same results)."""
+    import shutil
+    from edison_amd.context import Context
+    from oracle import net_ref
+    if compiler == "hipcc" and not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("no hipcc on this machine")
+    monkeypatch.setenv("EDISON_JIT_COMPILER", compiler)
+    c = Context(0, model_path=None)
+    c.load_weights_h(_header("kws_small"))
+    assert c.net_specialize() == state
+    (entry,) = list(jit_cache.glob("*.hsaco"))
+    assert entry.name.endswith("_%s.hsaco" % compiler)
+    info = c.net_info()
+    x = np.random.default_rng(3).integers(-128, 128, (2000, info["in_h"] * info["in_w"] * info["in_c"])).astype(np.int8)
+    ref = net_ref.run(_blob("kws_small"), x)
+    out = c.net(x)
+    assert np.array_equal(out["logits"], ref["logits"]) and np.array_equal(out["argmax"], ref["argmax"])
     c.close()

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--header", default=None)
 ap.add_argument("--n", type=int, default=262144)
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--specialize", action="store_true", help="time the general kernel, then the graph's own (edison_net_specialize)")
 a = ap.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -51,4 +52,12 @@ def timed(fn, tag):
 L = ctx._L
 timed(lambda: ctx._check(L.edison_net_batch_dev(ctx._h, _t_ptr(x), a.n, _t_ptr(logits), None, _t_ptr(am))),
       "edison_net_batch_dev (%s)" % {0: "layer-by-layer VALU kernel", 1: "kws_conv matrix-core kernel", 2: "general matrix-core kernel"}[2 if os.environ.get("EDISON_NET_FORCE_GENERAL") == "1" and info["accelerated"] == 1 else info["accelerated"]])
+if a.specialize:
+    import time
+    t0 = time.time()
+    st_ = ctx.net_specialize()
+    print("edison_net_specialize: %s in %.2f s" % ({1: "compiled by hipcc", 2: "from the cache", 3: "compiled by hipRTC"}[st_], time.time() - t0))
+    l2, a2 = torch.empty_like(logits), torch.empty_like(am)
+    timed(lambda: ctx._check(L.edison_net_batch_dev(ctx._h, _t_ptr(x), a.n, _t_ptr(l2), None, _t_ptr(a2))), "edison_net_batch_dev (the graph's own kernel)")
+    print("own kernel == general kernel: logits %s argmax %s" % (torch.equal(l2, logits), torch.equal(a2, am)))
 timed(lambda: ctx._check(L.edison_net_layers_dev(ctx._h, _t_ptr(x), a.n, _t_ptr(acts))), "edison_net_layers_dev (general + dumps)")
