@@ -497,7 +497,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int n_threads = blockDim.x, n_waves = n_threads >> 6;
 	/* small tables, copied once per workgroup: chunk offsets of every layer | seeds | column, expansion, input tables; then
-	 * the weight fragments (when resident); then one slice per wave: two ping-pong activation buffers and the expansion
+	 * the weight fragments (when resident); then one slice per wave: the activation region and the expansion
 	 * buffer */
 	lds8 *tbl = emm_lds;
 	EMM_CONST int n_koff = EMM_MF(n_koff), n_seeds = EMM_MF(n_seeds), n_coltab = EMM_MF(n_cols);
@@ -509,8 +509,8 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 	EMM_LDS uint16_t *intab_l = reinterpret_cast<EMM_LDS uint16_t *>(reinterpret_cast<lds8 *>(xtab_l) + ((8 * n_xtab + 15) & ~15));
 	lds8 *fragl = tbl + EMM_MF(tbl_bytes);
 	lds8 *slice = fragl + EMM_MF(frag_lds) + wave * (2 * buf_bytes + EMM_MF(x_bytes));
-	lds8 *bufs[2] = {slice, slice + buf_bytes};
-	lds8 *xbuf = slice + 2 * buf_bytes;
+	lds8 *xbuf = slice + 2 * buf_bytes; /* the activation region in front of it: a layer's input at one end, its output at the other */
+	lds8 *in0 = slice + EMM_RUN(0).in_off; /* (layer 0 always runs: a MaxPool is only skipped behind a convolution) */
 	{
 		for (int i = threadIdx.x; i < n_koff; i += n_threads) koff_all[i] = M->koff[i];
 		for (int i = threadIdx.x; i < n_seeds; i += n_threads) seeds_l[i] = seeds[i];
@@ -548,7 +548,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 			EMM_CONST int in_h = EMM_PF(in_h), in_w = EMM_PF(in_w), in_c = EMM_PF(in_c), in_n = EMM_PF(in_n);
 			if (l0.hp != in_h || l0.wp != in_w) /* uniform: a zero border to keep */
 			{
-				emm_zero(bufs[0], batch * l0.img, lane);
+				emm_zero(in0, batch * l0.img, lane);
 				emm_sync();
 			}
 			if (EMM_SKIP & 8) {}
@@ -565,7 +565,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 					const int e = 4 * lane + 256 * k;
 #pragma unroll
 					for (int t = 0; t < 4; t++)
-						if (e + t < in_n) bufs[0][intab_l[e + t]] = (int8_t)(v[k] >> (8 * t));
+						if (e + t < in_n) in0[intab_l[e + t]] = (int8_t)(v[k] >> (8 * t));
 				}
 			}
 			else if (n_intab)
@@ -574,7 +574,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 				for (int b = 0; b < nb; b++)
 				{
 					const int8_t *src = in + (u0 + b) * in_stride;
-					lds8 *dst = bufs[0] + b * l0.img;
+					lds8 *dst = in0 + b * l0.img;
 					for (int e = 4 * lane; e < in_n; e += 256)
 					{
 						uint32_t v;
@@ -612,14 +612,13 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 						if (i >= nb * in_n) continue;
 						int b, e, pix, c, y, x;
 						emm_divmod(i, in_n, inv_n, b, e); emm_divmod(e, in_c, inv_c, pix, c); emm_divmod(pix, in_w, inv_w, y, x);
-						bufs[0][b * l0.img + ((y + l0.py) * l0.wp + x + l0.px) * in_c + c] = v[k];
+						in0[b * l0.img + ((y + l0.py) * l0.wp + x + l0.px) * in_c + c] = v[k];
 					}
 				}
 			}
 			emm_sync();
 		}
 		EMM_ST(0)
-		int cur = 0;
 		EMM_UNROLL_LAYERS
 		for (int li = 0; li < n_layers; li++)
 		{
@@ -628,9 +627,8 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 			 * scalar loads and ~100 scalar instructions per layer and input) */
 			const ed_mm_run_t R = EMM_RUN(li);
 			if (R.kind == ED_RUN_SKIP) continue; /* a MaxPool taken in the epilogue of the layer in front of it */
-			const lds8 *a = bufs[cur];
-			lds8 *o = bufs[cur ^ 1];
-			cur ^= 1;
+			const lds8 *a = slice + R.in_off;
+			lds8 *o = slice + R.o_off;
 			if (R.zero_border) /* uniform: the consumer wants a zero border */
 			{
 				emm_zero(o, batch * R.o_img, lane);

@@ -265,6 +265,8 @@ typedef struct {
 	int32_t small;              /* 1: at most 16 columns per wave and nothing fused: v_mfma_i32_16x16x64_i8 tiles (16 rows x
 	                             * 16 columns, four 16-byte chunks per k-step); n_ks16 / n_rt16 count those                */
 	int32_t n_ks16, n_rt16;
+	int32_t toep;               /* 1: row-Toeplitz form (model_net_mm.c): the GEMM's rows are (output x, output channel), k runs over
+	                             * (kernel row, byte of the whole padded input row), one column per output row; no expansion     */
 } ed_mm_layer_t;
 
 /* What one pass of the kernel's layer loop needs, worked out on the host: one 128-byte record per layer that the wave
@@ -284,7 +286,9 @@ typedef struct {
 	int32_t out_c, rs, lo_clamp;
 	int32_t in_n;               /* Softmax: classes                                                                    */
 	int32_t small;              /* 1: the 16 x 16 x 64 tiles (n_ks / n_rt then count those)                            */
-	int32_t pad_[2];
+	int32_t in_off, o_off;      /* where the layer's input / output images start inside the wave's activation region: the
+	                             * planner places them at opposite ends, so the region is max(in + out) over the layers, not
+	                             * twice the largest image                                                                  */
 } ed_mm_run_t;
 #if defined(__cplusplus)
 static_assert(sizeof(ed_mm_run_t) == 128, "ed_mm_run_t: one 128-byte record per layer (two s_load_dwordx16)");
@@ -296,7 +300,7 @@ typedef struct {
 	int32_t ok;                 /* 0: this graph stays on the layer-by-layer kernel (why: the loader's error text)     */
 	int32_t batch;              /* inputs a WAVEFRONT takes through the layer list at a time                          */
 	int32_t waves;              /* wavefronts per workgroup: each works alone in its own LDS slice (no workgroup barrier) */
-	int32_t buf_bytes;          /* each of a wave's two ping-pong activation buffers                                  */
+	int32_t buf_bytes;          /* HALF of a wave's activation region (the two ends the layers ping-pong between)      */
 	int32_t x_bytes;            /* a wave's expansion buffer                                                          */
 	int32_t lds_bytes;
 	int32_t frag_lds;           /* bytes of LDS reserved for weight fragments                                         */

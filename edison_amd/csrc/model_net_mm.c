@@ -58,8 +58,38 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		M->n_ks = (kh * M->cpr + 1) / 2;
 		M->n_rt = (L->out_c + 31) / 32;
 		M->expand = (in_c % 16) != 0;
+		/* Row-Toeplitz form of a convolution over a NARROW image with few channels (a spectrogram: C_in = 1): the GEMM's rows
+		 * are (output x, output channel) pairs, its k runs over (kernel row, byte of the WHOLE zero-padded input row, 16-byte
+		 * aligned by construction), its columns are the output rows. A[(x, oc)][ky][q] = w[oc][ky][q / C_in - x * sw][q % C_in]
+		 * where that tap exists, else 0. No expanded copy of the input (the expansion pass and its LDS buffer -- 4.4 KB per
+		 * input on kws_conv, more than both activation buffers together -- disappear), and the output row of a column is
+		 * contiguous in the consumer's HWC layout, so the epilogue is the ordinary one with out_w * C_out "channels".
+		 * Taken when the plain form would need the expansion, the padded row fits four chunks and the matrix-core work does
+		 * not grow by more than half. EDISON_NET_NO_TOEPLITZ=1: A/B knob. */
+		if (!dense && M->expand)
+		{
+			const char *env = getenv("EDISON_NET_NO_TOEPLITZ");
+			const int rowb = up16(M->in_wp * in_c), rows = L->out_w * L->out_c;
+			const int64_t plain = (int64_t)M->n_rt * ((out_h * out_w + 31) / 32) * M->n_ks;
+			const int64_t toep = (int64_t)((rows + 31) / 32) * ((out_h + 31) / 32) * ((kh * (rowb / 16) + 1) / 2);
+			if (!(env && atoi(env)) && rowb <= 64 && rowb % in_c == 0 && rows <= 1024 && 2 * toep <= 3 * plain)
+			{
+				M->toep = 1;
+				M->in_wp = rowb / in_c;               /* zero columns behind the image up to the aligned row */
+				M->cpr = rowb / 16;
+				M->n_ks = (kh * M->cpr + 1) / 2;
+				M->n_rt = (rows + 31) / 32;
+				M->expand = 0;
+			}
+		}
 		M->in_img = (dense ? up16(L->in_n) : up16(M->in_hp * M->in_wp * in_c)) + 16; /* dense: the compact image, C_in = its whole length */
-		if (M->expand)
+		if (M->toep)
+		{
+			M->pitch_x = 0;                           /* one GEMM column per output ROW */
+			M->pitch_y = M->in_wp * in_c;
+			M->x_img = 0;
+		}
+		else if (M->expand)
 		{
 			M->pitch_x = 16 * M->cpr;
 			M->pitch_y = out_w * 16 * M->cpr;
@@ -74,7 +104,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		(void)sh;
 		/* the small-tile form of the same layer (chosen in pass 2, once the per-wave batch is known): room for either */
 		M->n_ks16 = (kh * M->cpr + 3) / 4;
-		M->n_rt16 = (L->out_c + 15) / 16;
+		M->n_rt16 = ((M->toep ? L->out_w * L->out_c : L->out_c) + 15) / 16;
 		M->frag_off = (int32_t)frag_bytes;
 		frag_bytes += (size_t)imax(M->n_rt * M->n_ks, M->n_rt16 * M->n_ks16) * 1024;
 		M->seed_off = n_seeds;
@@ -91,6 +121,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		if (!mm->L[i].mm || C->type != ED_NET_CONV || Q->type != ED_NET_POOL) continue;
 		if (Q->pad_h || Q->pad_w || Q->check_taps || Q->kh != Q->sh || Q->kw != Q->sw || (Q->kh * Q->kw != 2 && Q->kh * Q->kw != 4)) continue;
 		if (Q->out_h * Q->kh > C->out_h || Q->out_w * Q->kw > C->out_w) continue;
+		if (mm->L[i].toep && (Q->kw != 1 || Q->out_w != C->out_w)) continue; /* x lives in the GEMM's rows there: only windows along y fuse */
 		mm->L[i].pool_h = Q->kh; mm->L[i].pool_w = Q->kw;
 		mm->L[i + 1].skip = 1;
 		mm->L[i + 1].in_img = 0; /* the unpooled tensor never exists */
@@ -105,7 +136,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		M->col_off = -1;
 		if (!M->mm) continue;
 		const int dense = L->type == ED_NET_DENSE, fused = M->pool_h > 0, nx = fused ? i + 2 : i + 1;
-		const int st_h = dense ? 1 : (fused ? plan->L[i + 1].out_h : L->out_h), st_w = dense ? 1 : (fused ? plan->L[i + 1].out_w : L->out_w);
+		const int st_h = dense ? 1 : (fused ? plan->L[i + 1].out_h : L->out_h), st_w = dense || M->toep ? 1 : (fused ? plan->L[i + 1].out_w : L->out_w);
 		if (n_cols + st_h * st_w > ED_MM_MAX_COLS) continue;
 		const int ph = fused ? M->pool_h : 1, pw = fused ? M->pool_w : 1, sh = dense ? 1 : L->sh;
 		int owp, opy, opx; /* the consumer's layout (the last layer's output is compact) */
@@ -158,18 +189,20 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		mm->n_intab = plan->in_n;
 	}
 
-	/* LDS budget: two ping-pong buffers of batch x the largest image layout, the expansion buffer, the koff table */
-	int max_img = up16(plan->in_n) + 16, max_x = 0;
+	/* LDS budget: a wave's activation region for `batch` inputs -- a layer's input images at one end, its output images at
+	 * the other, the next layer the other way round: max(in + out) over the layers that run, not twice the largest image --
+	 * the expansion buffer, the koff table */
+	int max_pair = 0, max_x = 0;
 	for (int i = 0; i < n_layers; i++)
 	{
-		if (mm->L[i].in_img > max_img) max_img = mm->L[i].in_img;
 		if (mm->L[i].x_img > max_x) max_x = mm->L[i].x_img;
-		if (i == n_layers - 1)
-		{
-			const int out_img = up16(plan->L[i].out_n) + 16; /* the last layer's compact output */
-			if (out_img > max_img) max_img = out_img;
-		}
+		if (mm->L[i].skip) continue;
+		const int nx = mm->L[i].pool_h > 0 ? i + 2 : i + 1;
+		const int st_h = mm->L[i].pool_h > 0 ? plan->L[i + 1].out_h : plan->L[i].out_h, st_w = mm->L[i].pool_h > 0 ? plan->L[i + 1].out_w : plan->L[i].out_w;
+		const int out_img = nx < n_layers ? mm->L[nx].in_img : up16(st_h * st_w * plan->L[i].out_c) + 16; /* the last layer's output is compact */
+		if (mm->L[i].in_img + out_img > max_pair) max_pair = mm->L[i].in_img + out_img;
 	}
+	const int max_img = (max_pair / 2 + 15) & ~15; /* half of the region per input */
 	/* Where the weight fragments live: (2) ALL layers resident in LDS for the whole launch, shared by the waves of the
 	 * workgroup (one L2 read per workgroup), or (0) streamed from L2 per MFMA. Every wave gets its own activation slice
 	 * (two ping-pong buffers + the expansion buffer for `batch` inputs); as many waves as fit, at most 12, at least 4; the
@@ -220,7 +253,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 			ed_mm_layer_t *M = &mm->L[i];
 			if (!M->mm) continue;
 			const int dense = L->type == ED_NET_DENSE;
-			const int pix = dense ? 1 : L->out_h * L->out_w;
+			const int pix = dense ? 1 : L->out_h * (M->toep ? 1 : L->out_w);
 			M->small = !no_small && M->pool_h == 0 && batch * pix <= 16;
 		}
 		/* now that every layer's form is known: the exact fragment layout (pass 1 reserved room for either form), and
@@ -260,8 +293,25 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		memcpy(&r, p + 40 + (size_t)i * 48, sizeof(r));
 		const int dense = L->type == ED_NET_DENSE;
 		const int in_c = dense ? L->in_n : L->in_c, kh = dense ? 1 : L->kh, kw = dense ? 1 : L->kw;
-		const int seg = kw * in_c;
 		const int8_t *w = payload + r.v[9], *bias = payload + r.v[10]; /* OHWI / [out][in]: row o = kh segments of seg bytes */
+		int8_t *wt = NULL;
+		int seg = kw * in_c, n_rows = L->out_c;
+		if (M->toep)
+		{
+			/* the Toeplitz matrix, in the layout the packing below expects: [row = x * C_out + oc][ky][q < rowb] */
+			const int rowb = M->in_wp * in_c;
+			n_rows = L->out_w * L->out_c;
+			wt = (int8_t *)calloc((size_t)n_rows * kh * rowb, 1);
+			if (!wt) { free(fb); free(sb); return EDISON_E_NO_MEMORY; }
+			for (int x = 0; x < L->out_w; x++)
+				for (int o = 0; o < L->out_c; o++)
+					for (int ky = 0; ky < kh; ky++)
+						for (int t = 0; t < kw; t++)
+							for (int c = 0; c < in_c; c++)
+								wt[(((size_t)x * L->out_c + o) * kh + ky) * rowb + (x * L->sw + t) * in_c + c] = w[((size_t)o * kh + ky) * seg + t * in_c + c];
+			w = wt;
+			seg = rowb;
+		}
 		if (M->small)
 		{
 			/* lane l of k-step s of row tile rt: row 16 rt + (l & 15), chunk 4 s + (l >> 4) */
@@ -276,7 +326,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 						for (int j = 0; j < 16; j++)
 						{
 							const int q = 16 * jc + j;
-							f[l * 16 + j] = (row < L->out_c && ky < kh && q < seg) ? w[((size_t)row * kh + ky) * seg + q] : 0;
+							f[l * 16 + j] = (row < n_rows && ky < kh && q < seg) ? w[((size_t)row * kh + ky) * seg + q] : 0;
 						}
 					}
 				}
@@ -293,12 +343,13 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 					for (int j = 0; j < 16; j++)
 					{
 						const int q = 16 * jc + j;
-						f[l * 16 + j] = (row < L->out_c && ky < kh && q < seg) ? w[((size_t)row * kh + ky) * seg + q] : 0;
+						f[l * 16 + j] = (row < n_rows && ky < kh && q < seg) ? w[((size_t)row * kh + ky) * seg + q] : 0;
 					}
 				}
 			}
-		for (int o = 0; o < L->out_c; o++)
-			sb[M->seed_off + o] = (int32_t)((uint32_t)(int32_t)bias[o] << r.v[6]) + (int32_t)((1u << r.v[7]) >> 1);
+		free(wt);
+		for (int o = 0; o < n_rows; o++)
+			sb[M->seed_off + o] = (int32_t)((uint32_t)(int32_t)bias[o % L->out_c] << r.v[6]) + (int32_t)((1u << r.v[7]) >> 1);
 		for (int c = 0; c < (M->small ? 4 * M->n_ks16 : 2 * M->n_ks); c++)
 		{
 			const int ky = c / M->cpr, jc = c - ky * M->cpr;
@@ -307,6 +358,8 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 	}
 	/* bounds of everything the kernel will address in LDS, checked here on the host (a plan that fails stays off the
 	 * matrix-core path instead of reaching the device): B fragment reads and epilogue stores of every layer */
+	int in_off = 0; /* the first layer's input sits at the low end of the region */
+	const int region = 2 * mm->buf_bytes;
 	for (int i = 0; i < n_layers; i++)
 	{
 		const ed_net_layer_t *L = &plan->L[i];
@@ -318,11 +371,14 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		if (nx < n_layers) { ohp = mm->L[nx].in_hp; owp = mm->L[nx].in_wp; opy = mm->L[nx].in_py; opx = mm->L[nx].in_px; oimg = mm->L[nx].in_img; }
 		else { ohp = st_h; owp = st_w; opy = 0; opx = 0; oimg = up16(st_h * st_w * L->out_c) + 16; }
 		const int64_t last_store = ((int64_t)(st_h - 1 + opy) * owp + (st_w - 1 + opx)) * L->out_c + L->out_c;
-		int bad = last_store > oimg || ohp < st_h + opy || owp < st_w + opx || oimg > mm->buf_bytes / batch;
+		/* input at one end of the region, output at the other */
+		const int o_off = in_off == 0 ? region - batch * oimg : 0;
+		int bad = last_store > oimg || ohp < st_h + opy || owp < st_w + opx || batch * (M->in_img + oimg) > region || o_off < 0 || (o_off & 15) || (in_off & 15);
+		bad |= in_off + batch * M->in_img > region || (in_off == 0 ? batch * M->in_img > o_off : batch * oimg > in_off);
 		if (M->mm)
 		{
 			const int dense = L->type == ED_NET_DENSE;
-			const int out_h = dense ? 1 : L->out_h, out_w = dense ? 1 : L->out_w, sh = dense ? 1 : L->sh;
+			const int out_h = dense ? 1 : L->out_h, out_w = dense || M->toep ? 1 : L->out_w, sh = dense ? 1 : L->sh;
 			const int img = M->expand ? M->x_img : M->in_img;
 			int max_koff = 0;
 			for (int c = 0; c < (M->small ? 4 * M->n_ks16 : 2 * M->n_ks); c++) if (mm->koff[M->koff_off + c] > max_koff) max_koff = mm->koff[M->koff_off + c];
@@ -332,11 +388,11 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 			/* the tables the kernel follows blindly: every entry re-checked against the buffers it indexes */
 			if (M->col_off >= 0)
 			{
-				const int pix = dense ? 1 : st_h * st_w, wmax = fused ? ((M->pool_h - 1) * sh) * M->pitch_y + (M->pool_w - 1) * M->pitch_x : 0;
+				const int pix = dense ? 1 : st_h * (M->toep ? 1 : st_w), wmax = fused ? ((M->pool_h - 1) * sh) * M->pitch_y + (M->pool_w - 1) * M->pitch_x : 0;
 				for (int q = 0; q < pix; q++)
 				{
 					const int boff = mm->coltab[2 * (M->col_off + q)], ooff = mm->coltab[2 * (M->col_off + q) + 1];
-					bad |= boff < 0 || (boff & 15) || (int64_t)boff + wmax + max_koff + 16 > img || ooff < 0 || ooff + L->out_c > oimg;
+					bad |= boff < 0 || (boff & 15) || (int64_t)boff + wmax + max_koff + 16 > img || ooff < 0 || ooff + (M->toep ? L->out_w : 1) * L->out_c > oimg;
 				}
 			}
 			if (M->xtab_off >= 0)
@@ -368,9 +424,12 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		R->ph = fused ? M->pool_h : 1; R->pw = fused ? M->pool_w : 1;
 		R->small = M->small;
 		R->n_ks = M->small ? M->n_ks16 : M->n_ks; R->n_rt = M->small ? M->n_rt16 : M->n_rt; R->frag_off = M->frag_off; R->seed_off = M->seed_off; R->koff_off = M->koff_off; R->col_off = M->col_off;
-		R->pix_per_img = dense ? 1 : st_h * st_w; R->col_w = dense ? 1 : st_w;
-		R->out_c = L->out_c; R->rs = L->rs; R->lo_clamp = L->relu ? 0 : -128;
+		R->pix_per_img = dense ? 1 : st_h * (M->toep ? 1 : st_w); R->col_w = dense || M->toep ? 1 : st_w;
+		R->out_c = M->toep ? L->out_w * L->out_c : L->out_c; /* rows of the GEMM */
+		R->rs = L->rs; R->lo_clamp = L->relu ? 0 : -128;
 		R->in_n = L->in_n;
+		R->in_off = in_off; R->o_off = o_off;
+		in_off = o_off; /* the consumer reads where this layer stored */
 	}
 	*frag = fb;
 	*seeds = sb;
