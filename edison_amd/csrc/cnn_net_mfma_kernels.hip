@@ -20,7 +20,7 @@
  * counts): the planner ships one run record per layer (ed_mm_run_t, two scalar loads), the place of every input byte in
  * layer 0's layout, source / destination / valid bytes of every expansion record and the operand / output offsets of
  * every stored pixel; they are copied into LDS once per workgroup. Tiles: 32 x 32 x 32 with up to four MFMA chains at
- * once (the positions of a fused pooling window share an A fragment; two output tiles side by side), or 16 x 16 x 64
+ * once (groups of row tiles x column tiles x the positions of a fused pooling window, sharing A and B fragments), or 16 x 16 x 64
  * for layers with at most 16 columns per wave, where a 32-column tile would be mostly padding.
  */
 /* -DEMM_JIT=1: this text is being compiled by hipRTC at run time (edison_net_specialize, edison_net_jit.hip) for one graph:
@@ -153,6 +153,7 @@ __device__ __forceinline__ v4i emm_gather16(const lds8 *a, int soff, int keep)
  * down; lanes past the image fetch that same dword and drop it. (With byte loads under divergent branches for the tail
  * the compiler put a full vmcnt(0) behind every one of them -- inside the code that was meant to PREFETCH.) */
 #define EMM_PRE 2
+#define EMM_PB 4 /* images per wave the prefetch covers */
 __device__ __forceinline__ void emm_load_image(const int8_t *src, int in_n, int lane, uint32_t (&x)[EMM_PRE])
 {
 #pragma unroll
@@ -189,10 +190,12 @@ __device__ __forceinline__ v4i emm_load_a(const lds8 *fl, const int8_t *fg, int 
 }
 
 /*
- * The k-loop of U output tiles ("units": a row tile x a column tile each) with NW accumulator tiles per unit (the
- * positions of a fused pooling window; 1 when nothing is fused) -- NW * U <= 4 independent MFMA chains at once. The A
- * fragment of a k-step serves the NW windows of its unit. Software pipeline in program order, so that every wait covers
- * loads issued a whole step earlier (LDS returns in order):
+ * The k-loop of a GROUP of R row tiles x C column tiles with NW accumulator tiles each (the positions of a fused pooling
+ * window; 1 when nothing is fused) -- R * C * NW <= 4 independent MFMA chains at once. A k-step fetches R A fragments (one
+ * per row tile, shared by its C * NW chains) and C * NW B fragments (one per column tile and window, shared by the R row
+ * tiles): the kernel moves 1 KB of LDS per fragment and the LDS pipe is two thirds busy, so a 2 x 2 group (4 KB for four
+ * MFMAs) is worth twice a pair of independent tiles (4 KB for two). Software pipeline in program order, so that every wait
+ * covers loads issued a whole step earlier (LDS returns in order):
  *   step s:  chunk offset of step s+2  |  A_u(s+1), B_c(s+1) at the offset read one step ago  |  MFMAs of step s
  * The accumulators start as the seeds (read straight into them). acc[u] returns the element-wise maximum over the
  * unit's windows (max before the one requantisation is exact: the requantisation is monotone).
@@ -207,49 +210,56 @@ __device__ __forceinline__ void emm_keep(v4i (&x)[N])
 	for (int i = 0; i < N; i++) asm volatile("" : "+v"(x[i]));
 }
 
-template <int NW, int U, bool FRAG_LDS>
-__device__ __forceinline__ void emm_chain(const lds8 *(&fl)[U], const int8_t *(&fg)[U], const lds8 *kp /* &koff[h] */, const lds8 *(&bw)[NW * U],
-                                          int n_ks, const lds8 *(&sp)[U], v16i (&acc)[U])
+template <int NW, int R, int C, bool FRAG_LDS>
+__device__ __forceinline__ void emm_chain(const lds8 *(&fl)[R], const int8_t *(&fg)[R], const lds8 *kp /* &koff[h] */, const lds8 *(&bw)[NW * C],
+                                          int n_ks, const lds8 *(&sp)[R], v16i (&acc)[R * C])
 {
-	constexpr int NC = NW * U;
-	v16i aw[NC];
+	constexpr int NT = R * C * NW, NB = C * NW; /* accumulator tile (r, c, w) is aw[(r * C + c) * NW + w] */
+	v16i aw[NT];
 #pragma unroll
-	for (int c = 0; c < NC; c++)
+	for (int t = 0; t < NT; t++)
 #pragma unroll
 		for (int g = 0; g < 4; g++)
 		{
-			const v4i s4 = EMM_LD128(sp[c / NW] + 32 * g);
-			aw[c][4 * g] = s4.x; aw[c][4 * g + 1] = s4.y; aw[c][4 * g + 2] = s4.z; aw[c][4 * g + 3] = s4.w;
+			const v4i s4 = EMM_LD128(sp[t / (C * NW)] + 32 * g);
+			aw[t][4 * g] = s4.x; aw[t][4 * g + 1] = s4.y; aw[t][4 * g + 2] = s4.z; aw[t][4 * g + 3] = s4.w;
 		}
 	const int last = n_ks - 1;
 	int k_cur = EMM_LD32(kp), k_nxt = EMM_LD32(kp + 8 * (last < 1 ? last : 1));
-	v4i a[U], b[NC];
+	v4i a[R], b[NB];
 #pragma unroll
-	for (int u = 0; u < U; u++) a[u] = emm_load_a<FRAG_LDS>(fl[u], fg[u], 0);
+	for (int r = 0; r < R; r++) a[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], 0);
 #pragma unroll
-	for (int c = 0; c < NC; c++) b[c] = EMM_LD128(bw[c] + k_cur);
+	for (int c = 0; c < NB; c++) b[c] = EMM_LD128(bw[c] + k_cur);
 	for (int s = 0; s < ((EMM_SKIP & 2) ? 0 : n_ks); s++)
 	{
-		const int s1 = s + 1 < n_ks ? s + 1 : last, s2 = s + 2 < n_ks ? s + 2 : last;
+		const int s2 = s + 2 < n_ks ? s + 2 : last;
 		const int k3 = EMM_LD32(kp + 8 * s2);
-		v4i an[U], bn[NC];
+		v4i an[R], bn[NB];
 #pragma unroll
-		for (int u = 0; u < U; u++) an[u] = emm_load_a<FRAG_LDS>(fl[u], fg[u], s1);
+		for (int r = 0; r < R; r++) an[r] = a[r];
 #pragma unroll
-		for (int c = 0; c < NC; c++) bn[c] = EMM_LD128(bw[c] + k_nxt);
+		for (int c = 0; c < NB; c++) bn[c] = b[c];
+		if (s + 1 < n_ks) /* uniform: the last step has nothing to fetch (a k-step's operands are R + C * NW KB of LDS traffic) */
+		{
 #pragma unroll
-		for (int c = 0; c < NC; c++) aw[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[c / NW], b[c], aw[c], 0, 0, 0);
+			for (int r = 0; r < R; r++) an[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], s + 1);
+#pragma unroll
+			for (int c = 0; c < NB; c++) bn[c] = EMM_LD128(bw[c] + k_nxt);
+		}
+#pragma unroll
+		for (int t = 0; t < NT; t++) aw[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t / (C * NW)], b[t % (C * NW)], aw[t], 0, 0, 0);
 		k_nxt = k3;
 #pragma unroll
-		for (int u = 0; u < U; u++) a[u] = an[u];
+		for (int r = 0; r < R; r++) a[r] = an[r];
 #pragma unroll
-		for (int c = 0; c < NC; c++) b[c] = bn[c];
+		for (int c = 0; c < NB; c++) b[c] = bn[c];
 		asm volatile("" : "+v"(k_nxt));
 		emm_keep(a);
 		emm_keep(b);
 	}
 #pragma unroll
-	for (int u = 0; u < U; u++)
+	for (int u = 0; u < R * C; u++)
 	{
 		acc[u] = aw[u * NW];
 #pragma unroll
@@ -283,11 +293,11 @@ struct emm_mm_args
 #define EMM_ST_T(i)
 #endif
 
-template <int NW, int U, bool FRAG_LDS>
+template <int NW, int R, int C, bool FRAG_LDS>
 __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 {
 	const int col = lane & 31, h = lane >> 5;
-	const int n_ct = (A.n_cols + 31) >> 5, n_units = A.n_rt * n_ct;
+	const int n_ct = (A.n_cols + 31) >> 5;
 	const float inv_ppi = __builtin_amdgcn_rcpf((float)A.pix_per_img), inv_ow = __builtin_amdgcn_rcpf((float)A.col_w);
 	/* the windows of a column start (wy * sh) input rows / wx output columns after its first one; the fused windows are
 	 * 2x1, 1x2 or 2x2 */
@@ -298,22 +308,20 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 		const int wy = A.pw == 2 ? w >> 1 : w, wx = A.pw == 2 ? w & 1 : 0;
 		wdelta[w] = (wy * A.sh) * A.pitch_y + wx * A.pitch_x;
 	}
-	/* units in (row tile, column tile) order, U at a time; a group's spare slots repeat the last unit and store nothing */
-	int rt = 0, ct = 0;
-	for (int u0 = 0; u0 < n_units; u0 += U)
+	/* groups of R row tiles x C column tiles; a group's spare slots (past the last row / column tile) repeat the last tile
+	 * and store nothing */
+	for (int ct0 = 0; ct0 < n_ct; ct0 += C)
 	{
-		EMM_ST_T(43)
-		const lds8 *fl[U], *sp[U], *bw[NW * U];
-		const int8_t *fg[U];
-		lds8 *op[U];
-		bool live[U];
-		int rts[U];
+		/* this lane's column in each of the C column tiles: its B source and where its outputs go */
+		const lds8 *bw[NW * C];
+		lds8 *op[C];
+		bool live[C];
 #pragma unroll
-		for (int k = 0; k < U; k++)
+		for (int c = 0; c < C; c++)
 		{
-			const bool valid = u0 + k < n_units;
+			const int ct = ct0 + c < n_ct ? ct0 + c : n_ct - 1;
 			const int q = ct * 32 + col;
-			live[k] = valid && q < A.n_cols;
+			live[c] = ct0 + c < n_ct && q < A.n_cols;
 			const int qq = q < A.n_cols ? q : A.n_cols - 1;
 			int b = 0, pp = qq;
 			if (A.n_cols > A.pix_per_img) emm_divmod(qq, A.pix_per_img, inv_ppi, b, pp); /* uniform: more than one image per wave */
@@ -330,48 +338,57 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 				ooff = A.o_origin + y * A.o_row + x * A.oc_pitch;
 			}
 #pragma unroll
-			for (int w = 0; w < NW; w++) bw[k * NW + w] = A.bsrc + b * A.img + boff + wdelta[w];
-			fl[k] = A.fragl + rt * A.n_ks * 1024 + lane * 16;
-			fg[k] = A.fragg + (size_t)rt * A.n_ks * 1024 + lane * 16;
-			sp[k] = A.seeds + 4 * (32 * rt + 4 * h);
-			op[k] = A.o + b * A.o_img + ooff;
-			rts[k] = rt;
-			if (u0 + k + 1 < n_units) /* uniform */
-			{
-				ct++;
-				if (ct == n_ct) { ct = 0; rt++; }
-			}
+			for (int w = 0; w < NW; w++) bw[c * NW + w] = A.bsrc + b * A.img + boff + wdelta[w];
+			op[c] = A.o + b * A.o_img + ooff;
 		}
-		v16i acc[U];
-		EMM_ST_T(40)
-		emm_chain<NW, U, FRAG_LDS>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc);
-		EMM_ST_T(41)
-		/* lane (column, h) holds rows 32 rt + 8 g + 4 h .. +3 in registers 4g..4g+3. Requantise, clamp, pack four rows
-		 * into a dword with three v_perm_b32; whole groups of 8 rows past C_out are skipped under a uniform branch, the
-		 * store alone is predicated. */
+		for (int rt0 = 0; rt0 < A.n_rt; rt0 += R)
+		{
+			EMM_ST_T(43)
+			const lds8 *fl[R], *sp[R];
+			const int8_t *fg[R];
+			int rts[R];
 #pragma unroll
-		for (int k = 0; k < U; k++)
-#pragma unroll
-			for (int g = 0; g < 4; g++)
+			for (int r = 0; r < R; r++)
 			{
-				if ((EMM_SKIP & 1) || 32 * rts[k] + 8 * g >= A.out_c) continue; /* uniform */
-				const int r0 = 32 * rts[k] + 8 * g + 4 * h;
-				const int v0 = emm_med3(acc[k][4 * g] >> A.rs, A.lo_clamp, 127), v1 = emm_med3(acc[k][4 * g + 1] >> A.rs, A.lo_clamp, 127);
-				const int v2 = emm_med3(acc[k][4 * g + 2] >> A.rs, A.lo_clamp, 127), v3 = emm_med3(acc[k][4 * g + 3] >> A.rs, A.lo_clamp, 127);
-				if ((A.out_c & 3) == 0)
-				{
-					const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x0c0c0400u), p23 = __builtin_amdgcn_perm((uint32_t)v3, (uint32_t)v2, 0x0c0c0400u);
-					if (live[k] && r0 < A.out_c) EMM_ST32(op[k] + r0, __builtin_amdgcn_perm(p23, p01, 0x05040100u));
-				}
-				else if (live[k])
-				{
-					if (r0 < A.out_c) op[k][r0] = (int8_t)v0;
-					if (r0 + 1 < A.out_c) op[k][r0 + 1] = (int8_t)v1;
-					if (r0 + 2 < A.out_c) op[k][r0 + 2] = (int8_t)v2;
-					if (r0 + 3 < A.out_c) op[k][r0 + 3] = (int8_t)v3;
-				}
+				rts[r] = rt0 + r < A.n_rt ? rt0 + r : A.n_rt - 1;
+				fl[r] = A.fragl + rts[r] * A.n_ks * 1024 + lane * 16;
+				fg[r] = A.fragg + (size_t)rts[r] * A.n_ks * 1024 + lane * 16;
+				sp[r] = A.seeds + 4 * (32 * rts[r] + 4 * h);
 			}
-		EMM_ST_T(42)
+			v16i acc[R * C];
+			EMM_ST_T(40)
+			emm_chain<NW, R, C, FRAG_LDS>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc);
+			EMM_ST_T(41)
+			/* lane (column, h) holds rows 32 rt + 8 g + 4 h .. +3 in registers 4g..4g+3. Requantise, clamp, pack four rows
+			 * into a dword with three v_perm_b32; whole groups of 8 rows past C_out are skipped under a uniform branch, the
+			 * store alone is predicated. */
+#pragma unroll
+			for (int r = 0; r < R; r++)
+#pragma unroll
+				for (int c = 0; c < C; c++)
+#pragma unroll
+					for (int g = 0; g < 4; g++)
+					{
+						if ((EMM_SKIP & 1) || rt0 + r >= A.n_rt || 32 * rts[r] + 8 * g >= A.out_c) continue; /* uniform */
+						const v16i &t = acc[r * C + c];
+						const int r0 = 32 * rts[r] + 8 * g + 4 * h;
+						const int v0 = emm_med3(t[4 * g] >> A.rs, A.lo_clamp, 127), v1 = emm_med3(t[4 * g + 1] >> A.rs, A.lo_clamp, 127);
+						const int v2 = emm_med3(t[4 * g + 2] >> A.rs, A.lo_clamp, 127), v3 = emm_med3(t[4 * g + 3] >> A.rs, A.lo_clamp, 127);
+						if ((A.out_c & 3) == 0)
+						{
+							const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x0c0c0400u), p23 = __builtin_amdgcn_perm((uint32_t)v3, (uint32_t)v2, 0x0c0c0400u);
+							if (live[c] && r0 < A.out_c) EMM_ST32(op[c] + r0, __builtin_amdgcn_perm(p23, p01, 0x05040100u));
+						}
+						else if (live[c])
+						{
+							if (r0 < A.out_c) op[c][r0] = (int8_t)v0;
+							if (r0 + 1 < A.out_c) op[c][r0 + 1] = (int8_t)v1;
+							if (r0 + 2 < A.out_c) op[c][r0 + 2] = (int8_t)v2;
+							if (r0 + 3 < A.out_c) op[c][r0 + 3] = (int8_t)v3;
+						}
+					}
+			EMM_ST_T(42)
+		}
 	}
 }
 
@@ -382,10 +399,9 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
  * dense layer: 1); here a tile is 4 accumulator registers instead of 16 and the k-loop half as long. Up to four row
  * tiles run at once and share the B fragment of a k-step; same one-deep pipeline as emm_chain.
  */
-template <bool FRAG_LDS>
+template <int U, bool FRAG_LDS>
 __device__ __forceinline__ void emm_layer_small(const emm_mm_args &A, int lane)
 {
-	constexpr int U = 4;
 	const int col = lane & 15, kq = lane >> 4;
 	const bool live = col < A.n_cols;
 	const int qq = live ? col : A.n_cols - 1;
@@ -426,12 +442,17 @@ __device__ __forceinline__ void emm_layer_small(const emm_mm_args &A, int lane)
 		v4i bq = EMM_LD128(bp + k_cur);
 		for (int s = 0; s < ((EMM_SKIP & 2) ? 0 : n_ks); s++)
 		{
-			const int s1 = s + 1 < n_ks ? s + 1 : last, s2 = s + 2 < n_ks ? s + 2 : last;
+			const int s2 = s + 2 < n_ks ? s + 2 : last;
 			const int k3 = EMM_LD32(kp + 16 * s2);
-			v4i an[U];
+			v4i an[U], bn = bq;
 #pragma unroll
-			for (int u = 0; u < U; u++) an[u] = emm_load_a<FRAG_LDS>(fl[u], fg[u], s1);
-			const v4i bn = EMM_LD128(bp + k_nxt);
+			for (int u = 0; u < U; u++) an[u] = a[u];
+			if (s + 1 < n_ks) /* uniform: the last step has nothing to fetch */
+			{
+#pragma unroll
+				for (int u = 0; u < U; u++) an[u] = emm_load_a<FRAG_LDS>(fl[u], fg[u], s + 1);
+				bn = EMM_LD128(bp + k_nxt);
+			}
 #pragma unroll
 			for (int u = 0; u < U; u++) aw[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[u], bq, aw[u], 0, 0, 0);
 			k_nxt = k3; bq = bn;
@@ -464,24 +485,34 @@ __device__ __forceinline__ void emm_layer_small(const emm_mm_args &A, int lane)
 	}
 }
 
-/* NW windows per unit (1, 2 or 4); two units at once when the layer has them and four accumulator tiles hold them */
+/* NW windows per tile (1, 2 or 4) and the group shape: R row tiles x C column tiles, R * C * NW <= 4 accumulator tiles, rows
+ * first (a row tile more costs one A fragment per k-step, a column tile more costs NW B fragments) */
 template <bool FRAG_LDS>
 __device__ __forceinline__ void emm_layer_dispatch(const emm_mm_args &A, int lane)
 {
-	if (A.small) { emm_layer_small<FRAG_LDS>(A, lane); return; }
-	const int nwin = A.ph * A.pw, n_units = A.n_rt * ((A.n_cols + 31) >> 5);
+	if (A.small)
+	{
+		/* row tiles at a time: as many as the layer has, up to four (a spare slot would fetch its A fragments all the same) */
+		if (A.n_rt >= 3) emm_layer_small<4, FRAG_LDS>(A, lane);
+		else if (A.n_rt == 2) emm_layer_small<2, FRAG_LDS>(A, lane);
+		else emm_layer_small<1, FRAG_LDS>(A, lane);
+		return;
+	}
+	const int nwin = A.ph * A.pw, n_ct = (A.n_cols + 31) >> 5;
 	if (nwin == 1)
 	{
-		/* (four units of one window each would hold 8 A fragments beside 8 B fragments and 4 accumulators: it spills) */
-		if (n_units >= 2) emm_layer_tiles<1, 2, FRAG_LDS>(A, lane);
-		else emm_layer_tiles<1, 1, FRAG_LDS>(A, lane);
+		if (A.n_rt >= 2 && n_ct >= 2) emm_layer_tiles<1, 2, 2, FRAG_LDS>(A, lane);
+		else if (A.n_rt >= 2) emm_layer_tiles<1, 2, 1, FRAG_LDS>(A, lane);
+		else if (n_ct >= 2) emm_layer_tiles<1, 1, 2, FRAG_LDS>(A, lane);
+		else emm_layer_tiles<1, 1, 1, FRAG_LDS>(A, lane);
 	}
 	else if (nwin == 2)
 	{
-		if (n_units >= 2) emm_layer_tiles<2, 2, FRAG_LDS>(A, lane);
-		else emm_layer_tiles<2, 1, FRAG_LDS>(A, lane);
+		if (A.n_rt >= 2) emm_layer_tiles<2, 2, 1, FRAG_LDS>(A, lane);
+		else if (n_ct >= 2) emm_layer_tiles<2, 1, 2, FRAG_LDS>(A, lane);
+		else emm_layer_tiles<2, 1, 1, FRAG_LDS>(A, lane);
 	}
-	else emm_layer_tiles<4, 1, FRAG_LDS>(A, lane);
+	else emm_layer_tiles<4, 1, 1, FRAG_LDS>(A, lane);
 }
 
 template <bool FRAG_LDS>
@@ -531,12 +562,17 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 	for (int i = 0; i < 48; i++) stamp_[i] = 0;
 	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_) :: "memory");
 #endif
-	/* One image per wave and at most 512 bytes of it: the next image's dwords are requested from HBM before this one's layers
-	 * run (two registers; more would spill), so that the wave never waits a memory latency per input. */
+	/* Images of at most 512 bytes, up to EMM_PB per wave: the next batch's dwords are requested from HBM before this one's
+	 * layers run (two registers per image), so that the wave never waits a memory latency per batch. */
 	const int64_t u_first = ((int64_t)blockIdx.x * n_waves + wave) * batch, u_step = (int64_t)gridDim.x * n_waves * batch;
-	EMM_CONST bool prefetch = n_intab && batch == 1 && EMM_PF(in_n) <= EMM_PRE * 256 && EMM_PF(in_n) >= 4;
-	uint32_t pre[EMM_PRE];
-	if (prefetch && u_first < n) emm_load_image(in + u_first * in_stride, EMM_PF(in_n), lane, pre);
+	EMM_CONST bool prefetch = n_intab && batch <= EMM_PB && EMM_PF(in_n) <= EMM_PRE * 256 && EMM_PF(in_n) >= 4;
+	uint32_t pre[EMM_PB][EMM_PRE];
+	if (prefetch && u_first < n)
+	{
+#pragma unroll
+		for (int b = 0; b < EMM_PB; b++) /* a slot past the end of the input fetches the last image again: it is never written out */
+			if (b < batch) emm_load_image(in + (u_first + b < n ? u_first + b : n - 1) * in_stride, EMM_PF(in_n), lane, pre[b]);
+	}
 	for (int64_t u0 = u_first; u0 < n; u0 += u_step)
 	{
 		const int nb = batch == 1 ? 1 : (int)((n - u0) < batch ? (n - u0) : batch);
@@ -554,18 +590,29 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 			if (EMM_SKIP & 8) {}
 			else if (prefetch)
 			{
-				uint32_t v[EMM_PRE];
+				uint32_t v[EMM_PB][EMM_PRE];
 #pragma unroll
-				for (int k = 0; k < EMM_PRE; k++) v[k] = emm_image_dword(pre[k], in_n, lane, k);
-				/* unconditional, like the MFCC kernels' prefetch: a wave's last pass re-reads its own image (an L2 hit) */
-				emm_load_image(in + (u0 + u_step < n ? u0 + u_step : u0) * in_stride, in_n, lane, pre);
+				for (int b = 0; b < EMM_PB; b++)
+#pragma unroll
+					for (int k = 0; k < EMM_PRE; k++) v[b][k] = b < batch ? emm_image_dword(pre[b][k], in_n, lane, k) : 0u;
+				/* unconditional, like the MFCC kernels' prefetch: a wave's last pass re-reads its own images (an L2 hit) */
+				const int64_t u_nxt = u0 + u_step < n ? u0 + u_step : u0;
+#pragma unroll
+				for (int b = 0; b < EMM_PB; b++)
+					if (b < batch) emm_load_image(in + (u_nxt + b < n ? u_nxt + b : n - 1) * in_stride, in_n, lane, pre[b]);
 #pragma unroll
 				for (int k = 0; k < EMM_PRE; k++)
 				{
 					const int e = 4 * lane + 256 * k;
 #pragma unroll
 					for (int t = 0; t < 4; t++)
-						if (e + t < in_n) in0[intab_l[e + t]] = (int8_t)(v[k] >> (8 * t));
+						if (e + t < in_n)
+						{
+							const int at = intab_l[e + t]; /* the same place in every image of the batch */
+#pragma unroll
+							for (int b = 0; b < EMM_PB; b++)
+								if (b < batch) in0[b * l0.img + at] = (int8_t)(v[b][k] >> (8 * t));
+						}
 				}
 			}
 			else if (n_intab)
@@ -683,7 +730,8 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 				A.n_ks = R.n_ks; A.n_rt = R.n_rt;
 				A.col_w = R.col_w;
 				A.pix_per_img = R.pix_per_img;
-				A.n_cols = nb * R.pix_per_img;
+				A.n_cols = (EMM_SPEC ? batch : nb) * R.pix_per_img; /* the graph's own kernel keeps its tile counts constant: the slots past
+				                                                      * a ragged last batch compute on stale LDS and are never written out */
 				A.pitch_x = R.pitch_x; A.pitch_y = R.pitch_y; A.sh = R.sh;
 				A.ph = R.ph; A.pw = R.pw;
 				A.small = R.small;
