@@ -100,6 +100,18 @@ typedef EMM_LDS int lds32;
 /* lo <= hi: v_min_i32 + v_max_i32 (the nested-ternary form compiles to a compare and a v_cndmask on top of the v_min) */
 __device__ __forceinline__ int emm_med3(int v, int lo, int hi) { const int t = v > hi ? hi : v; return t < lo ? lo : t; }
 
+/* Four accumulators -> four requantised bytes in a dword: sat8(v >> rs) with the ReLU folded in as the lower clamp, packed
+ * with three v_perm_b32. (The v_cvt_pk_i16_i32 + v_sat_pk_u8_i16 sequence of cnn_mfma_kernels.hip measured 8.5 % SLOWER in
+ * the graph's own kernel and 0.5 % slower here: with constant bounds the clamp is one v_med3_i32 and the asm statements of
+ * the other form pin the schedule.) */
+__device__ __forceinline__ uint32_t emm_pack4(int a0, int a1, int a2, int a3, int rs, int lo_clamp)
+{
+	const int v0 = emm_med3(a0 >> rs, lo_clamp, 127), v1 = emm_med3(a1 >> rs, lo_clamp, 127);
+	const int v2 = emm_med3(a2 >> rs, lo_clamp, 127), v3 = emm_med3(a3 >> rs, lo_clamp, 127);
+	const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x0c0c0400u), p23 = __builtin_amdgcn_perm((uint32_t)v3, (uint32_t)v2, 0x0c0c0400u);
+	return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+}
+
 /* i / d and i % d for 0 <= i < 2^21, 0 < d: one float multiply and a one-step correction instead of the ~20-instruction
  * integer division sequence (gfx950 has no integer divide); inv ~ 1 / d (v_rcp_f32, 1 ulp) is computed once per loop. Every
  * index here counts bytes or records of one wave's LDS slice, < 2^18. */
@@ -372,19 +384,17 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 						if ((EMM_SKIP & 1) || rt0 + r >= A.n_rt || 32 * rts[r] + 8 * g >= A.out_c) continue; /* uniform */
 						const v16i &t = acc[r * C + c];
 						const int r0 = 32 * rts[r] + 8 * g + 4 * h;
-						const int v0 = emm_med3(t[4 * g] >> A.rs, A.lo_clamp, 127), v1 = emm_med3(t[4 * g + 1] >> A.rs, A.lo_clamp, 127);
-						const int v2 = emm_med3(t[4 * g + 2] >> A.rs, A.lo_clamp, 127), v3 = emm_med3(t[4 * g + 3] >> A.rs, A.lo_clamp, 127);
+						const uint32_t d = emm_pack4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3], A.rs, A.lo_clamp);
 						if ((A.out_c & 3) == 0)
 						{
-							const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x0c0c0400u), p23 = __builtin_amdgcn_perm((uint32_t)v3, (uint32_t)v2, 0x0c0c0400u);
-							if (live[c] && r0 < A.out_c) EMM_ST32(op[c] + r0, __builtin_amdgcn_perm(p23, p01, 0x05040100u));
+							if (live[c] && r0 < A.out_c) EMM_ST32(op[c] + r0, d);
 						}
 						else if (live[c])
 						{
-							if (r0 < A.out_c) op[c][r0] = (int8_t)v0;
-							if (r0 + 1 < A.out_c) op[c][r0 + 1] = (int8_t)v1;
-							if (r0 + 2 < A.out_c) op[c][r0 + 2] = (int8_t)v2;
-							if (r0 + 3 < A.out_c) op[c][r0 + 3] = (int8_t)v3;
+							if (r0 < A.out_c) op[c][r0] = (int8_t)d;
+							if (r0 + 1 < A.out_c) op[c][r0 + 1] = (int8_t)(d >> 8);
+							if (r0 + 2 < A.out_c) op[c][r0 + 2] = (int8_t)(d >> 16);
+							if (r0 + 3 < A.out_c) op[c][r0 + 3] = (int8_t)(d >> 24);
 						}
 					}
 			EMM_ST_T(42)
@@ -467,19 +477,17 @@ __device__ __forceinline__ void emm_layer_small(const emm_mm_args &A, int lane)
 		{
 			const int r0 = 16 * rts[u] + 4 * kq;
 			if ((EMM_SKIP & 1) || rt0 + u >= A.n_rt) continue; /* uniform */
-			const int v0 = emm_med3(aw[u].x >> A.rs, A.lo_clamp, 127), v1 = emm_med3(aw[u].y >> A.rs, A.lo_clamp, 127);
-			const int v2 = emm_med3(aw[u].z >> A.rs, A.lo_clamp, 127), v3 = emm_med3(aw[u].w >> A.rs, A.lo_clamp, 127);
+			const uint32_t d = emm_pack4(aw[u].x, aw[u].y, aw[u].z, aw[u].w, A.rs, A.lo_clamp);
 			if ((A.out_c & 3) == 0)
 			{
-				const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x0c0c0400u), p23 = __builtin_amdgcn_perm((uint32_t)v3, (uint32_t)v2, 0x0c0c0400u);
-				if (live && r0 < A.out_c) EMM_ST32(op + r0, __builtin_amdgcn_perm(p23, p01, 0x05040100u));
+				if (live && r0 < A.out_c) EMM_ST32(op + r0, d);
 			}
 			else if (live)
 			{
-				if (r0 < A.out_c) op[r0] = (int8_t)v0;
-				if (r0 + 1 < A.out_c) op[r0 + 1] = (int8_t)v1;
-				if (r0 + 2 < A.out_c) op[r0 + 2] = (int8_t)v2;
-				if (r0 + 3 < A.out_c) op[r0 + 3] = (int8_t)v3;
+				if (r0 < A.out_c) op[r0] = (int8_t)d;
+				if (r0 + 1 < A.out_c) op[r0 + 1] = (int8_t)(d >> 8);
+				if (r0 + 2 < A.out_c) op[r0 + 2] = (int8_t)(d >> 16);
+				if (r0 + 3 < A.out_c) op[r0 + 3] = (int8_t)(d >> 24);
 			}
 		}
 	}

@@ -494,7 +494,9 @@ def test_own_kernel_compiles_for_every_fixture_graph(built_lib, name):
               b"typedef unsigned long uintptr_t;\n")
     headers = [(b"stdint.h", stdint), (b"stddef.h", b"#pragma once\n"), (b"edison_hip.h", text("ed_jit_src_edison_hip_h")),
                (b"edison_internal.h", text("ed_jit_src_edison_internal_h")), (b"emm_spec.h", net_spec_source(blob).encode())]
-    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-fno-slp-vectorize", b"-DEMM_JIT=1", b"-DEMM_SPEC=1", b'-DEMM_SPEC_HEADER="emm_spec.h"']
+    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-fno-slp-vectorize", b"-DEMM_JIT=1", b"-DEMM_SPEC=1", b'-DEMM_SPEC_HEADER="emm_spec.h"',
+            b"-mllvm", b"-pragma-unroll-threshold=1000000"]
     r, log, code = _hiprtc_compile(text("ed_jit_src_kernel"), headers, opts)
     assert r == 0, log[:2000]
     assert b"ed_net_mfma_spec" in code and len(code) > 4096
+    assert "loop not unrolled" not in log, log[:2000]   # the layer loop MUST unroll: the layer records only become constants then
