@@ -675,6 +675,23 @@ def main():
             g_ms, _ = timed_region(net_step, 10, 2, 1 if world == 1 else world)
             kws["general_net_kernel"] = dict(value=round(world * nu / (g_ms * 1e-3), 1), unit="inputs/s", ms_per_step=round(g_ms, 4),
                                              what="kws_conv graph forced onto ed_net_mfma_kernel (edison_net_batch_dev, EDISON_NET_FORCE_GENERAL=1)")
+            # ... and through the graph's OWN kernel: the same source compiled at run time with this graph's plan as constants
+            # (edison_net_specialize); checked bit for bit against the hand-written kernel's logits of the same features
+            try:
+                ref_logits = logits.clone()
+                ctx.cnn_t(feat, nu, logits=ref_logits, softmax=soft, argmax=am)
+                t_c = time.perf_counter()
+                how = ctx.net_specialize()
+                t_c = time.perf_counter() - t_c
+                o_ms, _ = timed_region(net_step, 20, 3, 1 if world == 1 else world)
+                torch.cuda.synchronize()
+                kws["general_net_kernel"]["own_kernel"] = dict(
+                    value=round(world * nu / (o_ms * 1e-3), 1), unit="inputs/s", ms_per_step=round(o_ms, 4),
+                    how={1: "compiled by a hipcc child process", 2: "code object from the on-disk cache", 3: "compiled by hipRTC in this process"}[how],
+                    specialize_s=round(t_c, 2), logits_equal_hand_written_kernel=bool(torch.equal(logits, ref_logits)),
+                    what="ed_net_mfma_spec: ed_net_mfma_kernel's source with this graph's plan as constants (edison_net_specialize)")
+            except Exception as e:  # no compiler on this machine: the graph stays on the general kernel
+                kws["general_net_kernel"]["own_kernel"] = dict(value=None, error=str(e)[:200])
         finally:
             del os.environ["EDISON_NET_FORCE_GENERAL"]
         if not args.skip_q15:

@@ -165,7 +165,11 @@ __device__ __forceinline__ v4i emm_gather16(const lds8 *a, int soff, int keep)
  * down; lanes past the image fetch that same dword and drop it. (With byte loads under divergent branches for the tail
  * the compiler put a full vmcnt(0) behind every one of them -- inside the code that was meant to PREFETCH.) */
 #define EMM_PRE 2
-#define EMM_PB 4 /* images per wave the prefetch covers */
+#ifndef EMM_PB
+/* images per wave the prefetch covers: 4 in a graph's own kernel (unused slots fold away), 2 here -- the general kernel sits at
+ * its 168-register limit, two more images' registers go to scratch (+3 % at 2, measured on the planner's usual batch of 2) */
+#define EMM_PB (EMM_SPEC ? 4 : 2)
+#endif
 __device__ __forceinline__ void emm_load_image(const int8_t *src, int in_n, int lane, uint32_t (&x)[EMM_PRE])
 {
 #pragma unroll
