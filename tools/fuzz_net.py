@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Random sequential int8 graphs through the general network kernel against oracle/net_ref.py (which is pinned to
 the reference's NNoM on six graphs): shapes, kernels, strides, paddings and channel counts the fixtures do not hold.
-Graphs the planner refuses (reference quirks, LDS budget) are counted and skipped.   usage (box): tools/fuzz_net.py [n_graphs [seed]]"""
+Graphs the planner refuses (reference quirks, LDS budget) are counted and skipped.   usage (box): tools/fuzz_net.py [n_graphs [seed [own]]]
+With a third argument every graph that has a matrix-core plan is ALSO run on its own kernel (edison_net_specialize: ~1 s of
+compilation per graph) and compared again. 67 inputs per graph: ragged against every per-wave batch the planner picks."""
 import os
 import sys
 
@@ -55,8 +57,11 @@ def random_graph(rng):
 def main():
     n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
+    own = len(sys.argv) > 3
+    if own:
+        os.environ["EDISON_JIT_CACHE"] = "off"
     ctx = Context(0, model_path=None)
-    ran = refused = on_mfma = 0
+    ran = refused = on_mfma = on_own = 0
     while ran + refused < n_graphs:
         g = random_graph(rng)
         if g is None:
@@ -71,7 +76,7 @@ def main():
             assert e.code in (_lib.E_SIZE, _lib.E_NO_IMPL), str(e)
             refused += 1
             continue
-        x = rng.integers(-128, 128, (64, shape[0] * shape[1] * shape[2])).astype(np.int8)
+        x = rng.integers(-128, 128, (67, shape[0] * shape[1] * shape[2])).astype(np.int8)
         x[:8] = rng.integers(-10, 11, (8, x.shape[1]))
         ref = net_ref.run(blob, x)
         got = ctx.net_layers(x)
@@ -87,7 +92,14 @@ def main():
                 len(bad), bad[:1].tolist(), np.array_equal(out["argmax"], ref["argmax"])))
         ran += 1
         on_mfma += 1 if ctx.net_info().get("accelerated") == 2 else 0
-    print("general network kernel: %d random graphs bit-exact against oracle/net_ref.py (%d of them on the matrix-core kernel, the rest layer by layer), %d refused by the planner" % (ran, on_mfma, refused))
+        if own and ctx.net_info().get("accelerated") == 2:
+            ctx.net_specialize()
+            out2 = ctx.net(x)
+            if not (np.array_equal(out2["argmax"], ref["argmax"]) and np.array_equal(out2["logits"], ref["logits"])):
+                raise SystemExit("MISMATCH (the graph's OWN kernel) on graph %s %s" % (shape, [(L["type"], {k: v for k, v in L.items() if k not in ("w", "b")}) for L in plain]))
+            on_own += 1
+    print("general network kernel: %d random graphs bit-exact against oracle/net_ref.py (%d of them on the matrix-core kernel, the rest layer by layer%s), %d refused by the planner" % (
+        ran, on_mfma, "; %d of them again on their own run-time-compiled kernel" % on_own if own else "", refused))
 
 
 if __name__ == "__main__":
