@@ -126,6 +126,7 @@ int ed_ctx_net_launch_on(edison_ctx *ctx, hipStream_t stream, const int8_t *in, 
 int ed_ctx_net_spec_launch(edison_ctx *ctx, hipStream_t stream, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax,
                            int32_t *argmax);
 void ed_ctx_net_spec_drop(edison_ctx *ctx);
+void ed_ctx_net_spec_from_cache(edison_ctx *ctx);
 int ed_ctx_mfcc_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
                           int64_t frame_step, int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale,
                           int stages, float *fft, float *spec, float *mel, float *logmel);

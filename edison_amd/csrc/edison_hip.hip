@@ -272,10 +272,13 @@ extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t b
 	free(plan); free(h); free(hm); free(w); free(seeds);
 	if (r != EDISON_OK) return r;
 	ED_HIP(ctx, e);
-	/* EDISON_NET_SPECIALIZE=1: every load compiles (or finds in the cache) the graph's own kernel. A failure there is not a
-	 * failed load: the graph runs on the general kernel and edison_net_specialized() says so. */
-	static const int auto_spec = getenv("EDISON_NET_SPECIALIZE") ? atoi(getenv("EDISON_NET_SPECIALIZE")) : 0;
-	if (auto_spec && ctx->mm_ok) (void)edison_net_specialize(ctx);
+	/* The graph's own kernel (edison_net_jit.hip). By default a load takes it from the on-disk cache when an earlier
+	 * edison_net_specialize() of the same graph left it there (a file read, no compiler); EDISON_NET_SPECIALIZE=1: every load
+	 * compiles it when it is not cached; =0: never by itself. A failure there is not a failed load: the graph runs on the
+	 * general kernel and edison_net_specialized() says so. */
+	static const int auto_spec = getenv("EDISON_NET_SPECIALIZE") ? atoi(getenv("EDISON_NET_SPECIALIZE")) : -1;
+	if (auto_spec > 0 && ctx->mm_ok) { const int keep = edison_net_specialize(ctx); (void)keep; }
+	else if (auto_spec < 0 && ctx->mm_ok) ed_ctx_net_spec_from_cache(ctx);
 	return EDISON_OK;
 }
 

@@ -256,7 +256,9 @@ void ed_ctx_net_spec_drop(edison_ctx *ctx)
 	ctx->spec_state = 0;
 }
 
-extern "C" int edison_net_specialize(edison_ctx *ctx)
+/* cache_only: take the code object from the on-disk cache or leave the graph on the general kernel (EDISON_E_NO_IMPL), never
+ * start a compiler -- what a model load does by itself */
+static int specialize(edison_ctx *ctx, int cache_only)
 {
 	if (!ctx) return EDISON_E_ARGUMENT;
 	if (!ctx->have_model) return ed_set_err(ctx, EDISON_E_ARGUMENT, "edison_net_specialize: no model loaded");
@@ -294,6 +296,11 @@ extern "C" int edison_net_specialize(edison_ctx *ctx)
 		cache_path(path, sizeof(path), graph, source, is_hipcc ? "hipcc" : "hiprtc");
 		if (path[0] && (code = read_file(path, &code_bytes)) != NULL) state = 2;
 	}
+	if (!code && cache_only)
+	{
+		free(spec);
+		return ed_set_err(ctx, EDISON_E_NO_IMPL, "no cached code object for this graph");
+	}
 	if (!code)
 	{
 		int r = try_hipcc ? compile_with_hipcc(ctx, spec, &code, &code_bytes) : 0;
@@ -330,6 +337,16 @@ extern "C" int edison_net_specialize(edison_ctx *ctx)
 	ctx->spec_epoch = ctx->model_epoch;
 	ctx->spec_state = state;
 	return EDISON_OK;
+}
+
+extern "C" int edison_net_specialize(edison_ctx *ctx) { return specialize(ctx, 0); }
+
+/* a model load: the graph's own kernel if an earlier edison_net_specialize() left it in the cache; errors are not the load's */
+void ed_ctx_net_spec_from_cache(edison_ctx *ctx)
+{
+	char keep[sizeof(ctx->err)];
+	memcpy(keep, ctx->err, sizeof(keep));
+	if (specialize(ctx, 1) != EDISON_OK) memcpy(ctx->err, keep, sizeof(keep));
 }
 
 /* 0: the loaded graph runs on the general kernel; on its own kernel: 1 compiled just now by the hipcc child process, 2 taken

@@ -135,7 +135,9 @@ int edison_net_layers(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *acts
  * runs the general kernel for this load (edison_net_batch*, and edison_cnn_* / edison_kws_* / edison_stream_* for graphs
  * other than kws_conv) runs the graph's own: same arithmetic, bit-identical outputs, kws_conv graph 198 -> 236 M inputs/s.
  * EDISON_E_NO_IMPL: the graph has no matrix-core plan, or neither hipcc nor libhiprtc.so is installed -- the graph stays on the general
- * kernel. EDISON_NET_SPECIALIZE=1 in the environment makes every edison_model_load* do this by itself.
+ * kernel. A later edison_model_load* of the same graph (this process or another) takes the cached code object by itself (a
+ * file read, no compiler); EDISON_NET_SPECIALIZE=1 in the environment makes every load compile what is not cached, =0 keeps
+ * loads from looking.
  * edison_net_specialized: 0 general kernel; own kernel: 1 compiled just now by a hipcc child process (the installed ROCm's
  * compiler, tried first), 2 taken from the cache, 3 compiled just now by hipRTC in this process (EDISON_JIT_COMPILER=hipcc|hiprtc
  * picks one).

@@ -68,9 +68,10 @@ def test_own_kernel_matches_reference_fixtures_and_general_kernel(built_lib, jit
     assert np.array_equal(out["argmax"], np.argmax(final, axis=1))
     assert c.net_specialize() in (1, 3)                             # a second call changes nothing
     c.close()
-    # a new context finds the code object in the cache
+    # a new context finds the code object in the cache: already at load time, without being asked
     c2 = Context(0, model_path=None)
     c2.load_weights_h(_header(name))
+    assert c2.net_specialized() == 2
     assert c2.net_specialize() == 2
     again = c2.net(x)
     assert np.array_equal(again["logits"], ref["logits"]) and np.array_equal(again["argmax"], ref["argmax"])
@@ -113,11 +114,17 @@ def test_cache_can_be_switched_off_and_damaged_entries_are_replaced(built_lib, t
     (entry,) = list(d.glob("*.hsaco"))
     entry.write_bytes(b"not a code object")
     c = Context(0, model_path=None)
-    c.load_weights_h(_header("tiny_conv"))
-    with pytest.raises(Exception):
-        c.net_specialize()                                          # reported, the entry removed ...
-    assert c.net_specialized() == 0 and not entry.exists()
+    c.load_weights_h(_header("tiny_conv"))                          # the load looks into the cache by itself: a damaged entry is
+    assert c.net_specialized() == 0 and not entry.exists()          # not the load's problem; it is removed ...
     assert c.net_specialize() in (1, 3)                             # ... and the next call compiles again
+    entry.write_bytes(b"not a code object")
+    monkeypatch.setenv("EDISON_JIT_COMPILER", "neither")
+    c2 = Context(0, model_path=None)
+    c2.load_weights_h(_header("tiny_conv"))
+    with pytest.raises(Exception):
+        c2.net_specialize()                                         # an unknown compiler name is an argument error
+    c2.close()
+    monkeypatch.delenv("EDISON_JIT_COMPILER")
     x = np.zeros((3, c.net_info()["in_h"] * c.net_info()["in_w"] * c.net_info()["in_c"]), np.int8)
     c.net(x)
     c.close()
