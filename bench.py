@@ -152,10 +152,13 @@ def timed_region(step_fn, steps, warmup, world, settle_ms=0.0, settle_chunk=256,
     if cuda:
         e1.record()
     sync()
+    # this rank's K steps are done: its clock stops here, the MAX over ranks below is the job's time. The closing barrier is
+    # the fence in front of whatever is timed next; inside the interval it would add one more collective's latency (tens of
+    # microseconds) to a region that is 1 ms long at the default K for the 50 us MFCC step -- and only for N > 1.
+    wall = (time.perf_counter() - t0) * 1e3 / steps
     if world > 1:
         dist.barrier()
     sync()
-    wall = (time.perf_counter() - t0) * 1e3 / steps
     ev = e0.elapsed_time(e1) / steps if cuda else wall
     if world > 1:
         tt = torch.tensor([wall], dtype=torch.float64, device="cuda" if cuda else "cpu")
