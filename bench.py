@@ -680,7 +680,10 @@ def main():
                                              what="kws_conv graph forced onto ed_net_mfma_kernel (edison_net_batch_dev, EDISON_NET_FORCE_GENERAL=1)")
             # ... and through the graph's OWN kernel: the same source compiled at run time with this graph's plan as constants
             # (edison_net_specialize); checked bit for bit against the hand-written kernel's logits of the same features
+            # (N = 1 only: a per-GPU kernel figure, and a compiler that fails on ONE rank must not leave the others in a barrier)
             try:
+                if world > 1:
+                    raise RuntimeError("measured at N = 1 only")
                 ref_logits = logits.clone()
                 ctx.cnn_t(feat, nu, logits=ref_logits, softmax=soft, argmax=am)
                 t_c = time.perf_counter()
