@@ -265,6 +265,9 @@ typedef struct {
 	int32_t small;              /* 1: at most 16 columns per wave and nothing fused: v_mfma_i32_16x16x64_i8 tiles (16 rows x
 	                             * 16 columns, four 16-byte chunks per k-step); n_ks16 / n_rt16 count those                */
 	int32_t n_ks16, n_rt16;
+	int32_t pp;                 /* bytes from one input pixel to the next in this layer's LDS layout: C_in, or C_in + 16 where that
+	                             * takes the B reads (16 bytes per lane, neighbouring lanes = neighbouring pixels) and the
+	                             * producer's dword stores off the same LDS banks (C_in = 32, 64, ...: model_net_mm.c)          */
 	int32_t toep;               /* 1: row-Toeplitz form (model_net_mm.c): the GEMM's rows are (output x, output channel), k runs over
 	                             * (kernel row, byte of the whole padded input row), one column per output row; no expansion     */
 } ed_mm_layer_t;

@@ -35,6 +35,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		ed_mm_layer_t *M = &mm->L[i];
 		/* default: the layer reads a compact (unpadded) image */
 		M->in_hp = L->in_h; M->in_wp = L->in_w; M->in_py = 0; M->in_px = 0;
+		M->pp = L->type == ED_NET_DENSE ? L->in_n : L->in_c;
 		/* (a dense layer reads the same compact HWC image: it is a 1x1 convolution over ONE row of in_n bytes) */
 		if (L->type != ED_NET_CONV && L->type != ED_NET_DENSE)
 		{
@@ -127,6 +128,32 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		mm->L[i + 1].in_img = 0; /* the unpooled tensor never exists */
 	}
 
+	/* LDS banks. A B fragment is 16 bytes per lane and neighbouring lanes are neighbouring pixels; the epilogue of the layer in
+	 * front stores one dword per lane, neighbouring lanes again neighbouring pixels. With C_in = 32 or 64 bytes per pixel the 16
+	 * lanes of a read phase fall on every second / fourth 16-byte bank group and the stores on 8 / 4 of the 64 banks (the own
+	 * kernel of kws_conv: LDS pipe 86 % busy, 43 % of it conflicts, profiles/r03_net_counters.txt). One 16-byte gap behind every
+	 * pixel whose C_in is an EVEN multiple of 16 makes the pixel pitch an odd multiple: consecutive pixels then walk through all
+	 * 16 bank groups. Only the tables change (chunk offsets, column offsets, the producer's output pitch); the gaps are never
+	 * read. Not for layers that read an expanded copy or a Toeplitz row, not behind a Toeplitz producer (it stores whole rows),
+	 * not for Dense (one column per image: nothing to conflict with). EDISON_NET_NO_PIXEL_GAP=1: A/B knob. */
+	{
+		const char *env = getenv("EDISON_NET_NO_PIXEL_GAP");
+		for (int i = 0; i < n_layers && !(env && atoi(env)); i++)
+		{
+			const ed_net_layer_t *L = &plan->L[i];
+			ed_mm_layer_t *M = &mm->L[i];
+			if (!M->mm || L->type != ED_NET_CONV || M->expand || M->toep || (L->in_c % 32) != 0) continue;
+			int j = i - 1; /* the producer: the layer in front, or the one in front of a fused MaxPool */
+			if (j >= 0 && mm->L[j].skip) j--;
+			if (j >= 0 && mm->L[j].toep) continue;
+			if (j < 0 && !(plan->in_n <= ED_MM_MAX_INTAB)) continue; /* the input stage places pixels by table only */
+			M->pp = L->in_c + 16;
+			M->pitch_x = L->sw * M->pp;
+			M->pitch_y = M->in_wp * M->pp;
+			M->in_img = up16(M->in_hp * M->in_wp * M->pp) + 16;
+		}
+	}
+
 	/* column tables: (B offset, output offset) of every stored pixel, for the layers that fit ED_MM_MAX_COLS together */
 	int n_cols = 0;
 	for (int i = 0; i < n_layers; i++)
@@ -139,15 +166,15 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		const int st_h = dense ? 1 : (fused ? plan->L[i + 1].out_h : L->out_h), st_w = dense || M->toep ? 1 : (fused ? plan->L[i + 1].out_w : L->out_w);
 		if (n_cols + st_h * st_w > ED_MM_MAX_COLS) continue;
 		const int ph = fused ? M->pool_h : 1, pw = fused ? M->pool_w : 1, sh = dense ? 1 : L->sh;
-		int owp, opy, opx; /* the consumer's layout (the last layer's output is compact) */
-		if (nx < n_layers) { owp = mm->L[nx].in_wp; opy = mm->L[nx].in_py; opx = mm->L[nx].in_px; }
-		else { owp = fused ? plan->L[i + 1].out_w : L->out_w; opy = 0; opx = 0; }
+		int owp, opy, opx, opp; /* the consumer's layout (the last layer's output is compact) */
+		if (nx < n_layers) { owp = mm->L[nx].in_wp; opy = mm->L[nx].in_py; opx = mm->L[nx].in_px; opp = plan->L[nx].type == ED_NET_CONV ? mm->L[nx].pp : L->out_c; }
+		else { owp = fused ? plan->L[i + 1].out_w : L->out_w; opy = 0; opx = 0; opp = L->out_c; }
 		M->col_off = n_cols;
 		for (int y = 0; y < st_h; y++)
 			for (int x = 0; x < st_w; x++)
 			{
 				mm->coltab[2 * n_cols] = (y * ph * sh) * M->pitch_y + (x * pw) * M->pitch_x;
-				mm->coltab[2 * n_cols + 1] = ((y + opy) * owp + x + opx) * L->out_c;
+				mm->coltab[2 * n_cols + 1] = ((y + opy) * owp + x + opx) * opp;
 				n_cols++;
 			}
 	}
@@ -184,7 +211,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		for (int e = 0; e < plan->in_n; e++)
 		{
 			const int pix = e / plan->in_c, c = e - pix * plan->in_c, y = pix / plan->in_w, x = pix - y * plan->in_w;
-			mm->intab[e] = (uint16_t)(((y + M0->in_py) * M0->in_wp + x + M0->in_px) * plan->in_c + c);
+			mm->intab[e] = (uint16_t)(((y + M0->in_py) * M0->in_wp + x + M0->in_px) * (plan->L[0].type == ED_NET_CONV ? M0->pp : plan->in_c) + c);
 		}
 		mm->n_intab = plan->in_n;
 	}
@@ -353,7 +380,9 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		for (int c = 0; c < (M->small ? 4 * M->n_ks16 : 2 * M->n_ks); c++)
 		{
 			const int ky = c / M->cpr, jc = c - ky * M->cpr;
-			mm->koff[M->koff_off + c] = ky < kh ? ky * M->pitch_y + 16 * jc : 0; /* chunks past the end meet zero weights */
+			/* chunk jc of a kernel row: 16 bytes of pixel jc / (C_in / 16) -- behind a pixel gap the row is not contiguous */
+			const int in_row = (!dense && M->pp != in_c) ? (jc / (in_c / 16)) * M->pp + (jc % (in_c / 16)) * 16 : 16 * jc;
+			mm->koff[M->koff_off + c] = ky < kh ? ky * M->pitch_y + in_row : 0; /* chunks past the end meet zero weights */
 		}
 	}
 	/* bounds of everything the kernel will address in LDS, checked here on the host (a plan that fails stays off the
@@ -365,12 +394,12 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		const ed_net_layer_t *L = &plan->L[i];
 		const ed_mm_layer_t *M = &mm->L[i];
 		if (M->skip) continue; /* fused MaxPool: nothing runs for it */
-		int ohp, owp, opy, opx, oimg; /* the consumer's layout = where this layer's epilogue stores */
+		int ohp, owp, opy, opx, oimg, opp; /* the consumer's layout = where this layer's epilogue stores */
 		const int fused = M->pool_h > 0, nx = fused ? i + 2 : i + 1;          /* the consumer */
 		const int st_h = fused ? plan->L[i + 1].out_h : L->out_h, st_w = fused ? plan->L[i + 1].out_w : L->out_w; /* what is stored */
-		if (nx < n_layers) { ohp = mm->L[nx].in_hp; owp = mm->L[nx].in_wp; opy = mm->L[nx].in_py; opx = mm->L[nx].in_px; oimg = mm->L[nx].in_img; }
-		else { ohp = st_h; owp = st_w; opy = 0; opx = 0; oimg = up16(st_h * st_w * L->out_c) + 16; }
-		const int64_t last_store = ((int64_t)(st_h - 1 + opy) * owp + (st_w - 1 + opx)) * L->out_c + L->out_c;
+		if (nx < n_layers) { ohp = mm->L[nx].in_hp; owp = mm->L[nx].in_wp; opy = mm->L[nx].in_py; opx = mm->L[nx].in_px; oimg = mm->L[nx].in_img; opp = plan->L[nx].type == ED_NET_CONV ? mm->L[nx].pp : L->out_c; }
+		else { ohp = st_h; owp = st_w; opy = 0; opx = 0; oimg = up16(st_h * st_w * L->out_c) + 16; opp = L->out_c; }
+		const int64_t last_store = ((int64_t)(st_h - 1 + opy) * owp + (st_w - 1 + opx)) * opp + L->out_c;
 		/* input at one end of the region, output at the other */
 		const int o_off = in_off == 0 ? region - batch * oimg : 0;
 		int bad = last_store > oimg || ohp < st_h + opy || owp < st_w + opx || batch * (M->in_img + oimg) > region || o_off < 0 || (o_off & 15) || (in_off & 15);
@@ -409,6 +438,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		}
 		if (i == 0)
 			for (int e = 0; e < mm->n_intab; e++) bad |= mm->intab[e] >= M->in_img;
+		bad |= M->toep && opp != L->out_c; /* a Toeplitz layer stores whole rows: its consumer's pixels must be gap-free */
 		if (bad) { free(fb); free(sb); return EDISON_OK; } /* mm->ok stays 0 */
 		/* the run record */
 		ed_mm_run_t *R = &mm->R[i];
@@ -416,7 +446,7 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		R->kind = M->mm ? ED_RUN_MM : (L->type == ED_NET_POOL ? ((L->in_c & 3) == 0 ? ED_RUN_POOL4 : ED_RUN_POOL1) : ED_RUN_SOFTMAX);
 		R->zero_border = ohp != st_h || owp != st_w;
 		R->in_img = M->in_img; R->o_img = oimg;
-		R->oc_pitch = L->out_c; R->o_origin = (opy * owp + opx) * L->out_c; R->o_row = owp * L->out_c;
+		R->oc_pitch = opp; R->o_origin = (opy * owp + opx) * opp; R->o_row = owp * opp;
 		R->li_out = fused ? i + 1 : i;
 		R->expand = M->expand; R->x_img = M->x_img; R->xtab_off = M->xtab_off;
 		R->rec_per_img = M->mm ? (dense ? 1 : M->in_hp) * (dense ? 1 : L->out_w) * M->cpr : 0;
