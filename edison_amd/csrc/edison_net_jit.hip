@@ -190,7 +190,22 @@ static int compile_with_hipcc(edison_ctx *ctx, const char *spec, char **code, si
 		posix_spawn_file_actions_adddup2(&fa, 1, 2);
 		pid_t pid = 0;
 		int status = 0;
-		const int sp = posix_spawn(&pid, hipcc, &fa, NULL, (char *const *)argv, environ);
+		/* the compiler is a plain host program: it must not inherit what makes THIS process's children touch the GPU -- a
+		 * profiler's LD_PRELOAD / HSA_TOOLS_LIB / ROCP* settings would load the tool (and initialise the device) in hipcc and in
+		 * every program hipcc starts in turn */
+		size_t n_env = 0;
+		while (environ && environ[n_env]) n_env++;
+		char **envp = (char **)calloc(n_env + 1, sizeof(char *));
+		size_t kept = 0;
+		static const char *drop[] = {"LD_PRELOAD=", "HSA_TOOLS_LIB=", "HSA_TOOLS_REPORT_LOAD_FAILURE=", "ROCP", "ROCTRACER", "ROCPROFILER", "HIP_TOOLS", "OMPT_"};
+		for (size_t k = 0; envp && k < n_env; k++)
+		{
+			int skip = 0;
+			for (size_t d = 0; d < sizeof(drop) / sizeof(drop[0]); d++) skip |= strncmp(environ[k], drop[d], strlen(drop[d])) == 0;
+			if (!skip) envp[kept++] = environ[k];
+		}
+		const int sp = envp ? posix_spawn(&pid, hipcc, &fa, NULL, (char *const *)argv, envp) : ENOMEM;
+		free(envp);
 		posix_spawn_file_actions_destroy(&fa);
 		if (sp != 0) snprintf(ctx->err, sizeof(ctx->err), "edison_net_specialize: cannot start %s: %s", hipcc, strerror(sp));
 		else
