@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault("EDISON_NET_SPECIALIZE", "0")  # model loads do not take a cached own kernel by themselves: the general-kernel leg times the general kernel
 import numpy as np  # noqa: E402
 import torch        # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -9,6 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("EDISON_NET_SPECIALIZE", "0")  # a model load must not take a cached own kernel by itself: this tool times the general one
 import torch
 from edison_amd.context import Context, _t_ptr
 

@@ -4,6 +4,7 @@ usage (GPU box): tools/lab/ab_net.py [--utts N] name1 name2 ...   ('prod' = the 
 import argparse, ctypes, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("EDISON_NET_SPECIALIZE", "0")  # a model load must not take a cached own kernel by itself: this tool times the general one
 import torch
 os.environ["EDISON_NET_FORCE_GENERAL"] = "1"
 from edison_amd import _lib

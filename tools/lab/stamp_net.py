@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 os.environ["EDISON_NET_FORCE_GENERAL"] = "1"
 os.environ["EDISON_LIB"] = os.path.join(ROOT, "edison_amd/csrc/abl/libedison_hip_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "netstamp"))
+os.environ.setdefault("EDISON_NET_SPECIALIZE", "0")  # a model load must not take a cached own kernel by itself: this tool times the general one
 import torch
 from edison_amd import _lib
 from edison_amd.context import Context, _t_ptr
