@@ -34,8 +34,13 @@ struct edison_stream
 	int filter;
 	int use_graph;        /* edison_stream_opts.launch_mode */
 	double alpha, one_minus_alpha, threshold;
-	int16_t *d_audio;     /* [tail + chunk*hop]                      */
-	int8_t *d_feat;       /* [(30 + chunk) * 13]                     */
+	int16_t *d_audio;     /* [tail + slots*chunk*hop]                */
+	int8_t *d_feat;       /* [(30 + slots*chunk) * 13]               */
+	/* Direct device pushes SLIDE through buffers `slots` pushes long instead of moving the history back to the front after
+	 * every push: a_pos / f_pos = where the history (tail samples / 30 rows) starts now. The shift kernel runs when the next
+	 * push would not fit -- one launch in `slots` pushes instead of one per push (a push of 4096 frames is ~29 us of GPU time,
+	 * most of it kernel boundaries). Every other path (captured graphs hold addresses) first brings the history to the front. */
+	int slots, a_pos, f_pos;
 	int8_t *d_soft;       /* [chunk * 10]                            */
 	int8_t *d_logits;     /* [chunk * 10]                            */
 	int32_t *d_argmax;    /* [chunk]                                 */
@@ -89,18 +94,18 @@ struct edison_stream
 #define ED_STREAM_STAGED_MAX_BYTES (1u << 20) /* chunks above 1 MB of samples go through plain async copies */
 #define ED_STREAM_MAPPED_MAX_BYTES (16u << 10) /* pushes of at most 16 KB of samples run against host-mapped buffers */
 
-__global__ void ed_stream_shift_kernel(int16_t *audio, int tail, int new_samples, int8_t *feat, int chunk)
+__global__ void ed_stream_shift_kernel(int16_t *dst_audio, const int16_t *src_audio, int tail, int8_t *dst_feat, const int8_t *src_feat)
 {
-	/* keep the newest `tail` samples and the newest 30 feature rows at the front of their buffers. One workgroup:
-	 * read everything into registers first, then barrier, then write (source and destination may overlap). */
+	/* the newest `tail` samples and the newest 30 feature rows to the front of their buffers. One workgroup: read
+	 * everything into registers first, then barrier, then write (source and destination may overlap). */
 	const int t = threadIdx.x;
 	int16_t a[4];
 	int8_t f[2];
-	for (int i = 0; i < 4; i++) { const int j = t + i * 256; a[i] = j < tail ? audio[new_samples + j] : (int16_t)0; }
-	for (int i = 0; i < 2; i++) { const int j = t + i * 256; f[i] = j < 30 * EDISON_NUM_MFCC ? feat[chunk * EDISON_NUM_MFCC + j] : (int8_t)0; }
+	for (int i = 0; i < 4; i++) { const int j = t + i * 256; a[i] = j < tail ? src_audio[j] : (int16_t)0; }
+	for (int i = 0; i < 2; i++) { const int j = t + i * 256; f[i] = j < 30 * EDISON_NUM_MFCC ? src_feat[j] : (int8_t)0; }
 	__syncthreads();
-	for (int i = 0; i < 4; i++) { const int j = t + i * 256; if (j < tail) audio[j] = a[i]; }
-	for (int i = 0; i < 2; i++) { const int j = t + i * 256; if (j < 30 * EDISON_NUM_MFCC) feat[j] = f[i]; }
+	for (int i = 0; i < 4; i++) { const int j = t + i * 256; if (j < tail) dst_audio[j] = a[i]; }
+	for (int i = 0; i < 2; i++) { const int j = t + i * 256; if (j < 30 * EDISON_NUM_MFCC) dst_feat[j] = f[i]; }
 }
 
 /*
@@ -150,15 +155,17 @@ static int enqueue_mapped_push(edison_stream *s, unsigned seq, int *flag_written
 
 /* enqueue the device operations of a push on hipStream q (passed explicitly: ctx->stream is not touched); the CNN writes
  * logits / softmax / argmax where it is told to (the stream's own block, or the caller's buffers) */
-static int enqueue_push_on(edison_stream *s, hipStream_t q, int8_t *logits, int8_t *softmax, int32_t *argmax)
+static int enqueue_push_on(edison_stream *s, hipStream_t q, int8_t *logits, int8_t *softmax, int32_t *argmax, int slide = 0)
 {
 	edison_ctx *ctx = s->ctx;
+	int16_t *audio = s->d_audio + s->a_pos;                          /* history, then the new samples */
+	int8_t *feat = s->d_feat + (size_t)s->f_pos * EDISON_NUM_MFCC;   /* 30 rows of history, then the new rows */
 	/* 13 coefficients, int8 net input (scale 1): rows 30.. of the feature buffer */
-	int r = ed_ctx_mfcc_launch_on(ctx, q, s->d_audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
-	                              s->d_feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
+	int r = ed_ctx_mfcc_launch_on(ctx, q, audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
+	                              feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
 	if (r != EDISON_OK) return r;
 	/* window i of the push = rows i..i+30 of the feature buffer: a 13-byte utterance stride, nothing is copied */
-	r = ed_ctx_kws_cnn_launch_on(ctx, q, s->d_feat, s->chunk, EDISON_NUM_MFCC, logits, softmax, argmax);
+	r = ed_ctx_kws_cnn_launch_on(ctx, q, feat, s->chunk, EDISON_NUM_MFCC, logits, softmax, argmax);
 	if (r != EDISON_OK) return r;
 	if (s->filter)
 	{
@@ -166,9 +173,27 @@ static int enqueue_push_on(edison_stream *s, hipStream_t q, int8_t *logits, int8
 		                   s->one_minus_alpha, s->threshold, s->d_filt_state, s->d_filt, s->d_likely, s->d_spotted);
 		if (hipGetLastError() != hipSuccess) return ed_set_err(ctx, EDISON_E_RUNTIME, "stream: filter launch failed");
 	}
-	hipLaunchKernelGGL(ed_stream_shift_kernel, dim3(1), dim3(256), 0, q, s->d_audio, s->tail, s->chunk * s->hop,
-	                   s->d_feat, s->chunk);
+	if (slide && s->a_pos / (s->chunk * s->hop) + 2 <= s->slots)
+	{
+		/* the next push finds its history behind this push's samples / rows and still fits: nothing moves */
+		s->a_pos += s->chunk * s->hop;
+		s->f_pos += s->chunk;
+		return EDISON_OK;
+	}
+	hipLaunchKernelGGL(ed_stream_shift_kernel, dim3(1), dim3(256), 0, q, s->d_audio, audio + s->chunk * s->hop, s->tail,
+	                   s->d_feat, feat + (size_t)s->chunk * EDISON_NUM_MFCC);
+	if (slide) s->a_pos = s->f_pos = 0; /* (a captured graph always runs at position 0 and ends here) */
 	return hipGetLastError() == hipSuccess ? EDISON_OK : ed_set_err(ctx, EDISON_E_RUNTIME, "stream: shift launch failed");
+}
+
+/* every path but the sliding device push wants the history at the front of the buffers */
+static int history_to_front(edison_stream *s, hipStream_t q)
+{
+	if (!s->a_pos && !s->f_pos) return EDISON_OK;
+	hipLaunchKernelGGL(ed_stream_shift_kernel, dim3(1), dim3(256), 0, q, s->d_audio, s->d_audio + s->a_pos, s->tail,
+	                   s->d_feat, s->d_feat + (size_t)s->f_pos * EDISON_NUM_MFCC);
+	s->a_pos = s->f_pos = 0;
+	return hipGetLastError() == hipSuccess ? EDISON_OK : ed_set_err(s->ctx, EDISON_E_RUNTIME, "stream: shift launch failed");
 }
 
 static int enqueue_push(edison_stream *s) { return enqueue_push_on(s, s->own, s->d_logits, s->d_soft, s->d_argmax); }
@@ -236,6 +261,7 @@ extern "C" int edison_stream_reset(edison_stream *s)
 	if (!s) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
 	{ const int rq = drain_q(s, s->own); if (rq != EDISON_OK) return rq; }
+	s->a_pos = s->f_pos = 0;
 	ED_HIP(ctx, hipMemsetAsync(s->d_audio, 0, sizeof(int16_t) * (size_t)(s->tail + s->chunk * s->hop), s->own));
 	ED_HIP(ctx, hipMemsetAsync(s->d_feat, 0, (size_t)(30 + s->chunk) * EDISON_NUM_MFCC, s->own));
 	if (s->filter) ED_HIP(ctx, hipMemsetAsync(s->d_filt_state, 0, sizeof(float) * EDISON_NET_OUT, s->own));
@@ -253,6 +279,7 @@ static int stream_state_to(edison_stream *s, int host)
 	edison_ctx *ctx = s->ctx;
 	if (!s->m_audio || s->state_host == host) return EDISON_OK;
 	{ const int rq = drain_q(s, s->own); if (rq != EDISON_OK) return rq; }
+	{ const int rf = history_to_front(s, s->own); if (rf != EDISON_OK) return rf; }
 	const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
 	if (s->tail) ED_HIP(ctx, hipMemcpyAsync(host ? (void *)s->m_audio : (void *)s->d_audio, host ? (void *)s->d_audio : (void *)s->m_audio, sizeof(int16_t) * (size_t)s->tail, kind, s->own));
 	ED_HIP(ctx, hipMemcpyAsync(host ? (void *)s->m_feat : (void *)s->d_feat, host ? (void *)s->d_feat : (void *)s->m_feat, 30 * EDISON_NUM_MFCC, kind, s->own));
@@ -305,8 +332,10 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming);
-	if (e == hipSuccess) e = hipMalloc((void **)&s->d_audio, sizeof(int16_t) * (size_t)(s->tail + s->chunk * s->hop) + 16);
-	if (e == hipSuccess) e = hipMalloc((void **)&s->d_feat, (size_t)(30 + s->chunk) * EDISON_NUM_MFCC + 16);
+	/* eight pushes of room for the sliding device pushes, as long as that stays below 64 MB of samples */
+	s->slots = (!s->use_graph && (size_t)s->chunk * s->hop * sizeof(int16_t) * 8 <= ((size_t)64 << 20)) ? 8 : 1;
+	if (e == hipSuccess) e = hipMalloc((void **)&s->d_audio, sizeof(int16_t) * ((size_t)s->tail + (size_t)s->slots * s->chunk * s->hop) + 16);
+	if (e == hipSuccess) e = hipMalloc((void **)&s->d_feat, (size_t)(30 + (size_t)s->slots * s->chunk) * EDISON_NUM_MFCC + 16);
 	{
 		/* every output of a push in one device block, so that the host path fetches them with a single copy */
 		const size_t c = (size_t)s->chunk;
@@ -439,10 +468,10 @@ extern "C" int edison_stream_push_dev(edison_stream *s, const int16_t *samples, 
 		 * buffers; the private stream is idle here (everything it ever does ends in a synchronisation) */
 		hipStream_t q = ctx->stream;
 		{ const int rq = drain_q(s, q); if (rq != EDISON_OK) return rq; }
-		ED_HIP(ctx, hipMemcpyAsync(s->d_audio + s->tail, samples, nnew * sizeof(int16_t), hipMemcpyDeviceToDevice, q));
+		ED_HIP(ctx, hipMemcpyAsync(s->d_audio + s->a_pos + s->tail, samples, nnew * sizeof(int16_t), hipMemcpyDeviceToDevice, q));
 		/* the output filter reads the softmax from the stream's own block */
 		int8_t *so = s->filter ? s->d_soft : softmax;
-		{ const int rd = enqueue_push_on(s, q, logits, so, argmax); if (rd != EDISON_OK) return rd; }
+		{ const int rd = enqueue_push_on(s, q, logits, so, argmax, 1); if (rd != EDISON_OK) return rd; }
 		if (s->filter && softmax) ED_HIP(ctx, hipMemcpyAsync(softmax, s->d_soft, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToDevice, q));
 		s->q_last = q;
 		s->q_pending = 1;
@@ -527,6 +556,7 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 	}
 	{ const int rs = stream_state_to(s, 0); if (rs != EDISON_OK) return rs; }
 	{ const int rq = drain_q(s, s->own); if (rq != EDISON_OK) return rq; } /* device pushes may have left work on the caller's stream */
+	{ const int rf = history_to_front(s, s->own); if (rf != EDISON_OK) return rf; } /* ... and the history somewhere behind the front */
 	s->last_push_mapped = 0;
 	if (s->exec_h)
 	{

@@ -224,3 +224,39 @@ def test_stream_launch_modes_agree(ctx, hop, chunk, filt):
         st.close()
     assert np.array_equal(got[False][0], got[True][0]) and np.array_equal(got[False][1], got[True][1])
     assert np.array_equal(got[False][0], res[False]["softmax"])
+
+
+@pytest.mark.parametrize("hop,chunk", [(512, 3), (1024, 1), (300, 7)])
+def test_device_pushes_slide_through_the_history_buffer_and_wrap(ctx, hop, chunk):
+    """Direct device pushes do not move the history back to the front after every push: they slide through buffers eight
+    pushes long and shift once when the next push would not fit (edison_stream.hip: slots). 27 device pushes = three wraps,
+    with a host push thrown in at the 6th and the 14th (which first brings the history to the front): every output equals
+    what a stream fed through host pushes alone answers."""
+    import torch
+    from edison_amd.stream import Stream
+    rng = np.random.default_rng(1000 + hop + chunk)
+    n_push = 27
+    audio = np.clip(rng.normal(0, 2500, n_push * chunk * hop), -32768, 32767).astype(np.int16)
+    ref = Stream(ctx, hop=hop, chunk_frames=chunk)
+    want = [ref.push(audio[i * chunk * hop:(i + 1) * chunk * hop]) for i in range(n_push)]
+    ref.close()
+    dev = torch.device("cuda", ctx.device)
+    ctx.use_torch_stream()
+    a = torch.from_numpy(audio).to(dev)
+    st = Stream(ctx, hop=hop, chunk_frames=chunk)
+    so = torch.zeros((n_push * chunk, 10), dtype=torch.int8, device=dev)
+    am = torch.zeros((n_push * chunk,), dtype=torch.int32, device=dev)
+    for i in range(n_push):
+        if i in (5, 13):
+            got = st.push(audio[i * chunk * hop:(i + 1) * chunk * hop])
+            assert np.array_equal(got["softmax"], want[i]["softmax"]) and np.array_equal(got["argmax"], want[i]["argmax"]), i
+        else:
+            st.push_t(a[i * chunk * hop:(i + 1) * chunk * hop], softmax=so[i * chunk:(i + 1) * chunk], argmax=am[i * chunk:(i + 1) * chunk])
+    torch.cuda.synchronize()
+    st.close()
+    so, am = so.cpu().numpy(), am.cpu().numpy()
+    for i in range(n_push):
+        if i in (5, 13):
+            continue
+        assert np.array_equal(so[i * chunk:(i + 1) * chunk], want[i]["softmax"]), i
+        assert np.array_equal(am[i * chunk:(i + 1) * chunk], np.asarray(want[i]["argmax"]).reshape(-1)), i
