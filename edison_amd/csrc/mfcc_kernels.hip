@@ -420,6 +420,12 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
                            * (slowest) waves while the older ones had retired: loop ends 38 .. 46 us after launch (stamps). Needs
                            * ED2_CVT_END and ED2_ASM_QUEUE. */
 #endif
+#if ED2_STAGGER && (ED2_TABLES_FIRST || ED2_TW_LDS)
+/* measured the hard way (round 3, a lab build that never returned): with ED2_STAGGER the tables are staged by the first four
+ * waves, which then count in LDS; the ED2_TABLES_FIRST staging loop does not count (every wave would poll for ever) and the
+ * ED2_TW_LDS twiddles are read before the poll */
+#error "ED2_STAGGER needs ED2_TABLES_FIRST = 0 and ED2_TW_LDS = 0"
+#endif
 #ifndef ED2_STAGGER_SLEEP
 #define ED2_STAGGER_SLEEP 8 /* s_sleep units (64 cycles each) per wave group */
 #endif
