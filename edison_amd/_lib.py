@@ -67,6 +67,9 @@ SIGNATURES = {
     "edison_net_specialize": (c_int, [c_void_p]),
     "edison_net_specialized": (c_int, [c_void_p]),
     "edison_net_spec_source": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+    "edison_net_plan_dump": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, ctypes.c_size_t, c_void_p, ctypes.c_size_t, c_void_p, ctypes.c_size_t,
+                                     ctypes.POINTER(ctypes.c_size_t), c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+    "edison_net_plan_layout": (ctypes.c_size_t, [c_int]),
     "edison_dist_available": (c_int, []),
     "edison_dist_unique_id": (c_int, [c_void_p]),
     "edison_dist_init": (c_int, [c_void_p, c_void_p, c_int, c_int]),

@@ -146,6 +146,13 @@ int edison_net_layers(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *acts
 int edison_net_specialize(edison_ctx *ctx);
 int edison_net_specialized(edison_ctx *ctx);
 int edison_net_spec_source(const void *ednn_blob, size_t blob_bytes, char *out, size_t cap, size_t *need);
+/* Host only, for tests and inspection: the plans of an .ednn blob as the matrix-core kernels get them (raw structs of
+ * csrc/edison_internal.h: ed_net_plan_t, ed_mm_plan_t), the packed weight fragments and the accumulator seeds; any out pointer
+ * may be NULL, *_need report the bytes wanted. edison_net_plan_layout(i): struct sizes / field offsets (see net_spec.c) so that a
+ * reader outside C need not restate the layout -- tests/plan_emulator.py walks a plan in numpy exactly as the kernel does. */
+int edison_net_plan_dump(const void *ednn_blob, size_t blob_bytes, void *plan_out, size_t plan_cap, void *mm_out, size_t mm_cap,
+                         void *frag_out, size_t frag_cap, size_t *frag_need, void *seeds_out, size_t seeds_cap, size_t *seeds_need);
+size_t edison_net_plan_layout(int which);
 
 /* ---- device memory helpers (so a C caller needs nothing but this library) ---------------------------- */
 int edison_dev_alloc(edison_ctx *ctx, size_t bytes, void **dptr);
