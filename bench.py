@@ -602,7 +602,7 @@ def main():
         d_ms, dev_ms = timed_region(d_step, max(20, args.steps // 4), min(args.warmup, 50), world)
         variant_d = dict(metric="MFCC frames/sec, variant D (firmware float32 ML-KWS extractor, 512-sample frames, hop 256)", unit="frames/s",
                          value=round(world * nfd / (d_ms * 1e-3), 1), ms_per_step=round(d_ms, 4), kernel_ms=round(dev_ms, 4),
-                         frames_per_step=nfd, parity="unpinned (no reference vectors; checker oracle/mfcc_f32_ref.c)")
+                         frames_per_step=nfd, parity="pinned on the reference's object code (mfcc_compute + CMSIS float transform; tests/golden/mfccf32_golden.npz)")
         md.close()
     except Exception as e:  # an extra workload must never cost the headline numbers
         variant_d = dict(error=repr(e))

@@ -154,7 +154,7 @@ extern "C" int ed_launch_mfcc_f32(const ed_mfcc_f32_args_t *args, const ed_f32_t
  * give). Frames are handed to the 12 waves of a CU-wide workgroup through a counter in LDS, as in ed_mfcc2_kernel.
  * Mel: two lanes per band (first / second half of the band's taps), log, DCT row per lane, scale, round half away,
  * saturate -- float32 like the firmware; the order of the partial sums differs from its serial loops, inside the bars
- * tests/test_gpu_f32.py states. Parity unpinned, as for the whole variant.
+ * tests/test_gpu_f32.py states (the variant is pinned on the reference's compiled mfcc_compute + CMSIS transform: tests/golden/mfccf32_golden.npz).
  */
 #include "mfcc_fft.h"
 

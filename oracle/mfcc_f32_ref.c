@@ -14,8 +14,11 @@
  * reference calls CMSIS arm_rfft_fast_f32, whose tables (arm_common_tables.c) are missing from the snapshot; here the
  * transform is evaluated in double and rounded to float, i.e. at least as accurate as any float32 FFT.
  *
- * PARITY STATUS: parity unpinned. The reference holds no vector for this path, it cannot be linked here, and in the
- * reference itself it is switched off (#if'd "NNoM example") and feeds a 63 x 12 input that the shipped 31 x 13
+ * PARITY STATUS: pinned (round 3). The reference's own mfcc_compute with CMSIS-DSP's float transform compiled under it
+ * (oracle/_ref/libmfcc_f32_ref.so, ref_shim/mfcc_f32_ref_shim.c; the transform's table values regenerated, its bit-reversal
+ * list derived from the routine) answers the same frames: int8 equal but for rounding-boundary values, log-mel within 1e-3
+ * clear of the float32 rounding floor (tests/test_oracle_refpins.py, fixture tests/golden/mfccf32_golden.npz). In the
+ * reference itself the path is switched off (#if'd "NNoM example") and feeds a 63 x 12 input that the shipped 31 x 13
  * network does not accept.
  */
 /* no fused multiply-adds: mfcc.c is compiled at -O0 for the MCU (firmware/Makefile:42) and plain C rounds every operation;

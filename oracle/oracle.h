@@ -67,7 +67,7 @@ int oracle_mfcc_q15(const oracle_q15_tables_t *t, const int16_t *x, int64_t n_fr
 void oracle_net_input_q15(const int16_t *mfcc, int64_t n_rows, int stride, int n_coef, int scale, int clip_lo,
                           int clip_hi, int8_t *out);
 
-/* ---- MFCC variant D: the firmware's float32 ML-KWS extractor (mfcc_f32_ref.c; parity unpinned, see its header) ---- */
+/* ---- MFCC variant D: the firmware's float32 ML-KWS extractor (mfcc_f32_ref.c; pinned on the reference's object code, see its header) ---- */
 
 typedef struct oracle_f32_mfcc oracle_f32_mfcc_t;
 /* mfcc_create (firmware/src/audio/mfcc.c:47-84); NULL on bad arguments */

@@ -232,7 +232,11 @@ class MfccF32Ref:
 
     def __init__(self):
         vp, ci = ctypes.c_void_p, ctypes.c_int
-        self._f = _open_lazy(F32_REF_SO, {"f32ref_dct_matrix": (ci, [ci, ci, vp]), "f32ref_mel_fbank": (ci, [ci, vp, vp, vp, ci])})
+        cf = ctypes.c_float
+        self._f = _open_lazy(F32_REF_SO, {"f32ref_dct_matrix": (ci, [ci, ci, vp]), "f32ref_mel_fbank": (ci, [ci, vp, vp, vp, ci]),
+                                          "f32ref_cfft": (None, [vp, vp, ci, ci, vp, ci]), "f32ref_rfft": (None, [vp, vp, ci, vp, ci, vp, vp]),
+                                          "f32ref_compute": (ci, [ci, ci, ci, ci, cf, vp, vp, ci, vp, vp, ci, ci, vp, vp])})
+        self._tables = {}
 
     def dct_matrix(self, input_length, coefficient_count):
         out = np.zeros((coefficient_count, input_length), np.float32)
@@ -247,6 +251,86 @@ class MfccF32Ref:
         if n < 0:
             raise RuntimeError("create_mel_fbank failed")
         return first, last, w[:n].copy()
+
+
+    # ---- the CMSIS-DSP float transform of the reference, on tables regenerated here (arm_common_tables.c is absent from the snapshot)
+    def fft_tables(self, n):
+        """Tables for arm_rfft_fast_f32 of n real points (n / 2 complex): (twiddle [n/2][2] f32, bit-reversal list u16, rfft twiddle f32).
+        Twiddle VALUES by their formula (float64 cos / sin rounded to float32). The bit-reversal PERMUTATION is read off the
+        reference's own routine: arm_cfft_f32 without bit reversal is run on the n / 2 complex exponentials and the bin each one
+        lands in is where the reversal has to fetch it from. Both, and the layout of the real-transform twiddles, are then
+        checked against numpy's FFT through the reference's compiled arm_cfft_f32 / arm_rfft_fast_f32 (float32 tolerance)."""
+        if n in self._tables:
+            return self._tables[n]
+        m = n // 2
+        k = np.arange(m)
+        tw = np.stack([np.cos(2 * np.pi * k / m), np.sin(2 * np.pi * k / m)], axis=1).astype(np.float32)
+        none = np.zeros(2, np.uint16)
+        perm = np.zeros(m, np.int64)
+        for q in range(m):
+            z = np.exp(2j * np.pi * q * k / m)
+            d = np.stack([z.real, z.imag], axis=1).astype(np.float32).copy()
+            self._f["f32ref_cfft"](_p(tw), _p(none), 0, m, _p(d), 0)
+            mag = d[:, 0].astype(np.float64) ** 2 + d[:, 1].astype(np.float64) ** 2
+            perm[q] = int(np.argmax(mag))
+            assert mag[perm[q]] > 0.99 * m * m and np.delete(mag, perm[q]).max() < 1e-3 * m * m, "the transform's output is not a permutation of the DFT"
+        assert np.array_equal(np.sort(perm), k), "the transform's output is not a permutation of the DFT"
+        # X[q] sits at position perm[q]. arm_bitreversal_32 applies a LIST OF SWAPS (word index = entry >> 2, two words per complex
+        # value); a mixed-radix digit reversal (4 x 8 x 8 for 256 points) is not its own inverse, so the list walks the cycles:
+        # swapping (q0, q1), (q1, q2), ... along q -> perm[q] leaves d[perm[q]] at q. ARM's table orders its swaps differently; pure
+        # data movement, the same result.
+        pairs, seen = [], np.zeros(m, bool)
+        for q0 in range(m):
+            q = q0
+            while not seen[q]:
+                seen[q] = True
+                nxt = int(perm[q])
+                if nxt != q0 and not seen[nxt]:
+                    pairs.append((q, nxt))
+                q = nxt
+        rev = np.array([v for a, b in pairs for v in (8 * a, 8 * b)], np.uint16)
+        rng = np.random.default_rng(5)
+        z = rng.normal(size=m) + 1j * rng.normal(size=m)
+        d = np.stack([z.real, z.imag], axis=1).astype(np.float32).copy()
+        self._f["f32ref_cfft"](_p(tw), _p(rev), rev.size, m, _p(d), 1)
+        want = np.fft.fft(z)
+        assert np.abs((d[:, 0] + 1j * d[:, 1]) - want).max() < 1e-4 * np.abs(want).max(), "arm_cfft_f32 on the regenerated tables is not the DFT"
+        # the real-transform stage: CMSIS stores (sin, cos) of 2 pi i / n -- both layouts are tried, the DFT decides
+        x = rng.normal(size=n).astype(np.float32)
+        wantr = np.fft.rfft(x.astype(np.float64))
+        rt = None
+        for cand in (np.stack([np.sin(2 * np.pi * k / n), np.cos(2 * np.pi * k / n)], axis=1), np.stack([np.cos(2 * np.pi * k / n), np.sin(2 * np.pi * k / n)], axis=1)):
+            cand = cand.astype(np.float32)
+            xin, out = x.copy(), np.zeros(n, np.float32)
+            self._f["f32ref_rfft"](_p(tw), _p(rev), rev.size, _p(cand), n, _p(xin), _p(out))
+            got = out[0::2].astype(np.float64) + 1j * out[1::2].astype(np.float64)   # [X0.re + i X(n/2).re, X1, X2, ...]
+            ok = abs(got[0].real - wantr[0].real) < 1e-3 and abs(got[0].imag - wantr[m].real) < 1e-3 and np.abs(got[1:] - wantr[1:m]).max() < 1e-4 * np.abs(wantr).max()
+            if ok:
+                rt = cand
+                break
+        assert rt is not None, "arm_rfft_fast_f32 on the regenerated tables is not the real DFT"
+        self._tables[n] = (tw, rev, rt)
+        return self._tables[n]
+
+    def compute(self, x, n_frames=None, frame_step=None, num_mfcc_features=13, feature_offset=1, frame_len=512, mfcc_dec_bits=8, preempha=0.97):
+        """The reference's own mfcc_compute (mfcc.c:174-255) with the CMSIS transform compiled from the reference under it:
+        -> (int8 [n][num_mfcc_features - feature_offset], float32 log-mel [n][26])."""
+        x = np.ascontiguousarray(x, dtype=np.int16).ravel()
+        step = frame_len if frame_step is None else frame_step
+        if n_frames is None:
+            n_frames = 1 + (x.shape[0] - frame_len) // step if x.shape[0] >= frame_len else 0
+        n = max(int(n_frames), 0)
+        padded = 1 << int(np.ceil(np.log2(frame_len)))
+        tw, rev, rt = self.fft_tables(padded)
+        out = np.zeros((n, num_mfcc_features - feature_offset), np.int8)
+        lm = np.zeros((n, 26), np.float32)
+        if n:
+            assert (n - 1) * step + frame_len <= x.shape[0]
+            r = self._f["f32ref_compute"](num_mfcc_features, feature_offset, frame_len, mfcc_dec_bits, float(preempha), _p(tw), _p(rev), rev.size, _p(rt),
+                                          _p(x), n, step, _p(out), _p(lm))
+            if r != 0:
+                raise RuntimeError("f32ref_compute failed")
+        return out, lm
 
 
 def mfcc_f32_ref():

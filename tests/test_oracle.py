@@ -179,3 +179,22 @@ def test_net_restatement_on_the_shipped_graph(cnn_golden):
     for got, key in zip(out["acts"], ("conv1", "pool1", "conv2", "pool2", "conv3", "conv4", "dense", "softmax")):
         assert np.array_equal(got, cnn_golden[key].reshape(n, -1)), key
     assert np.array_equal(out["argmax"], cnn_golden["argmax"].ravel())
+
+
+def test_variant_d_restatement_against_the_reference_made_fixture(oracle_mod):
+    """tests/golden/mfccf32_golden.npz: variant D as the reference's own mfcc_compute + CMSIS float transform compute it
+    (tests/golden/gen_fixtures_f32.py, reference object code). The restatement that checks the GPU must reproduce it without the
+    reference at hand: int8 equal but for rounding-boundary values, log-mel within 1e-3 clear of the float32 rounding floor, within that floor elsewhere."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mfccf32_golden.npz"))
+    x = g["audio"]
+    for i, bar in ((0, 0.999), (1, 0.98), (2, 0.999)):
+        nf, off, flen, bits, pre, hop = g["cfg%d" % i]
+        m = oracle_mod.MfccF32(int(nf), int(off), int(flen), int(bits), float(pre))
+        pi, _, plm = m(x, frame_step=int(hop))
+        ri, rlm = g["mfcc%d" % i], g["logmel%d" % i]
+        assert pi.shape == ri.shape
+        d = np.abs(ri.astype(int) - pi.astype(int))
+        assert d.max() <= 1 and (d == 0).mean() >= bar, (i, d.max(), (d == 0).mean())
+        from test_oracle_refpins import _variant_d_logmel_close
+        _variant_d_logmel_close(x, int(hop), int(flen), float(pre), rlm, plm)

@@ -165,3 +165,57 @@ def test_variant_d_mel_filterbank_equals_the_reference(built_lib, oracle_mod, f3
         assert np.array_equal(np.array(t.dct, dtype=np.float32)[:13 * 26].view(np.uint32), f32ref.dct_matrix(26, 13).ravel().view(np.uint32))
         _, ofirst, olast, ow = oracle_mod.MfccF32(frame_len=frame_len).tables()
         assert np.array_equal(ofirst, first) and np.array_equal(olast, last) and np.array_equal(ow.view(np.uint32), w.view(np.uint32))
+
+
+def _variant_d_logmel_close(x, hop, N, preempha, rlm, plm):
+    """Two float32 transforms agree to ~1e-6 of a frame's LARGEST bin: band energies are compared in the linear domain against
+    that floor (1e-4 of the largest bin: a band below it holds each FFT's own rounding noise), and in the log domain (1e-3)
+    wherever the band stands clear of it."""
+    n = rlm.shape[0]
+    fr = np.stack([x[i * hop:i * hop + N] for i in range(n)]).astype(np.float64)
+    pre = np.concatenate([fr[:, :1], (fr[:, 1:] - preempha * fr[:, :-1]) / 32768.0], axis=1)      # mfcc.c:180-186 (sample 0 is not scaled)
+    spec_max = np.abs(np.fft.rfft(pre * (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(N) / N)), 1 << int(np.ceil(np.log2(N))))).max(axis=1)
+    er, ep = np.exp(rlm.astype(np.float64)), np.exp(plm.astype(np.float64))
+    assert np.all(np.abs(er - ep) <= 1e-4 * spec_max[:, None] + 1e-30)
+    clear = ep > 1e-2 * spec_max[:, None]
+    assert clear.mean() > 0.3 and np.abs(rlm - plm)[clear].max() <= 1e-3, np.abs(rlm - plm)[clear].max()
+
+
+def test_variant_d_transform_tables_come_from_the_reference_routine(oracle_mod, f32ref):
+    """arm_common_tables.c is absent from the snapshot; the reference's compiled arm_cfft_f32 / arm_rfft_fast_f32 take their
+    tables by pointer. MfccF32Ref.fft_tables regenerates the twiddle VALUES by formula and reads the bit-reversal permutation
+    off the routine itself (it asserts, through the compiled routines, that the result is the DFT to float32 accuracy). The
+    swap list it derives is exactly as long as ARM's table for 256 points (ARMBITREVINDEXTABLE_256_TABLE_LENGTH = 440,
+    arm_common_tables.h), and the fixture keeps it."""
+    tw, rev, rt = f32ref.fft_tables(512)
+    assert tw.shape == (256, 2) and rt.shape == (256, 2) and rev.size == 440 and rev.max() < 8 * 256 and (rev % 8 == 0).all()
+    assert rt[0, 0] == 0.0 and rt[0, 1] == 1.0                      # (sin, cos): the layout the real-transform stage reads
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mfccf32_golden.npz"))
+    assert np.array_equal(g["bitrev_swaps_256"], rev)
+    for n in (64, 128, 256, 1024, 2048):                            # every length mfcc_create can ask for in practice
+        f32ref.fft_tables(n)
+
+
+def test_variant_d_restatement_equals_the_reference_mfcc_compute(oracle_mod, f32ref):
+    """oracle/mfcc_f32_ref.c (the checker of the GPU's variant D) against the reference's own mfcc_compute + CMSIS transform,
+    compiled from the reference (oracle/_ref/libmfcc_f32_ref.so), frame by frame on fresh seeded audio -- noise from 3 LSB to
+    clipping, a tone, silence, both rails. int8 outputs: equal but for values that sit on a rounding boundary (<= 0.1 % of them,
+    off by one); log-mel energies: within 1e-3 wherever the band stands clear of the frame's float32 rounding floor, within
+    that floor (linear domain) elsewhere, silence bit-identical (the FLT_MIN branch)."""
+    rng = np.random.default_rng(123)
+    parts = [np.clip(rng.normal(0, s, 150 * 256), -32768, 32767) for s in (3, 100, 3000, 20000, 50000)]
+    t = np.arange(150 * 256)
+    parts += [6000 * np.sin(2 * np.pi * 1000 * t / 16000) + 20 * rng.normal(size=t.size), np.zeros(40 * 256), np.full(40 * 256, 32767.0), np.full(40 * 256, -32768.0)]
+    x = np.concatenate(parts).astype(np.int16)
+    for cfg, bar in ((dict(), 0.999), (dict(num_mfcc_features=13, feature_offset=0, frame_len=480, mfcc_dec_bits=7, preempha=0.0), 0.98),
+                     (dict(num_mfcc_features=10, feature_offset=1, frame_len=400, mfcc_dec_bits=5, preempha=0.95), 0.999)):
+        hop = cfg.get("frame_len", 512) // 2
+        ri, rlm = f32ref.compute(x, frame_step=hop, **cfg)
+        pi, _, plm = oracle_mod.MfccF32(**cfg)(x, frame_step=hop)
+        assert ri.shape == pi.shape and ri.shape[0] > 1000
+        d = np.abs(ri.astype(int) - pi.astype(int))
+        assert d.max() <= 1 and (d == 0).mean() >= bar, (cfg, d.max(), (d == 0).mean())
+        _variant_d_logmel_close(x, hop, cfg.get("frame_len", 512), cfg.get("preempha", 0.97), rlm, plm)
+        quiet = (x[: (ri.shape[0] - 1) * hop + cfg.get("frame_len", 512)].reshape(-1)[None] == 0).all()  # (never: the stream is mixed)
+        sil = np.array([not x[i * hop:i * hop + cfg.get("frame_len", 512)].any() for i in range(ri.shape[0])])
+        assert sil.sum() > 10 and np.array_equal(rlm[sil].view(np.uint32), plm[sil].view(np.uint32)) and not quiet
