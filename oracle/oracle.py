@@ -235,7 +235,8 @@ class MfccF32Ref:
         cf = ctypes.c_float
         self._f = _open_lazy(F32_REF_SO, {"f32ref_dct_matrix": (ci, [ci, ci, vp]), "f32ref_mel_fbank": (ci, [ci, vp, vp, vp, ci]),
                                           "f32ref_cfft": (None, [vp, vp, ci, ci, vp, ci]), "f32ref_rfft": (None, [vp, vp, ci, vp, ci, vp, vp]),
-                                          "f32ref_compute": (ci, [ci, ci, ci, ci, cf, vp, vp, ci, vp, vp, ci, ci, vp, vp])})
+                                          "f32ref_compute": (ci, [ci, ci, ci, ci, cf, vp, vp, ci, vp, vp, ci, ci, vp, vp]),
+                                          "f32ref_max": (None, [vp, ci, vp, vp])})
         self._tables = {}
 
     def dct_matrix(self, input_length, coefficient_count):
@@ -252,6 +253,13 @@ class MfccF32Ref:
             raise RuntimeError("create_mel_fbank failed")
         return first, last, w[:n].copy()
 
+
+    def arm_max(self, v):
+        """CMSIS-DSP's arm_max_f32 compiled from the reference: (maximum, index of its FIRST occurrence)."""
+        v = np.ascontiguousarray(v, np.float32)
+        val, idx = np.zeros(1, np.float32), np.zeros(1, np.uint32)
+        self._f["f32ref_max"](_p(v), int(v.size), _p(val), _p(idx))
+        return float(val[0]), int(idx[0])
 
     # ---- the CMSIS-DSP float transform of the reference, on tables regenerated here (arm_common_tables.c is absent from the snapshot)
     def fft_tables(self, n):

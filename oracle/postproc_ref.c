@@ -3,7 +3,8 @@
  * continuous mode (firmware/src/app.c:332-356): cast to float, moving average in DOUBLE arithmetic (the constants
  * NET_OUT_MOVING_AVG_ALPHA and 1.0 are doubles, app.c:38,342) rounded to float on the store, arm_max_f32 (first
  * maximum: CMSIS StatisticsFunctions/arm_max_f32.c scalar branch, strict `out < maxVal`), TRUE_THRESHOLD compare.
- * Parity: restated from the source; the reference holds no vectors for it (parity unpinned).
+ * Parity: restated from the source; the reference holds no vectors for it (parity unpinned) -- except the class choice, which is
+ * checked against CMSIS-DSP's arm_max_f32 compiled from the reference (tests/test_oracle_refpins.py).
  */
 #include <stdint.h>
 

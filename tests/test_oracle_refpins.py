@@ -219,3 +219,23 @@ def test_variant_d_restatement_equals_the_reference_mfcc_compute(oracle_mod, f32
         quiet = (x[: (ri.shape[0] - 1) * hop + cfg.get("frame_len", 512)].reshape(-1)[None] == 0).all()  # (never: the stream is mixed)
         sil = np.array([not x[i * hop:i * hop + cfg.get("frame_len", 512)].any() for i in range(ri.shape[0])])
         assert sil.sum() > 10 and np.array_equal(rlm[sil].view(np.uint32), plm[sil].view(np.uint32)) and not quiet
+
+
+def test_output_filter_class_choice_equals_arm_max_f32(oracle_mod, f32ref):
+    """The firmware's output post-processing (app.c:332-356) is inline code in a file that cannot be built here, except for its
+    one library call: arm_max_f32 picks the class. The restatement's choice (oracle_output_filter: `likely`) against CMSIS-DSP's
+    arm_max_f32 compiled from the reference, on the filtered states of random softmax sequences -- exact ties included (the state
+    starts as zeros; two classes fed the same values): always the FIRST maximum."""
+    rng = np.random.default_rng(17)
+    soft = rng.integers(-128, 128, (3000, 10)).astype(np.int8)
+    soft[:5] = 0                                                     # the state starts as zeros: ten equal values
+    soft[5:65] = -50
+    soft[5:65, 2] = 100
+    soft[5:65, 5] = 100                                              # two classes fed identically from equal states: exact ties
+    filt, likely, spotted, _ = oracle_mod.output_filter(soft)
+    ties = 0
+    for i in range(soft.shape[0]):
+        val, idx = f32ref.arm_max(filt[i])
+        assert idx == likely[i] and val == filt[i, likely[i]], i
+        ties += int((filt[i] == val).sum() > 1)
+    assert ties >= 20
