@@ -85,3 +85,18 @@ def test_plan_walk_on_random_graphs(built_lib):
         gap += any(m.mm and m.pp not in (0, plan.PL[i].in_c, plan.PL[i].in_n) for i, m in enumerate(plan.ML))
         small += any(r.small for r in plan.R)
     assert toep >= 5 and small >= 5, (toep, gap, small)      # the sample reaches the planner's special forms
+
+
+def test_planners_under_address_and_ub_sanitizers(built_lib):
+    """tools/verify/asan_planner.sh: the library's host C (planners, kws_conv model parser, the table builders of all four MFCC
+    variants) rebuilt with gcc -fsanitize=address,undefined and run on the shipped graph, the seven fixture graphs, 80 random
+    graphs, truncated copies of every blob (exact-size heap copies: all refused) and every filterbank / frame length the tests
+    configure: no report. (Sanitizers exist on the CPU build only.)"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(HERE)
+    r = subprocess.run(["bash", os.path.join(root, "tools", "verify", "asan_planner.sh"), "80"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "no sanitizer report" in r.stdout and "ERROR" not in r.stderr
