@@ -320,7 +320,17 @@ static int specialize(edison_ctx *ctx, int cache_only)
 	{
 		int r = try_hipcc ? compile_with_hipcc(ctx, spec, &code, &code_bytes) : 0;
 		if (r == 1) state = 1;
-		if (r == 0 && try_rtc && (r = compile_with_hiprtc(ctx, spec, &code, &code_bytes)) == 1) state = 3;
+		if (r != 1 && try_rtc)
+		{
+			/* no hipcc here, or it ran and failed (a read-only TMPDIR, a broken installation): the in-process compiler is the second
+			 * chance; if that fails too, the FIRST compiler's message is the one worth keeping */
+			char first[sizeof(ctx->err)];
+			memcpy(first, ctx->err, sizeof(first));
+			const int r1 = r;
+			r = compile_with_hiprtc(ctx, spec, &code, &code_bytes);
+			if (r == 1) state = 3;
+			else if (r1 == -1) { memcpy(ctx->err, first, sizeof(first)); r = -1; }
+		}
 		if (r != 1)
 		{
 			free(spec);

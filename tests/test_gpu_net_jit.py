@@ -151,3 +151,18 @@ def test_both_compilers_give_the_same_answers(built_lib, jit_cache, monkeypatch,
     out = c.net(x)
     assert np.array_equal(out["logits"], ref["logits"]) and np.array_equal(out["argmax"], ref["argmax"])
     c.close()
+
+
+def test_a_failing_hipcc_falls_through_to_hiprtc(built_lib, jit_cache, monkeypatch, tmp_path):
+    """EDISON_HIPCC pointing at a program that exits non-zero: edison_net_specialize still succeeds, through hipRTC (state 3)."""
+    from edison_amd.context import Context
+    bad = tmp_path / "hipcc"
+    bad.write_text("#!/bin/sh\necho broken compiler >&2\nexit 3\n")
+    bad.chmod(0o755)
+    monkeypatch.setenv("EDISON_HIPCC", str(bad))
+    c = Context(0, model_path=None)
+    c.load_weights_h(_header("tiny_conv"))
+    assert c.net_specialize() == 3
+    x = np.zeros((5, c.net_info()["in_h"] * c.net_info()["in_w"] * c.net_info()["in_c"]), np.int8)
+    c.net(x)
+    c.close()
