@@ -226,9 +226,13 @@ __device__ __forceinline__ void emm_keep(v4i (&x)[N])
 	for (int i = 0; i < N; i++) asm volatile("" : "+v"(x[i]));
 }
 
-template <int NW, int R, int C, bool FRAG_LDS>
+/* MODE (a graph's own kernel only, where n_ks is a constant and the k-loop is unrolled): 1 = the B fragments of all k-steps are
+ * already in registers (res[s * C * NW + c]: a layer with one column-tile group and several row-tile groups fetched them once
+ * for all of those), 2 = the A fragments are (res[s * R + r]: one row-tile group, several column-tile groups). */
+#define EMM_RES_MAX 8
+template <int NW, int R, int C, bool FRAG_LDS, int MODE>
 __device__ __forceinline__ void emm_chain(const lds8 *(&fl)[R], const int8_t *(&fg)[R], const lds8 *kp /* &koff[h] */, const lds8 *(&bw)[NW * C],
-                                          int n_ks, const lds8 *(&sp)[R], v16i (&acc)[R * C])
+                                          int n_ks, const lds8 *(&sp)[R], v16i (&acc)[R * C], const v4i (&res)[EMM_RES_MAX])
 {
 	constexpr int NT = R * C * NW, NB = C * NW; /* accumulator tile (r, c, w) is aw[(r * C + c) * NW + w] */
 	v16i aw[NT];
@@ -244,13 +248,13 @@ __device__ __forceinline__ void emm_chain(const lds8 *(&fl)[R], const int8_t *(&
 	int k_cur = EMM_LD32(kp), k_nxt = EMM_LD32(kp + 8 * (last < 1 ? last : 1));
 	v4i a[R], b[NB];
 #pragma unroll
-	for (int r = 0; r < R; r++) a[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], 0);
+	for (int r = 0; r < R; r++) a[r] = MODE == 2 ? res[r] : emm_load_a<FRAG_LDS>(fl[r], fg[r], 0);
 #pragma unroll
-	for (int c = 0; c < NB; c++) b[c] = EMM_LD128(bw[c] + k_cur);
+	for (int c = 0; c < NB; c++) b[c] = MODE == 1 ? res[c] : EMM_LD128(bw[c] + k_cur);
 	for (int s = 0; s < ((EMM_SKIP & 2) ? 0 : n_ks); s++)
 	{
 		const int s2 = s + 2 < n_ks ? s + 2 : last;
-		const int k3 = EMM_LD32(kp + 8 * s2);
+		const int k3 = MODE == 1 ? 0 : EMM_LD32(kp + 8 * s2);
 		v4i an[R], bn[NB];
 #pragma unroll
 		for (int r = 0; r < R; r++) an[r] = a[r];
@@ -259,9 +263,9 @@ __device__ __forceinline__ void emm_chain(const lds8 *(&fl)[R], const int8_t *(&
 		if (s + 1 < n_ks) /* uniform: the last step has nothing to fetch (a k-step's operands are R + C * NW KB of LDS traffic) */
 		{
 #pragma unroll
-			for (int r = 0; r < R; r++) an[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], s + 1);
+			for (int r = 0; r < R; r++) an[r] = MODE == 2 ? res[(s + 1) * R + r] : emm_load_a<FRAG_LDS>(fl[r], fg[r], s + 1);
 #pragma unroll
-			for (int c = 0; c < NB; c++) bn[c] = EMM_LD128(bw[c] + k_nxt);
+			for (int c = 0; c < NB; c++) bn[c] = MODE == 1 ? res[(s + 1) * NB + c] : EMM_LD128(bw[c] + k_nxt);
 		}
 #pragma unroll
 		for (int t = 0; t < NT; t++) aw[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t / (C * NW)], b[t % (C * NW)], aw[t], 0, 0, 0);
@@ -324,6 +328,22 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 		const int wy = A.pw == 2 ? w >> 1 : w, wx = A.pw == 2 ? w & 1 : 0;
 		wdelta[w] = (wy * A.sh) * A.pitch_y + wx * A.pitch_x;
 	}
+	/* A graph's own kernel keeps what every group of a layer would fetch again in registers (all uniform, constants there):
+	 * the A fragments when the layer is ONE group of row tiles walked over several column-tile groups, the B fragments when it
+	 * is one column-tile group under several row-tile groups (a Toeplitz first layer: 3 of its 4.5 KB of operands per group). */
+	const bool a_res = EMM_SPEC && !(EMM_SKIP & 2) && A.n_rt <= R && n_ct > C && A.n_ks * R <= EMM_RES_MAX;
+	const bool b_res = EMM_SPEC && !(EMM_SKIP & 2) && !a_res && A.n_rt > R && n_ct <= C && A.n_ks * C * NW <= EMM_RES_MAX;
+	v4i res[EMM_RES_MAX];
+	if (a_res)
+	{
+#pragma unroll
+		for (int r = 0; r < R; r++)
+		{
+			const int rt = r < A.n_rt ? r : A.n_rt - 1;
+			for (int s_ = 0; s_ < A.n_ks; s_++)
+				res[s_ * R + r] = emm_load_a<FRAG_LDS>(A.fragl + rt * A.n_ks * 1024 + lane * 16, A.fragg + (size_t)rt * A.n_ks * 1024 + lane * 16, s_);
+		}
+	}
 	/* groups of R row tiles x C column tiles; a group's spare slots (past the last row / column tile) repeat the last tile
 	 * and store nothing */
 	for (int ct0 = 0; ct0 < n_ct; ct0 += C)
@@ -357,6 +377,15 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 			for (int w = 0; w < NW; w++) bw[c * NW + w] = A.bsrc + b * A.img + boff + wdelta[w];
 			op[c] = A.o + b * A.o_img + ooff;
 		}
+		if (b_res)
+		{
+			for (int s_ = 0; s_ < A.n_ks; s_++)
+			{
+				const int k_ = EMM_LD32(A.koff + 4 * h + 8 * s_);
+#pragma unroll
+				for (int c = 0; c < NW * C; c++) res[s_ * NW * C + c] = EMM_LD128(bw[c] + k_);
+			}
+		}
 		for (int rt0 = 0; rt0 < A.n_rt; rt0 += R)
 		{
 			EMM_ST_T(43)
@@ -373,7 +402,9 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 			}
 			v16i acc[R * C];
 			EMM_ST_T(40)
-			emm_chain<NW, R, C, FRAG_LDS>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc);
+			if (a_res) emm_chain<NW, R, C, FRAG_LDS, EMM_SPEC ? 2 : 0>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc, res);
+			else if (b_res) emm_chain<NW, R, C, FRAG_LDS, EMM_SPEC ? 1 : 0>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc, res);
+			else emm_chain<NW, R, C, FRAG_LDS, 0>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc, res);
 			EMM_ST_T(41)
 			/* lane (column, h) holds rows 32 rt + 8 g + 4 h .. +3 in registers 4g..4g+3. Requantise, clamp, pack four rows
 			 * into a dword with three v_perm_b32; whole groups of 8 rows past C_out are skipped under a uniform branch, the
