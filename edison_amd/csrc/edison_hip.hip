@@ -272,13 +272,23 @@ extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t b
 	free(plan); free(h); free(hm); free(w); free(seeds);
 	if (r != EDISON_OK) return r;
 	ED_HIP(ctx, e);
-	/* The graph's own kernel (edison_net_jit.hip). By default a load takes it from the on-disk cache when an earlier
-	 * edison_net_specialize() of the same graph left it there (a file read, no compiler); EDISON_NET_SPECIALIZE=1: every load
-	 * compiles it when it is not cached; =0: never by itself. A failure there is not a failed load: the graph runs on the
-	 * general kernel and edison_net_specialized() says so. */
-	static const int auto_spec = getenv("EDISON_NET_SPECIALIZE") ? atoi(getenv("EDISON_NET_SPECIALIZE")) : -1;
-	if (auto_spec > 0 && ctx->mm_ok) { const int keep = edison_net_specialize(ctx); (void)keep; }
-	else if (auto_spec < 0 && ctx->mm_ok) ed_ctx_net_spec_from_cache(ctx);
+	/* The graph's own kernel (edison_net_jit.hip) is part of loading a model, as model_compile() is part of it in NNoM: a graph
+	 * that would run on the general matrix-core kernel gets its own -- from the on-disk cache, else compiled now (~1 s, once per
+	 * graph and machine). The kws_conv graph runs on its hand-written kernel and only looks into the cache. EDISON_NET_SPECIALIZE
+	 * (read at every load): 0 = never by itself, 1 = compile for every graph, cache = only look into the cache. A failure here
+	 * (no compiler on the machine, ...) is not a failed load: the graph runs on the general kernel, edison_net_specialized() says so. */
+	const char *env_spec = getenv("EDISON_NET_SPECIALIZE");
+	const int never = env_spec && !strcmp(env_spec, "0"), always = env_spec && !strcmp(env_spec, "1"), cache_only = env_spec && !strcmp(env_spec, "cache");
+	if (ctx->mm_ok && !never)
+	{
+		if (always || (!cache_only && !ctx->fast_model))
+		{
+			char keep[sizeof(ctx->err)];
+			memcpy(keep, ctx->err, sizeof(keep));
+			if (edison_net_specialize(ctx) != EDISON_OK) memcpy(ctx->err, keep, sizeof(keep));
+		}
+		else ed_ctx_net_spec_from_cache(ctx);
+	}
 	return EDISON_OK;
 }
 

@@ -135,9 +135,10 @@ int edison_net_layers(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *acts
  * runs the general kernel for this load (edison_net_batch*, and edison_cnn_* / edison_kws_* / edison_stream_* for graphs
  * other than kws_conv) runs the graph's own: same arithmetic, bit-identical outputs, kws_conv graph 198 -> 236 M inputs/s.
  * EDISON_E_NO_IMPL: the graph has no matrix-core plan, or neither hipcc nor libhiprtc.so is installed -- the graph stays on the general
- * kernel. A later edison_model_load* of the same graph (this process or another) takes the cached code object by itself (a
- * file read, no compiler); EDISON_NET_SPECIALIZE=1 in the environment makes every load compile what is not cached, =0 keeps
- * loads from looking.
+ * kernel. edison_model_load* does this by itself for every graph that would otherwise run on the general kernel (the
+ * kws_conv graph has its hand-written kernel and only looks into the cache): ~1 s at the first load of a graph on a machine,
+ * a file read afterwards. EDISON_NET_SPECIALIZE in the environment, read at every load: 0 = loads never do it, cache = loads
+ * only look into the cache, 1 = every load compiles, kws_conv included; a failure there never fails the load.
  * edison_net_specialized: 0 general kernel; own kernel: 1 compiled just now by a hipcc child process (the installed ROCm's
  * compiler, tried first), 2 taken from the cache, 3 compiled just now by hipRTC in this process (EDISON_JIT_COMPILER=hipcc|hiprtc
  * picks one).

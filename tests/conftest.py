@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# Which network kernel a test exercises is the test's choice, not the model load's: loads do not compile / fetch a graph's own
+# kernel by themselves here (the library's default does, for every graph but kws_conv); tests/test_gpu_net_jit.py asks for it.
+os.environ.setdefault("EDISON_NET_SPECIALIZE", "0")
 
 
 def pytest_configure(config):

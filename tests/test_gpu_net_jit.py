@@ -28,6 +28,7 @@ def _blob(name):
 def jit_cache(tmp_path, monkeypatch):
     d = tmp_path / "jit"
     monkeypatch.setenv("EDISON_JIT_CACHE", str(d))
+    monkeypatch.setenv("EDISON_NET_SPECIALIZE", "cache")           # loads only LOOK into the cache: the tests decide when to compile
     return d
 
 
@@ -101,6 +102,7 @@ def test_reload_drops_the_own_kernel_and_other_entry_points_use_it(built_lib, ji
 def test_cache_can_be_switched_off_and_damaged_entries_are_replaced(built_lib, tmp_path, monkeypatch):
     from edison_amd.context import Context
     monkeypatch.setenv("EDISON_JIT_CACHE", "off")
+    monkeypatch.setenv("EDISON_NET_SPECIALIZE", "cache")
     c = Context(0, model_path=None)
     c.load_weights_h(_header("tiny_conv"))
     assert c.net_specialize() in (1, 3)
@@ -165,4 +167,32 @@ def test_a_failing_hipcc_falls_through_to_hiprtc(built_lib, jit_cache, monkeypat
     assert c.net_specialize() == 3
     x = np.zeros((5, c.net_info()["in_h"] * c.net_info()["in_w"] * c.net_info()["in_c"]), np.int8)
     c.net(x)
+    c.close()
+
+
+def test_a_model_load_compiles_the_own_kernel_by_itself(built_lib, tmp_path, monkeypatch, oracle_mod, oracle_model):
+    """The library's default (EDISON_NET_SPECIALIZE unset): loading any graph but kws_conv ends with its own kernel (compiled at the
+    first load on a machine, from the cache afterwards); kws_conv keeps its hand-written kernel and compiles nothing; =0: never."""
+    from edison_amd.context import Context
+    from oracle import net_ref
+    monkeypatch.setenv("EDISON_JIT_CACHE", str(tmp_path / "jit3"))
+    monkeypatch.delenv("EDISON_NET_SPECIALIZE", raising=False)
+    c = Context(0)                                                   # the shipped kws_conv graph
+    assert c.net_specialized() == 0 and not list((tmp_path / "jit3").glob("*.hsaco"))
+    c.load_weights_h(_header("kws_small"))
+    assert c.net_specialized() in (1, 3) and len(list((tmp_path / "jit3").glob("*.hsaco"))) == 1
+    info = c.net_info()
+    x = np.random.default_rng(8).integers(-128, 128, (1501, info["in_h"] * info["in_w"] * info["in_c"])).astype(np.int8)
+    ref = net_ref.run(_blob("kws_small"), x)
+    out = c.net(x)
+    assert np.array_equal(out["logits"], ref["logits"]) and np.array_equal(out["argmax"], ref["argmax"])
+    c.close()
+    c = Context(0, model_path=None)
+    c.load_weights_h(_header("kws_small"))
+    assert c.net_specialized() == 2                                  # the second load on this "machine": a file read
+    c.close()
+    monkeypatch.setenv("EDISON_NET_SPECIALIZE", "0")
+    c = Context(0, model_path=None)
+    c.load_weights_h(_header("kws_small"))
+    assert c.net_specialized() == 0
     c.close()

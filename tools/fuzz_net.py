@@ -58,6 +58,7 @@ def main():
     n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
     own = len(sys.argv) > 3
+    os.environ["EDISON_NET_SPECIALIZE"] = "0"   # loads leave the graph on the general kernel; `own` asks for the own kernel explicitly
     if own:
         os.environ["EDISON_JIT_CACHE"] = "off"
     ctx = Context(0, model_path=None)
