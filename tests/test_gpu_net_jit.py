@@ -196,3 +196,34 @@ def test_a_model_load_compiles_the_own_kernel_by_itself(built_lib, tmp_path, mon
     c.load_weights_h(_header("kws_small"))
     assert c.net_specialized() == 0
     c.close()
+
+
+def test_kws_and_stream_entry_points_on_another_graphs_own_kernel(built_lib, jit_cache):
+    """A 31 x 13 x 1 -> 10 softmax graph that is NOT kws_conv serves edison_kws_* and edison_stream_* through the network kernels:
+    windows 13 bytes apart (the stream's sliding window), 403-byte utterances, one-window host pushes. Same answers from the
+    general kernel and from the graph's own."""
+    from edison_amd.context import Context
+    from edison_amd.stream import Stream
+    rng = np.random.default_rng(21)
+    audio = np.clip(rng.normal(0, 3000, 9 * 31744), -32768, 32767).astype(np.int16)
+    hop, chunk, n_push = 512, 5, 11
+    st_audio = np.clip(rng.normal(0, 2500, n_push * chunk * hop), -32768, 32767).astype(np.int16)
+    res = {}
+    for own in (False, True):
+        c = Context(0, model_path=None)
+        c.load_weights_h(_header("kws_small"))
+        if own:
+            assert c.net_specialize() in (1, 2, 3)
+        assert (c.net_specialized() != 0) == own
+        r = c.kws(audio, n_utt=9, utt_stride=31744)
+        st = Stream(c, hop=hop, chunk_frames=chunk)
+        outs = [st.push(st_audio[i * chunk * hop:(i + 1) * chunk * hop]) for i in range(n_push)]
+        st.close()
+        st1 = Stream(c, hop=hop, chunk_frames=1)
+        one = [st1.push(st_audio[i * hop:(i + 1) * hop]) for i in range(40)]
+        st1.close()
+        res[own] = (r["logits"], r["softmax"], r["argmax"], np.concatenate([o["softmax"] for o in outs]), np.concatenate([o["softmax"] for o in one]))
+        c.close()
+    for a, b in zip(res[False], res[True]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[True][3][:40], res[True][4])           # chunk 5 and chunk 1 streams see the same windows
