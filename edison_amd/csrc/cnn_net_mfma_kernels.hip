@@ -563,7 +563,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
                                              const int8_t *__restrict__ frag, const int32_t *__restrict__ seeds,
                                              const int8_t *__restrict__ in, int64_t n, int64_t in_stride,
                                              int8_t *__restrict__ logits, int8_t *__restrict__ softmax,
-                                             int32_t *__restrict__ argmax)
+                                             int32_t *__restrict__ argmax, unsigned *done_flag, unsigned done_seq)
 {
 	extern __shared__ __attribute__((aligned(16))) int8_t emm_lds_generic[];
 	lds8 *emm_lds = (lds8 *)emm_lds_generic;
@@ -903,6 +903,14 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 		EMM_ST(46)
 		emm_sync(); /* the next batch overwrites both buffers */
 	}
+	/* one-window launches of the microphone path (edison_stream.hip): the only wave that had work tells the host itself, in
+	 * host-mapped memory behind a system-scope fence, as ed_cnn_mfma_kernel does (a command-processor write behind the kernel
+	 * costs ~2 us more). The launcher passes a flag only when the launch is one workgroup whose first wave takes every input. */
+	if (done_flag && blockIdx.x == 0 && wave == 0)
+	{
+		__threadfence_system();
+		if (lane == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 #if EMM_STAMP
 	if (g_emm_dbg && threadIdx.x == 0 && blockIdx.x == 0) for (int i = 0; i < 48; i++) g_emm_dbg[i] = stamp_[i];
 #endif
@@ -914,9 +922,9 @@ extern "C" __global__ __launch_bounds__(64 * EMM_SM_waves) void ed_net_mfma_spec
                                                                              const int8_t *__restrict__ frag, const int32_t *__restrict__ seeds,
                                                                              const int8_t *__restrict__ in, int64_t n, int64_t in_stride,
                                                                              int8_t *__restrict__ logits, int8_t *__restrict__ softmax,
-                                                                             int32_t *__restrict__ argmax)
+                                                                             int32_t *__restrict__ argmax, unsigned *done_flag, unsigned done_seq)
 {
-	emm_net_body<EMM_SM_frag_mode == 2>(P, M, frag, seeds, in, n, in_stride, logits, softmax, argmax);
+	emm_net_body<EMM_SM_frag_mode == 2>(P, M, frag, seeds, in, n, in_stride, logits, softmax, argmax, done_flag, done_seq);
 }
 #else
 template <bool FRAG_LDS>
@@ -924,15 +932,17 @@ __global__ __launch_bounds__(EMM_MAX_THREADS) void ed_net_mfma_kernel(const ed_n
                                                                  const int8_t *__restrict__ frag, const int32_t *__restrict__ seeds,
                                                                  const int8_t *__restrict__ in, int64_t n, int64_t in_stride,
                                                                  int8_t *__restrict__ logits, int8_t *__restrict__ softmax,
-                                                                 int32_t *__restrict__ argmax)
+                                                                 int32_t *__restrict__ argmax, unsigned *done_flag, unsigned done_seq)
 {
-	emm_net_body<FRAG_LDS>(P, M, frag, seeds, in, n, in_stride, logits, softmax, argmax);
+	emm_net_body<FRAG_LDS>(P, M, frag, seeds, in, n, in_stride, logits, softmax, argmax, done_flag, done_seq);
 }
 
 extern "C" int ed_launch_net_mfma(const ed_net_plan_t *dev_plan, const ed_mm_plan_t *dev_mm, const int8_t *dev_frag,
                                   const int32_t *dev_seeds, int lds_bytes, int batch, int waves, int frag_mode, const int8_t *in, int64_t n,
-                                  int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu, hipStream_t stream)
+                                  int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu, hipStream_t stream,
+                                  unsigned *done_flag, unsigned done_seq, int *flag_written)
 {
+	if (flag_written) *flag_written = 0;
 	if (n <= 0) return 0;
 	if (waves < 1 || waves > EMM_MAX_THREADS / 64) return (int)hipErrorInvalidValue;
 	int per_cu = (160 * 1024) / (lds_bytes + 256);
@@ -954,8 +964,12 @@ extern "C" int ed_launch_net_mfma(const ed_net_plan_t *dev_plan, const ed_mm_pla
 		if (e != hipSuccess) return (int)e;
 		max_lds_set[resident] = lds_bytes;
 	}
+	/* done_flag: written by the kernel itself when the launch is one workgroup whose first wave takes every input */
+	unsigned *flag = (done_flag && n <= batch) ? done_flag : nullptr;
 	void *kargs[] = {(void *)&dev_plan, (void *)&dev_mm, (void *)&dev_frag, (void *)&dev_seeds, (void *)&in, (void *)&n, (void *)&in_stride,
-	                 (void *)&logits, (void *)&softmax, (void *)&argmax};
-	return (int)hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(64 * waves), kargs, (size_t)lds_bytes, stream);
+	                 (void *)&logits, (void *)&softmax, (void *)&argmax, (void *)&flag, (void *)&done_seq};
+	const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(64 * waves), kargs, (size_t)lds_bytes, stream);
+	if (e == hipSuccess && flag && flag_written) *flag_written = 1;
+	return (int)e;
 }
 #endif /* !EMM_JIT */

@@ -29,7 +29,8 @@ extern "C" int ed_launch_net(const ed_net_plan_t *dev_plan, const int8_t *dev_w,
 
 extern "C" int ed_launch_net_mfma(const ed_net_plan_t *dev_plan, const ed_mm_plan_t *dev_mm, const int8_t *dev_frag,
                                   const int32_t *dev_seeds, int lds_bytes, int batch, int waves, int frag_mode, const int8_t *in, int64_t n,
-                                  int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu, hipStream_t stream);
+                                  int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax, int n_cu, hipStream_t stream,
+                                  unsigned *done_flag, unsigned done_seq, int *flag_written);
 
 extern "C" int ed_launch_mfcc_q15(const ed_mfcc_q15_args_t *args, const ed_q15_tables_t *dev_tab, int mel_nlo, int mel_nhi,
                                   int stages, int n_cu, hipStream_t stream);
@@ -124,7 +125,10 @@ int ed_ctx_net_launch_on(edison_ctx *ctx, hipStream_t stream, const int8_t *in, 
                          int32_t *argmax);
 /* edison_net_jit.hip */
 int ed_ctx_net_spec_launch(edison_ctx *ctx, hipStream_t stream, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax,
-                           int32_t *argmax);
+                           int32_t *argmax, unsigned *done_flag, unsigned done_seq, int *flag_written);
+/* ed_ctx_net_launch_on with the completion flag of the one-window microphone push (see ed_ctx_kws_cnn_launch_flag) */
+int ed_ctx_net_launch_flag(edison_ctx *ctx, hipStream_t stream, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax,
+                           int32_t *argmax, unsigned *flag, unsigned seq, int *flag_written);
 void ed_ctx_net_spec_drop(edison_ctx *ctx);
 void ed_ctx_net_spec_from_cache(edison_ctx *ctx);
 int ed_ctx_mfcc_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,

@@ -467,12 +467,19 @@ int ed_ctx_net_launch(edison_ctx *ctx, const int8_t *in, int64_t n, int64_t in_s
 
 int ed_ctx_net_launch_on(edison_ctx *ctx, hipStream_t stream, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax)
 {
+	return ed_ctx_net_launch_flag(ctx, stream, in, n, in_stride, logits, softmax, argmax, NULL, 0, NULL);
+}
+
+int ed_ctx_net_launch_flag(edison_ctx *ctx, hipStream_t stream, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax, int32_t *argmax,
+                           unsigned *flag, unsigned seq, int *flag_written)
+{
+	if (flag_written) *flag_written = 0;
 	static const int no_mfma = getenv("EDISON_NET_NO_MFMA") ? atoi(getenv("EDISON_NET_NO_MFMA")) : 0;
 	if (ctx->mm_ok && !no_mfma && ctx->spec_fn && ctx->spec_epoch == ctx->model_epoch)
-		return ed_ctx_net_spec_launch(ctx, stream, in, n, in_stride, logits, softmax, argmax);
+		return ed_ctx_net_spec_launch(ctx, stream, in, n, in_stride, logits, softmax, argmax, flag, seq, flag_written);
 	if (ctx->mm_ok && !no_mfma)
 		return ed_launch_net_mfma(ctx->d_net_plan, ctx->d_mm_plan, ctx->d_mm_frag, ctx->d_mm_seeds, ctx->mm_lds, ctx->mm_batch, ctx->mm_waves, ctx->mm_frag_mode, in, n,
-		                          in_stride, logits, softmax, argmax, ctx->n_cu, stream);
+		                          in_stride, logits, softmax, argmax, ctx->n_cu, stream, flag, seq, flag_written);
 	return ed_launch_net(ctx->d_net_plan, ctx->d_net_w, ctx->d_net_seeds, ctx->net.lds_bytes, in, n, in_stride, logits, softmax, argmax,
 	                     NULL, ctx->n_cu, stream);
 }
@@ -498,7 +505,7 @@ int ed_ctx_kws_cnn_launch_flag(edison_ctx *ctx, hipStream_t stream, const int8_t
 		return set_err(ctx, EDISON_E_SIZE, "the loaded model is not a 31x13x1 -> 10 softmax classifier; use edison_net_batch");
 	int e = ctx->fast_model
 	            ? ed_launch_cnn_mfma_flag(ctx->d_model_mfma, feat, n_utt, feat_stride, logits, softmax, argmax, ctx->n_cu, stream, flag, seq, flag_written)
-	            : ed_ctx_net_launch_on(ctx, stream, feat, n_utt, feat_stride, logits, softmax, argmax);
+	            : ed_ctx_net_launch_flag(ctx, stream, feat, n_utt, feat_stride, logits, softmax, argmax, flag, seq, flag_written);
 	if (e != 0)
 	{
 		snprintf(ctx->err, sizeof(ctx->err), "CNN kernel launch failed: %s", hipGetErrorString((hipError_t)e));

@@ -383,8 +383,9 @@ extern "C" int edison_net_specialized(edison_ctx *ctx)
 
 /* the launch of the graph's own kernel: grid and LDS exactly as ed_launch_net_mfma's */
 int ed_ctx_net_spec_launch(edison_ctx *ctx, hipStream_t stream, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax,
-                           int32_t *argmax)
+                           int32_t *argmax, unsigned *done_flag, unsigned done_seq, int *flag_written)
 {
+	if (flag_written) *flag_written = 0;
 	if (n <= 0) return 0;
 	const int waves = ctx->mm_waves;
 	int per_cu = (160 * 1024) / (ctx->mm_lds + 256);
@@ -397,7 +398,10 @@ int ed_ctx_net_spec_launch(edison_ctx *ctx, hipStream_t stream, const int8_t *in
 	const ed_mm_plan_t *dev_mm = ctx->d_mm_plan;
 	const int8_t *dev_frag = ctx->d_mm_frag;
 	const int32_t *dev_seeds = ctx->d_mm_seeds;
+	unsigned *flag = (done_flag && n <= ctx->mm_batch) ? done_flag : NULL; /* one workgroup whose first wave takes every input */
 	void *kargs[] = {(void *)&dev_plan, (void *)&dev_mm, (void *)&dev_frag, (void *)&dev_seeds, (void *)&in, (void *)&n, (void *)&in_stride,
-	                 (void *)&logits, (void *)&softmax, (void *)&argmax};
-	return (int)hipModuleLaunchKernel((hipFunction_t)ctx->spec_fn, (unsigned)blocks, 1, 1, (unsigned)(64 * waves), 1, 1, (unsigned)ctx->mm_lds, stream, kargs, NULL);
+	                 (void *)&logits, (void *)&softmax, (void *)&argmax, (void *)&flag, (void *)&done_seq};
+	const hipError_t e = hipModuleLaunchKernel((hipFunction_t)ctx->spec_fn, (unsigned)blocks, 1, 1, (unsigned)(64 * waves), 1, 1, (unsigned)ctx->mm_lds, stream, kargs, NULL);
+	if (e == hipSuccess && flag && flag_written) *flag_written = 1;
+	return (int)e;
 }
