@@ -23,6 +23,7 @@
 #include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <spawn.h>
 #include <stdlib.h>
 #include <string.h>
@@ -210,8 +211,16 @@ static int compile_with_hipcc(edison_ctx *ctx, const char *spec, char **code, si
 		if (sp != 0) snprintf(ctx->err, sizeof(ctx->err), "edison_net_specialize: cannot start %s: %s", hipcc, strerror(sp));
 		else
 		{
-			while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
-			*code = WIFEXITED(status) && WEXITSTATUS(status) == 0 ? read_file(out, code_bytes) : NULL;
+			/* a compiler that does not come back must not hang a model load: two minutes (it needs ~1 s), then it is stopped by PID */
+			int done = 0;
+			for (int waited_ms = 0; !done; waited_ms += 5)
+			{
+				const pid_t w = waitpid(pid, &status, WNOHANG);
+				if (w == pid || (w < 0 && errno != EINTR)) done = 1;
+				else if (waited_ms > 120000) { (void)kill(pid, SIGKILL); while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {} status = -1; done = 1; }
+				else usleep(5000);
+			}
+			*code = status != -1 && WIFEXITED(status) && WEXITSTATUS(status) == 0 ? read_file(out, code_bytes) : NULL;
 			if (*code) r = 1;
 			else
 			{
