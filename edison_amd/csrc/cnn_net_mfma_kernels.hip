@@ -9,12 +9,20 @@
  *
  * Scheme (ed_mm_plan_t, model_net_mm.c): implicit GEMM D[out_channel][pixel] with k = (kernel row, 16-byte chunk of the
  * row's contiguous kw * C_in input bytes). The consumer layer dictates how its input lies in LDS: zero-padded so that no
- * tap test is needed; the producing layer's epilogue writes straight into that layout. Layers whose C_in is not a
- * multiple of 16 read from an expanded copy with one aligned record per (input row, output x). A WAVEFRONT takes `batch`
- * inputs through the whole layer list by itself in its own slice of LDS -- no workgroup barrier in the loop (a wave's DS
- * instructions are serviced in order); the first version ran the workgroup in lockstep phases and spent a third of its
- * time in barriers. The weight fragments stay in LDS for the whole launch, shared by the waves, when they fit beside the
- * activation slices (mode 2), else they stream from L2 (0).
+ * tap test is needed (and, where C_in is an even multiple of 16, with a 16-byte gap behind every pixel that takes neighbouring
+ * pixels off the same LDS banks); the producing layer's epilogue writes straight into that layout. Layers whose C_in is not a
+ * multiple of 16 read from an expanded copy with one aligned record per (input row, output x) -- unless the image is narrow
+ * (a spectrogram, C_in = 1): then the layer runs in ROW-TOEPLITZ form, the GEMM's rows being (output x, output channel)
+ * pairs and k running over whole zero-padded input rows, with no copy at all. A WAVEFRONT takes `batch` inputs through the
+ * whole layer list by itself in its own slice of LDS (a layer's input images at one end of the activation region, its output
+ * images at the other) -- no workgroup barrier in the loop (a wave's DS instructions are serviced in order); the first
+ * version ran the workgroup in lockstep phases and spent a third of its time in barriers. The weight fragments stay in LDS
+ * for the whole launch, shared by the waves, when they fit beside the activation slices (mode 2), else they stream from L2 (0).
+ *
+ * Two builds of this text. The GENERAL kernel (ed_net_mfma_kernel) reads all of the above from the plans at run time. A
+ * graph's OWN kernel (ed_net_mfma_spec: -DEMM_SPEC, compiled at run time by edison_net_specialize with the plan in front of
+ * the text as constants, net_spec.c) has the layer loop and the k-loops unrolled, every choice below made by the compiler,
+ * fragments that several tile groups share held in registers: 2-3 x the general kernel, bit-identical.
  *
  * What the wave does NOT work out itself (the kernel is bound by vector-instruction issue, so every index calculation
  * counts): the planner ships one run record per layer (ed_mm_run_t, two scalar loads), the place of every input byte in
