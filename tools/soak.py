@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Soak run on the GPU box: minutes of create / load / specialise / run / stream / destroy cycles with every result checked
+(oracle on samples, determinism on the large batches), device-memory and host-RSS watched for leaks.
+usage (box): tools/soak.py [seconds=300]     prints a progress line every ~20 s and a summary"""
+import os
+import resource
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from edison_amd import _lib, nnom_import  # noqa: E402
+from edison_amd.context import Context  # noqa: E402
+from edison_amd.stream import Stream  # noqa: E402
+from oracle import net_ref, oracle  # noqa: E402
+
+NAMES = ["same_stride", "odd_no_softmax", "square", "kws_small", "tiny_conv", "low_latency_small", "even_same"]
+
+
+def blob_of(name):
+    with open(os.path.join(ROOT, "tests", "golden", "alt_models", name + ".h")) as f:
+        shape, layers = nnom_import.parse_weights_h(f.read())
+    return nnom_import.build_blob(shape, layers)
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    os.environ["EDISON_JIT_CACHE"] = "/tmp/edison_soak_jit"
+    rng = np.random.default_rng(2026)
+    oracle.build()
+    model = oracle.Model()
+    blobs = {n: blob_of(n) for n in NAMES}
+    dev = torch.device("cuda", 0)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    t0 = last = time.time()
+    n = dict(contexts=0, loads=0, own_kernels=0, net_inputs=0, stream_pushes=0, kws_utterances=0, mfcc_frames=0, q15_frames=0)
+    big = Context(0)
+    big.use_torch_stream()
+    audio = torch.from_numpy(np.clip(rng.normal(0, 3000, 16384 * 31744), -32768, 32767).astype(np.int16)).to(dev)
+    ref_am = None
+    while time.time() - t0 < seconds:
+        # ---- A: a fresh context, a random graph, general kernel then its own, both against the restatement
+        name = NAMES[int(rng.integers(0, len(NAMES)))]
+        os.environ["EDISON_NET_SPECIALIZE"] = "0"
+        c = Context(0, model_path=None)
+        c.load_model_bytes(blobs[name])
+        info = c.net_info()
+        x = rng.integers(-128, 128, (int(rng.integers(1, 700)), info["in_h"] * info["in_w"] * info["in_c"])).astype(np.int8)
+        want = net_ref.run(blobs[name], x[:48])
+        g = c.net(x)
+        assert np.array_equal(g["logits"][:48], want["logits"]) and np.array_equal(g["argmax"][:48], want["argmax"]), ("general", name)
+        c.net_specialize()
+        o = c.net(x)
+        assert np.array_equal(o["logits"], g["logits"]) and np.array_equal(o["argmax"], g["argmax"]), ("own", name)
+        c.close()
+        n["contexts"] += 1; n["loads"] += 1; n["own_kernels"] += 1; n["net_inputs"] += 2 * x.shape[0]
+        # ---- B: a stream of random shape on the shipped model, host and device pushes, against the batch path + oracle CNN
+        hop, chunk = 2 * int(rng.integers(64, 513)), int(rng.choice([1, 2, 5, 16, 64]))
+        n_push = int(rng.integers(3, 20))
+        a = np.clip(rng.normal(0, 2500, n_push * chunk * hop), -32768, 32767).astype(np.int16)
+        st = Stream(big, hop=hop, chunk_frames=chunk)
+        soft = []
+        a_dev = torch.from_numpy(a).to(dev)
+        for i in range(n_push):
+            sl = slice(i * chunk * hop, (i + 1) * chunk * hop)
+            if rng.integers(0, 2):
+                so = torch.zeros((chunk, 10), dtype=torch.int8, device=dev)
+                st.push_t(a_dev[sl], softmax=so)
+                torch.cuda.synchronize()
+                soft.append(so.cpu().numpy())
+            else:
+                soft.append(st.push(a[sl])["softmax"])
+        st.close()
+        full = np.concatenate([np.zeros(1024 - hop, np.int16), a])
+        _, feat = big.mfcc(full, n_frames=n_push * chunk, frame_step=hop, variant=_lib.MFCC_B, n_coef=13, want_feat=True)
+        padded = np.concatenate([np.zeros((30, 13), np.int8), feat])
+        win = np.stack([padded[i:i + 31].reshape(-1) for i in range(n_push * chunk)])
+        assert np.array_equal(np.concatenate(soft), oracle.cnn(model, win, n_threads=4)["softmax"]), ("stream", hop, chunk)
+        n["stream_pushes"] += n_push
+        # ---- C: a large KWS batch, twice the same answer; float and Q15 MFCC launches
+        nu = 16384
+        feat_t = torch.zeros((nu, 403), dtype=torch.int8, device=dev)
+        lo = torch.zeros((nu, 10), dtype=torch.int8, device=dev)
+        am = torch.zeros((nu,), dtype=torch.int32, device=dev)
+        big.kws_t(audio, nu, 31744, feat=feat_t, logits=lo, argmax=am, q15=bool(n["contexts"] & 1))
+        torch.cuda.synchronize()
+        key = (bool(n["contexts"] & 1), am.cpu().numpy().copy())
+        if ref_am is None:
+            ref_am = {}
+        if key[0] in ref_am:
+            assert np.array_equal(ref_am[key[0]], key[1]), "a KWS batch changed its answer"
+        ref_am[key[0]] = key[1]
+        n["kws_utterances"] += nu
+        n["q15_frames" if key[0] else "mfcc_frames"] += nu * 31
+        if time.time() - last > 20:
+            last = time.time()
+            torch.cuda.synchronize()
+            print("t=%4.0f s  %s  device memory in use +%.1f MB  host RSS +%.1f MB" % (
+                last - t0, n, (free0 - torch.cuda.mem_get_info()[0]) / 1e6, (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - rss0) / 1e3), flush=True)
+    big.close()
+    del audio, feat_t, lo, am, a_dev
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    grown = (free0 - torch.cuda.mem_get_info()[0]) / 1e6
+    print("soak: %.0f s, %s; every result checked; device memory after close: %+.1f MB against the start, host RSS peak +%.1f MB" % (
+        time.time() - t0, n, grown, (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - rss0) / 1e3))
+    # the ROCm runtime keeps pools it grew once (graph memory, kernel-argument and scratch pools, torch's context): what counts is
+    # that the figure printed every 20 s stops moving, which the progress lines show; a leak per cycle would be GBs by now
+    assert grown < 512, "device memory grew over the run"
+
+
+if __name__ == "__main__":
+    main()
