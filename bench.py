@@ -228,7 +228,7 @@ def stream_bench(ctx, dev):
                     realtime_factor=round(n_push * chunk * hop / 16000.0 / dt, 1))
     lat_direct = latency(False)
     lat_direct["what"] = ("host push of 512 new samples -> softmax/argmax on the host through the Python mirror (edison_amd/stream.py): MFCC + CNN "
-                          "launched directly against host-mapped buffers, no copy nodes, completion by a command-processor write the host spins on")
+                          "in ONE launch (ed_kws1_kernel) against host-mapped buffers, no copy nodes, completion flag written by the kernel, the host spins on it")
     lat_graph = latency(True)
     lat_graph["what"] = "the same push with launch_mode = EDISON_STREAM_LAUNCH_GRAPH: one hipGraphLaunch of the captured upload + MFCC + CNN + shift + download nodes, then hipStreamSynchronize"
     thr_direct, thr_graph = throughput(False), throughput(True)

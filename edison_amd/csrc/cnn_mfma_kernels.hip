@@ -182,13 +182,40 @@ __device__ __forceinline__ uint4 edm_fix_row(uint4 d, int64_t base, int nb, int6
 	return u < nb ? d : make_uint4(0, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_mfma_model_t *__restrict__ model,
-                                                                 const int8_t *__restrict__ feat, int64_t n_utt,
-                                                                 int64_t feat_stride, int8_t *__restrict__ logits,
-                                                                 int8_t *__restrict__ softmax,
-                                                                 int32_t *__restrict__ argmax, unsigned *done_flag, unsigned done_seq)
+/* The kernel in two parts, so that ed_kws1_kernel (below) can put the MFCC of the newest frame between them:
+ * edm_prologue requests the first group's feature rows and stages the weights (no barrier), edm_main waits at the workgroup
+ * barrier and does everything else. row30: null, or 16 bytes in LDS that hold the LAST feature row of the (single) utterance
+ * at +3 -- where edm_load_rows would have fetched it from, had it been in memory already. */
+__device__ __forceinline__ void edm_prologue(const ed_cnn_mfma_model_t *__restrict__ model, const int8_t *__restrict__ feat, int64_t n_utt,
+                                             int64_t feat_stride, unsigned char *smem, uint4 (&rows)[2])
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	unsigned *queue = reinterpret_cast<unsigned *>(smem + sizeof(ed_cnn_mfma_model_t) + EDM_WAVES * EDM_WAVE_LDS);
+	const int64_t n_groups = (n_utt + EDM_G - 1) / EDM_G;
+	const int64_t g_lo = (int64_t)blockIdx.x * n_groups / gridDim.x;
+	const uint32_t cnt = (uint32_t)((int64_t)(blockIdx.x + 1) * n_groups / gridDim.x - g_lo);
+	/* The feature rows of the wave's first group go in flight BEFORE the weight staging (round 3): loads return in issue order,
+	 * so the staging below waits behind them anyway, and for a one-window push of the microphone path these rows come over
+	 * the bus from host-mapped memory (~2 us) -- with the rows requested after the staging barrier the two latencies added up.
+	 * The rows of a wave's next group are fetched while it works on the current one. */
+	if ((uint32_t)wave < cnt)
+	{
+		const int64_t b0 = (g_lo + wave) * EDM_G;
+		edm_load_rows(feat, feat_stride, b0, (int)((n_utt - b0) < EDM_G ? (n_utt - b0) : EDM_G), n_utt, lane, rows);
+	}
+	{ /* stage the weight fragments once per workgroup */
+		const v4i *src = reinterpret_cast<const v4i *>(model);
+		v4i *dst = reinterpret_cast<v4i *>(smem);
+		for (int i = threadIdx.x; i < (int)(sizeof(ed_cnn_mfma_model_t) / 16); i += EDM_THREADS) dst[i] = src[i];
+		if (threadIdx.x == 0) *queue = EDM_WAVES;
+	}
+}
+
+__device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_t n_utt, int64_t feat_stride, int8_t *__restrict__ logits,
+                                         int8_t *__restrict__ softmax, int32_t *__restrict__ argmax, unsigned *done_flag, unsigned done_seq,
+                                         unsigned char *smem, uint4 (&rows)[2], const unsigned char *row30)
+{
 	const ed_cnn_mfma_model_t &M = *reinterpret_cast<const ed_cnn_mfma_model_t *>(smem);
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -202,23 +229,13 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 	const int64_t n_groups = (n_utt + EDM_G - 1) / EDM_G;
 	const int64_t g_lo = (int64_t)blockIdx.x * n_groups / gridDim.x;
 	const uint32_t cnt = (uint32_t)((int64_t)(blockIdx.x + 1) * n_groups / gridDim.x - g_lo);
-	/* The feature rows of the wave's first group go in flight BEFORE the weight staging (round 3): loads return in issue order,
-	 * so the staging below waits behind them anyway, and for a one-window push of the microphone path these rows come over
-	 * the bus from host-mapped memory (~2 us) -- with the rows requested after the staging barrier the two latencies added up.
-	 * The rows of a wave's next group are fetched while it works on the current one. */
-	uint4 rows[2];
-	if ((uint32_t)wave < cnt)
-	{
-		const int64_t b0 = (g_lo + wave) * EDM_G;
-		edm_load_rows(feat, feat_stride, b0, (int)((n_utt - b0) < EDM_G ? (n_utt - b0) : EDM_G), n_utt, lane, rows);
-	}
-	{ /* stage the weight fragments once per workgroup */
-		const v4i *src = reinterpret_cast<const v4i *>(model);
-		v4i *dst = reinterpret_cast<v4i *>(smem);
-		for (int i = threadIdx.x; i < (int)(sizeof(ed_cnn_mfma_model_t) / 16); i += EDM_THREADS) dst[i] = src[i];
-		if (threadIdx.x == 0) *queue = EDM_WAVES;
-	}
 	__syncthreads();
+	if (row30 && wave == 0 && lane == ED_IN_H - 1) /* uniform: ed_kws1_kernel -- the newest row was computed by this very wave a moment ago */
+	{
+		uint4 d;
+		__builtin_memcpy(&d, row30, 16);
+		rows[0] = d;
+	}
 	const int col = lane & 31, h = lane >> 5;
 	const unsigned char *afrag = reinterpret_cast<const unsigned char *>(&M) + lane * 16;
 	const int a1_off = (int)offsetof(ed_cnn_mfma_model_t, a1), a2_off = (int)offsetof(ed_cnn_mfma_model_t, a2);
@@ -580,6 +597,54 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 	}
 }
 
+__global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_mfma_model_t *__restrict__ model,
+                                                                 const int8_t *__restrict__ feat, int64_t n_utt,
+                                                                 int64_t feat_stride, int8_t *__restrict__ logits,
+                                                                 int8_t *__restrict__ softmax,
+                                                                 int32_t *__restrict__ argmax, unsigned *done_flag, unsigned done_seq)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint4 rows[2];
+	edm_prologue(model, feat, n_utt, feat_stride, smem, rows);
+	edm_main(feat, n_utt, feat_stride, logits, softmax, argmax, done_flag, done_seq, smem, rows, nullptr);
+}
+
+/*
+ * ed_kws1_kernel -- the one-frame microphone push in ONE launch (edison_stream.hip, host-mapped path, chunk 1): the MFCC of
+ * the newest frame (variant A / B: ed_mfcc1_body, the one-frame kernel's body -- bit-identical to the batch kernel, which the
+ * tests hold against it) and the CNN on the 31-row window it completes. Two dependent launches cost 8.7 us where one costs
+ * 6.0 (tools/ubench/launch_lat), the host issues one launch instead of two, and the CNN's weight staging and its reads of
+ * the 30 older rows (over the bus, from the host's ring) overlap the MFCC instead of following it.
+ *   all waves: request the older rows (wave 0) and stage the CNN weights; stage the MFCC tables; workgroup barrier
+ *   wave 0:    MFCC of the frame -> the row to the host's ring (history for the next pushes) and to 16 bytes of LDS
+ *   all waves: the CNN kernel's barrier; wave 0 runs the one group, takes the newest row from LDS, writes outputs + flag
+ * LDS: the CNN kernel's layout; the MFCC tables and wave 0's transform buffer live in the activation slots of waves 1..,
+ * which have no group in a one-utterance launch.
+ */
+#include "mfcc_one_frame.h"
+#define EDK1_MFCC_FLOATS(NLO, NHI) (ED_FIXTAB_FLOATS + ((NLO) + (NHI)) * 256 + ED_TWTAB_FLOATS + ED_XBUF_FLOATS)
+
+template <int NLO, int NHI>
+__global__ __launch_bounds__(EDM_THREADS) void ed_kws1_kernel(ed_mfcc_args_t margs, const ed_mfcc_tables_t *__restrict__ tab,
+                                                             const ed_cnn_mfma_model_t *__restrict__ model, const int8_t *__restrict__ feat,
+                                                             int8_t *__restrict__ logits, int8_t *__restrict__ softmax, int32_t *__restrict__ argmax,
+                                                             unsigned *done_flag, unsigned done_seq)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	static_assert(sizeof(float) * EDK1_MFCC_FLOATS(NLO, NHI) + 16 <= (size_t)(EDM_WAVES - 1) * EDM_WAVE_LDS, "the MFCC tables do not fit the idle waves' slots");
+	float *msmem = reinterpret_cast<float *>(smem + sizeof(ed_cnn_mfma_model_t) + EDM_WAVE_LDS); /* behind wave 0's activations */
+	unsigned char *row30 = reinterpret_cast<unsigned char *>(msmem + EDK1_MFCC_FLOATS(NLO, NHI));
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	uint4 rows[2];
+	edm_prologue(model, feat, 1, ED_IN_W, smem, rows);
+	/* one frame, taken by wave 0 (every wave passes wave index 0 for the LDS layout: only wave 0's transform buffer exists) */
+	ed_mfcc1_body<false, false, NLO, NHI>(margs, tab, msmem, 0, wave == 0 ? 0u : 1u, 1u << 30, reinterpret_cast<int8_t *>(row30) + 3);
+	edm_main(feat, 1, ED_IN_W, logits, softmax, argmax, done_flag, done_seq, smem, rows, row30);
+}
+
+extern "C" int ed_launch_kws1(const ed_mfcc_args_t *margs, const ed_mfcc_tables_t *dev_tab, const ed_cnn_mfma_model_t *dev_model, const int8_t *feat,
+                              int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *done_flag, unsigned done_seq, hipStream_t stream);
+
 /* "the kernel's dynamic-LDS limit has been raised" is a property of the function ON A DEVICE: one flag per device, so that
  * two contexts on different GPUs of one process both get it */
 static int g_cnn_mfma_ready[16] = {0};
@@ -624,4 +689,30 @@ extern "C" int ed_launch_cnn_mfma_flag(const ed_cnn_mfma_model_t *dev_model, con
 	                   feat_stride, logits, softmax, argmax, flag, done_seq);
 	if (flag && flag_written) *flag_written = 1;
 	return (int)hipGetLastError();
+}
+
+
+/* margs: ONE frame (n_frames = 1) with its int8 row going to margs->feat (the host's ring); feat: the 31-row window that row
+ * completes (its last row is read from LDS, not from there). done_flag / done_seq as in ed_launch_cnn_mfma_flag: always written. */
+extern "C" int ed_launch_kws1(const ed_mfcc_args_t *margs, const ed_mfcc_tables_t *dev_tab, const ed_cnn_mfma_model_t *dev_model, const int8_t *feat,
+                              int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *done_flag, unsigned done_seq, hipStream_t stream)
+{
+	if (margs->n_frames != 1 || !margs->feat || !done_flag) return (int)hipErrorInvalidValue;
+	const size_t lds = sizeof(ed_cnn_mfma_model_t) + (size_t)EDM_WAVES * EDM_WAVE_LDS + 16 /* queue */;
+	const bool narrow = margs->mel_NLO == 2 && margs->mel_NHI == 5;
+	if (!narrow && !(margs->mel_NLO == ED_MEL_NLO_MAX && margs->mel_NHI == ED_MEL_NHI_MAX)) return (int)hipErrorInvalidValue;
+	const void *fn = narrow ? (const void *)ed_kws1_kernel<2, 5> : (const void *)ed_kws1_kernel<ED_MEL_NLO_MAX, ED_MEL_NHI_MAX>;
+	static int ready[16][2];
+	int dev_ = 0;
+	(void)hipGetDevice(&dev_);
+	dev_ &= 15;
+	if (!ready[dev_][narrow])
+	{
+		hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return (int)e;
+		ready[dev_][narrow] = 1;
+	}
+	void *kargs[] = {(void *)margs, (void *)&dev_tab, (void *)&dev_model, (void *)&feat, (void *)&logits, (void *)&softmax, (void *)&argmax,
+	                 (void *)&done_flag, (void *)&done_seq};
+	return (int)hipLaunchKernel(fn, dim3(1), dim3(EDM_THREADS), kargs, lds, stream);
 }

@@ -381,6 +381,33 @@ int ed_ctx_mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, 
 	                   stages, fft, spec, mel, logmel);
 }
 
+/* The one-frame microphone push in ONE launch (ed_kws1_kernel, cnn_mfma_kernels.hip): the MFCC (variant A / B, 13 int8 features,
+ * scale 1) of the 1024 samples at `audio`, its row written to feat_row (the host's ring) and completing the 31-row window at
+ * `window`, the kws_conv CNN on that window, outputs and the completion flag written by the kernel. EDISON_E_NO_IMPL when the
+ * loaded model / variant has no such kernel (the caller launches the two kernels one after the other then). */
+int ed_ctx_kws1_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int variant, int8_t *feat_row, const int8_t *window,
+                          int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *flag, unsigned seq)
+{
+	const int v = variant & 0xff;
+	if (!ctx || !audio || !feat_row || !window || !flag) return EDISON_E_ARGUMENT;
+	if (!ctx->have_model || !ctx->fast_model || (v != EDISON_MFCC_A && v != EDISON_MFCC_B)) return EDISON_E_NO_IMPL;
+	ed_mfcc_args_t a;
+	memset(&a, 0, sizeof(a));
+	a.audio = audio; a.n_frames = 1; a.frames_per_group = 1; a.group_stride = 0; a.frame_step = EDISON_FRAME_LEN;
+	a.n_coef = EDISON_NUM_MFCC; a.use_log = (variant & EDISON_MFCC_USE_LOG) ? 1 : 0;
+	a.mel_NLO = ctx->mel_NLO[v];
+	a.mel_NHI = ctx->mel_NHI[v];
+	a.feat = feat_row; a.feat_scale = 1.0f;
+	const int e = ed_launch_kws1(&a, ctx->d_tab[v], ctx->d_model_mfma, window, logits, softmax, argmax, flag, seq, stream);
+	if (e == (int)hipErrorInvalidValue) return EDISON_E_NO_IMPL;
+	if (e != 0)
+	{
+		snprintf(ctx->err, sizeof(ctx->err), "one-frame KWS kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+		return EDISON_E_RUNTIME;
+	}
+	return EDISON_OK;
+}
+
 /* the same on an explicit stream (edison_stream.hip: a stream object launches on its private stream without touching
  * ctx->stream, which another thread's call on the context may be reading) */
 int ed_ctx_mfcc_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int64_t n_frames, int64_t fpg, int64_t group_stride,
