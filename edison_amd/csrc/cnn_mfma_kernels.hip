@@ -638,7 +638,9 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_kws1_kernel(ed_mfcc_args_t mar
 	uint4 rows[2];
 	edm_prologue(model, feat, 1, ED_IN_W, smem, rows);
 	/* one frame, taken by wave 0 (every wave passes wave index 0 for the LDS layout: only wave 0's transform buffer exists) */
-	ed_mfcc1_body<false, false, NLO, NHI>(margs, tab, msmem, 0, wave == 0 ? 0u : 1u, 1u << 30, reinterpret_cast<int8_t *>(row30) + 3);
+	/* (ALIGNED: the launcher checks that the frame starts on a dword -- the host's ring does -- so the samples come over the bus
+	 * as 8 dword loads per lane instead of 16 halfword loads) */
+	ed_mfcc1_body<false, true, NLO, NHI>(margs, tab, msmem, 0, wave == 0 ? 0u : 1u, 1u << 30, reinterpret_cast<int8_t *>(row30) + 3);
 	edm_main(feat, 1, ED_IN_W, logits, softmax, argmax, done_flag, done_seq, smem, rows, row30);
 }
 
@@ -697,7 +699,7 @@ extern "C" int ed_launch_cnn_mfma_flag(const ed_cnn_mfma_model_t *dev_model, con
 extern "C" int ed_launch_kws1(const ed_mfcc_args_t *margs, const ed_mfcc_tables_t *dev_tab, const ed_cnn_mfma_model_t *dev_model, const int8_t *feat,
                               int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *done_flag, unsigned done_seq, hipStream_t stream)
 {
-	if (margs->n_frames != 1 || !margs->feat || !done_flag) return (int)hipErrorInvalidValue;
+	if (margs->n_frames != 1 || !margs->feat || !done_flag || (reinterpret_cast<uintptr_t>(margs->audio) & 3)) return (int)hipErrorInvalidValue;
 	const size_t lds = sizeof(ed_cnn_mfma_model_t) + (size_t)EDM_WAVES * EDM_WAVE_LDS + 16 /* queue */;
 	const bool narrow = margs->mel_NLO == 2 && margs->mel_NHI == 5;
 	if (!narrow && !(margs->mel_NLO == ED_MEL_NLO_MAX && margs->mel_NHI == ED_MEL_NHI_MAX)) return (int)hipErrorInvalidValue;
