@@ -695,11 +695,12 @@ extern "C" int ed_launch_cnn_mfma_flag(const ed_cnn_mfma_model_t *dev_model, con
 
 
 /* margs: ONE frame (n_frames = 1) with its int8 row going to margs->feat (the host's ring); feat: the 31-row window that row
- * completes (its last row is read from LDS, not from there). done_flag / done_seq as in ed_launch_cnn_mfma_flag: always written. */
+ * completes (its last row is read from LDS, not from there). done_flag / done_seq as in ed_launch_cnn_mfma_flag: written when given
+ * (null: something else follows on the stream, e.g. the output filter, and signals completion). */
 extern "C" int ed_launch_kws1(const ed_mfcc_args_t *margs, const ed_mfcc_tables_t *dev_tab, const ed_cnn_mfma_model_t *dev_model, const int8_t *feat,
                               int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *done_flag, unsigned done_seq, hipStream_t stream)
 {
-	if (margs->n_frames != 1 || !margs->feat || !done_flag || (reinterpret_cast<uintptr_t>(margs->audio) & 3)) return (int)hipErrorInvalidValue;
+	if (margs->n_frames != 1 || !margs->feat || (reinterpret_cast<uintptr_t>(margs->audio) & 3)) return (int)hipErrorInvalidValue;
 	const size_t lds = sizeof(ed_cnn_mfma_model_t) + (size_t)EDM_WAVES * EDM_WAVE_LDS + 16 /* queue */;
 	const bool narrow = margs->mel_NLO == 2 && margs->mel_NHI == 5;
 	if (!narrow && !(margs->mel_NLO == ED_MEL_NLO_MAX && margs->mel_NHI == ED_MEL_NHI_MAX)) return (int)hipErrorInvalidValue;

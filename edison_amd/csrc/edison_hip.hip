@@ -389,7 +389,7 @@ int ed_ctx_kws1_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *au
                           int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *flag, unsigned seq)
 {
 	const int v = variant & 0xff;
-	if (!ctx || !audio || !feat_row || !window || !flag) return EDISON_E_ARGUMENT;
+	if (!ctx || !audio || !feat_row || !window) return EDISON_E_ARGUMENT;
 	if (!ctx->have_model || !ctx->fast_model || (v != EDISON_MFCC_A && v != EDISON_MFCC_B)) return EDISON_E_NO_IMPL;
 	ed_mfcc_args_t a;
 	memset(&a, 0, sizeof(a));

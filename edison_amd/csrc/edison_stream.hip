@@ -216,22 +216,27 @@ static int enqueue_mapped_push(edison_stream *s, unsigned seq, int *flag_written
 {
 	edison_ctx *ctx = s->ctx;
 	unsigned char *o8 = s->md_out;
-	/* one frame, no output filter, float features, the kws_conv model: MFCC and CNN in ONE launch (ed_kws1_kernel) -- the
+	/* one frame, float features, the kws_conv model: MFCC and CNN in ONE launch (ed_kws1_kernel) -- the
 	 * dependent-kernel boundary, the second launch call and the wait of the CNN's weight staging behind the MFCC are gone
 	 * (C host, one box: p50 18.3 -> see DESIGN 7). EDISON_STREAM_NO_FUSED=1: A/B knob. */
 	static const int no_fused = getenv("EDISON_STREAM_NO_FUSED") ? atoi(getenv("EDISON_STREAM_NO_FUSED")) : 0;
-	if (s->chunk == 1 && !s->filter && !no_fused)
+	int r = EDISON_E_NO_IMPL;
+	if (s->chunk == 1 && !no_fused)
 	{
-		const int rf = ed_ctx_kws1_launch_on(ctx, s->own, s->md_audio, s->variant, s->md_feat + 30 * EDISON_NUM_MFCC, s->md_feat, (int8_t *)o8,
-		                                     (int8_t *)(o8 + s->off_soft), (int32_t *)(o8 + s->off_argmax), s->md_flag, seq);
-		if (rf == EDISON_OK) { *flag_written = 1; return EDISON_OK; }
-		if (rf != EDISON_E_NO_IMPL) return rf;
+		/* with the output filter behind it the kernel leaves the completion flag to whoever comes last */
+		r = ed_ctx_kws1_launch_on(ctx, s->own, s->md_audio, s->variant, s->md_feat + 30 * EDISON_NUM_MFCC, s->md_feat, (int8_t *)o8,
+		                          (int8_t *)(o8 + s->off_soft), (int32_t *)(o8 + s->off_argmax), s->filter ? NULL : s->md_flag, seq);
+		if (r == EDISON_OK && !s->filter) { *flag_written = 1; return EDISON_OK; }
+		if (r != EDISON_OK && r != EDISON_E_NO_IMPL) return r;
 	}
-	int r = ed_ctx_mfcc_launch_on(ctx, s->own, s->md_audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
-	                              s->md_feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
-	if (r == EDISON_OK)
-		r = ed_ctx_kws_cnn_launch_flag(ctx, s->own, s->md_feat, s->chunk, EDISON_NUM_MFCC, (int8_t *)o8, (int8_t *)(o8 + s->off_soft), (int32_t *)(o8 + s->off_argmax),
-		                               s->filter ? NULL : s->md_flag, seq, flag_written);
+	if (r == EDISON_E_NO_IMPL) /* no one-launch kernel for this model / variant / chunk: the two kernels one after the other */
+	{
+		r = ed_ctx_mfcc_launch_on(ctx, s->own, s->md_audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
+		                          s->md_feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
+		if (r == EDISON_OK)
+			r = ed_ctx_kws_cnn_launch_flag(ctx, s->own, s->md_feat, s->chunk, EDISON_NUM_MFCC, (int8_t *)o8, (int8_t *)(o8 + s->off_soft), (int32_t *)(o8 + s->off_argmax),
+			                               s->filter ? NULL : s->md_flag, seq, flag_written);
+	}
 	if (r == EDISON_OK && s->filter)
 	{
 		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, s->own, (const int8_t *)(o8 + s->off_soft), s->chunk, s->alpha,
