@@ -212,9 +212,10 @@ __device__ __forceinline__ void edm_prologue(const ed_cnn_mfma_model_t *__restri
 	}
 }
 
+template <bool HAS_FILTER>
 __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_t n_utt, int64_t feat_stride, int8_t *__restrict__ logits,
                                          int8_t *__restrict__ softmax, int32_t *__restrict__ argmax, unsigned *done_flag, unsigned done_seq,
-                                         unsigned char *smem, uint4 (&rows)[2], const unsigned char *row30)
+                                         unsigned char *smem, uint4 (&rows)[2], const unsigned char *row30, const ed_out_filter_t &flt, int with_filter)
 {
 	const ed_cnn_mfma_model_t &M = *reinterpret_cast<const ed_cnn_mfma_model_t *>(smem);
 	const int lane = threadIdx.x & 63;
@@ -580,6 +581,23 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 						p[3] = (uint16_t)(sw[1] >> 16); p[4] = (uint16_t)sw[2];
 					}
 					if (argmax) argmax[utt] = best;
+					if (HAS_FILTER && with_filter && utt == 0) /* ed_kws1_kernel with the stream's output filter: app.c:341-356 for this one inference, in this lane */
+					{
+						float ymax = 0.0f;
+						int imax = 0;
+#pragma unroll
+						for (int i = 0; i < 10; i++)
+						{
+							const int v = (int)(int8_t)(sw[i >> 2] >> (8 * (i & 3)));
+							/* separately rounded double multiply / add (the Cortex-M4 has no double FPU, nothing is fused) */
+							const float y = (float)__dadd_rn(__dmul_rn(flt.alpha, (double)flt.state[i]), __dmul_rn(flt.one_minus_alpha, (double)(float)v));
+							flt.state[i] = y;
+							flt.filt[i] = y;
+							if (i == 0 || ymax < y) { ymax = y; imax = i; } /* arm_max_f32: the first maximum */
+						}
+						*flt.likely = imax;
+						*flt.spotted = ((double)ymax > flt.threshold) ? imax : -1;
+					}
 				}
 			}
 			parked = 0;
@@ -606,7 +624,8 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint4 rows[2];
 	edm_prologue(model, feat, n_utt, feat_stride, smem, rows);
-	edm_main(feat, n_utt, feat_stride, logits, softmax, argmax, done_flag, done_seq, smem, rows, nullptr);
+	const ed_out_filter_t none = {0.0, 0.0, 0.0, nullptr, nullptr, nullptr, nullptr};
+	edm_main<false>(feat, n_utt, feat_stride, logits, softmax, argmax, done_flag, done_seq, smem, rows, nullptr, none, 0);
 }
 
 /*
@@ -628,7 +647,7 @@ template <int NLO, int NHI>
 __global__ __launch_bounds__(EDM_THREADS) void ed_kws1_kernel(ed_mfcc_args_t margs, const ed_mfcc_tables_t *__restrict__ tab,
                                                              const ed_cnn_mfma_model_t *__restrict__ model, const int8_t *__restrict__ feat,
                                                              int8_t *__restrict__ logits, int8_t *__restrict__ softmax, int32_t *__restrict__ argmax,
-                                                             unsigned *done_flag, unsigned done_seq)
+                                                             unsigned *done_flag, unsigned done_seq, ed_out_filter_t flt, int with_filter)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	static_assert(sizeof(float) * EDK1_MFCC_FLOATS(NLO, NHI) + 16 <= (size_t)(EDM_WAVES - 1) * EDM_WAVE_LDS, "the MFCC tables do not fit the idle waves' slots");
@@ -641,11 +660,12 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_kws1_kernel(ed_mfcc_args_t mar
 	/* (ALIGNED: the launcher checks that the frame starts on a dword -- the host's ring does -- so the samples come over the bus
 	 * as 8 dword loads per lane instead of 16 halfword loads) */
 	ed_mfcc1_body<false, true, NLO, NHI>(margs, tab, msmem, 0, wave == 0 ? 0u : 1u, 1u << 30, reinterpret_cast<int8_t *>(row30) + 3);
-	edm_main(feat, 1, ED_IN_W, logits, softmax, argmax, done_flag, done_seq, smem, rows, row30);
+	edm_main<true>(feat, 1, ED_IN_W, logits, softmax, argmax, done_flag, done_seq, smem, rows, row30, flt, with_filter);
 }
 
 extern "C" int ed_launch_kws1(const ed_mfcc_args_t *margs, const ed_mfcc_tables_t *dev_tab, const ed_cnn_mfma_model_t *dev_model, const int8_t *feat,
-                              int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *done_flag, unsigned done_seq, hipStream_t stream);
+                              int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *done_flag, unsigned done_seq, const ed_out_filter_t *filter,
+                              hipStream_t stream);
 
 /* "the kernel's dynamic-LDS limit has been raised" is a property of the function ON A DEVICE: one flag per device, so that
  * two contexts on different GPUs of one process both get it */
@@ -696,10 +716,13 @@ extern "C" int ed_launch_cnn_mfma_flag(const ed_cnn_mfma_model_t *dev_model, con
 
 /* margs: ONE frame (n_frames = 1) with its int8 row going to margs->feat (the host's ring); feat: the 31-row window that row
  * completes (its last row is read from LDS, not from there). done_flag / done_seq as in ed_launch_cnn_mfma_flag: written when given
- * (null: something else follows on the stream, e.g. the output filter, and signals completion). */
+ * (null: something else follows on the stream and signals completion). filter: null, or the stream's output filter, applied to
+ * this inference by the kernel (the softmax must be asked for then). */
 extern "C" int ed_launch_kws1(const ed_mfcc_args_t *margs, const ed_mfcc_tables_t *dev_tab, const ed_cnn_mfma_model_t *dev_model, const int8_t *feat,
-                              int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *done_flag, unsigned done_seq, hipStream_t stream)
+                              int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *done_flag, unsigned done_seq, const ed_out_filter_t *filter,
+                              hipStream_t stream)
 {
+	if (filter && (!softmax || !filter->state || !filter->filt || !filter->likely || !filter->spotted)) return (int)hipErrorInvalidValue;
 	if (margs->n_frames != 1 || !margs->feat || (reinterpret_cast<uintptr_t>(margs->audio) & 3)) return (int)hipErrorInvalidValue;
 	const size_t lds = sizeof(ed_cnn_mfma_model_t) + (size_t)EDM_WAVES * EDM_WAVE_LDS + 16 /* queue */;
 	const bool narrow = margs->mel_NLO == 2 && margs->mel_NHI == 5;
@@ -715,7 +738,10 @@ extern "C" int ed_launch_kws1(const ed_mfcc_args_t *margs, const ed_mfcc_tables_
 		if (e != hipSuccess) return (int)e;
 		ready[dev_][narrow] = 1;
 	}
+	ed_out_filter_t f = {0.0, 0.0, 0.0, nullptr, nullptr, nullptr, nullptr};
+	if (filter) f = *filter;
+	int with_filter = filter != nullptr;
 	void *kargs[] = {(void *)margs, (void *)&dev_tab, (void *)&dev_model, (void *)&feat, (void *)&logits, (void *)&softmax, (void *)&argmax,
-	                 (void *)&done_flag, (void *)&done_seq};
+	                 (void *)&done_flag, (void *)&done_seq, (void *)&f, (void *)&with_filter};
 	return (int)hipLaunchKernel(fn, dim3(1), dim3(EDM_THREADS), kargs, lds, stream);
 }

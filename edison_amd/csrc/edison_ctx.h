@@ -125,9 +125,10 @@ int ed_ctx_net_launch_on(edison_ctx *ctx, hipStream_t stream, const int8_t *in, 
                          int32_t *argmax);
 /* the one-frame microphone push in one launch (ed_kws1_kernel) */
 extern "C" int ed_launch_kws1(const ed_mfcc_args_t *margs, const ed_mfcc_tables_t *dev_tab, const ed_cnn_mfma_model_t *dev_model, const int8_t *feat,
-                              int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *done_flag, unsigned done_seq, hipStream_t stream);
+                              int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *done_flag, unsigned done_seq, const ed_out_filter_t *filter,
+                              hipStream_t stream);
 int ed_ctx_kws1_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int variant, int8_t *feat_row, const int8_t *window,
-                          int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *flag, unsigned seq);
+                          int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *flag, unsigned seq, const ed_out_filter_t *filter);
 /* edison_net_jit.hip */
 int ed_ctx_net_spec_launch(edison_ctx *ctx, hipStream_t stream, const int8_t *in, int64_t n, int64_t in_stride, int8_t *logits, int8_t *softmax,
                            int32_t *argmax, unsigned *done_flag, unsigned done_seq, int *flag_written);

@@ -386,7 +386,7 @@ int ed_ctx_mfcc_launch(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, 
  * `window`, the kws_conv CNN on that window, outputs and the completion flag written by the kernel. EDISON_E_NO_IMPL when the
  * loaded model / variant has no such kernel (the caller launches the two kernels one after the other then). */
 int ed_ctx_kws1_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *audio, int variant, int8_t *feat_row, const int8_t *window,
-                          int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *flag, unsigned seq)
+                          int8_t *logits, int8_t *softmax, int32_t *argmax, unsigned *flag, unsigned seq, const ed_out_filter_t *filter)
 {
 	const int v = variant & 0xff;
 	if (!ctx || !audio || !feat_row || !window) return EDISON_E_ARGUMENT;
@@ -398,7 +398,7 @@ int ed_ctx_kws1_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *au
 	a.mel_NLO = ctx->mel_NLO[v];
 	a.mel_NHI = ctx->mel_NHI[v];
 	a.feat = feat_row; a.feat_scale = 1.0f;
-	const int e = ed_launch_kws1(&a, ctx->d_tab[v], ctx->d_model_mfma, window, logits, softmax, argmax, flag, seq, stream);
+	const int e = ed_launch_kws1(&a, ctx->d_tab[v], ctx->d_model_mfma, window, logits, softmax, argmax, flag, seq, filter, stream);
 	if (e == (int)hipErrorInvalidValue) return EDISON_E_NO_IMPL;
 	if (e != 0)
 	{

@@ -337,6 +337,16 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 size_t ed_emit_net_spec(const ed_net_plan_t *P, const ed_mm_plan_t *M, char *out, size_t cap);
 uint64_t ed_net_spec_hash(const ed_net_plan_t *P, const ed_mm_plan_t *M);
 
+/* The firmware's output post-processing (app.c:332-356) for ONE inference, done by the one-launch microphone kernel itself
+ * (ed_kws1_kernel) behind the softmax: moving average in double arithmetic rounded to float, first maximum, threshold. */
+typedef struct {
+	double alpha, one_minus_alpha, threshold;
+	float *state;     /* [10] netOutFilt, device memory: read and written */
+	float *filt;      /* [10] out                                          */
+	int32_t *likely;  /* [1]  out                                          */
+	int32_t *spotted; /* [1]  out: the class, or -1 below the threshold    */
+} ed_out_filter_t;
+
 /* ------------------------------------------------------------------ kernel launchers (HIP side)           */
 typedef struct {
 	const int16_t *audio;

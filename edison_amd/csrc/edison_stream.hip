@@ -211,7 +211,8 @@ static int drain_q(edison_stream *s, hipStream_t q)
 }
 
 /* the device work of a push against the host-mapped buffers, on the stream's private hipStream. When the CNN is the last
- * kernel (no output filter) and runs as one group, it writes the completion sequence number itself (*flag_written = 1). */
+ * kernel (no output filter, or the one-launch kernel that filters itself) and runs as one group, it writes the completion
+ * sequence number itself (*flag_written = 1). */
 static int enqueue_mapped_push(edison_stream *s, unsigned seq, int *flag_written)
 {
 	edison_ctx *ctx = s->ctx;
@@ -223,11 +224,14 @@ static int enqueue_mapped_push(edison_stream *s, unsigned seq, int *flag_written
 	int r = EDISON_E_NO_IMPL;
 	if (s->chunk == 1 && !no_fused)
 	{
-		/* with the output filter behind it the kernel leaves the completion flag to whoever comes last */
+		/* the stream's output filter (app.c:341-356) for this one inference is done by the same kernel, behind its softmax */
+		ed_out_filter_t f;
+		f.alpha = s->alpha; f.one_minus_alpha = s->one_minus_alpha; f.threshold = s->threshold;
+		f.state = s->d_filt_state; f.filt = (float *)(o8 + s->off_filt); f.likely = (int32_t *)(o8 + s->off_likely); f.spotted = (int32_t *)(o8 + s->off_spotted);
 		r = ed_ctx_kws1_launch_on(ctx, s->own, s->md_audio, s->variant, s->md_feat + 30 * EDISON_NUM_MFCC, s->md_feat, (int8_t *)o8,
-		                          (int8_t *)(o8 + s->off_soft), (int32_t *)(o8 + s->off_argmax), s->filter ? NULL : s->md_flag, seq);
-		if (r == EDISON_OK && !s->filter) { *flag_written = 1; return EDISON_OK; }
-		if (r != EDISON_OK && r != EDISON_E_NO_IMPL) return r;
+		                          (int8_t *)(o8 + s->off_soft), (int32_t *)(o8 + s->off_argmax), s->md_flag, seq, s->filter ? &f : NULL);
+		if (r == EDISON_OK) { *flag_written = 1; return EDISON_OK; }
+		if (r != EDISON_E_NO_IMPL) return r;
 	}
 	if (r == EDISON_E_NO_IMPL) /* no one-launch kernel for this model / variant / chunk: the two kernels one after the other */
 	{

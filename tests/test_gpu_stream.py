@@ -78,6 +78,27 @@ def test_stream_q15_and_output_filter(ctx, oracle_mod, oracle_model, hop, chunk)
     st.close()
 
 
+def test_one_launch_push_filters_like_the_filter_kernel(ctx, oracle_mod):
+    """A one-frame float push is ONE launch that also applies the output filter (ed_kws1_kernel); a five-frame stream uses the
+    separate filter kernel. Over 200 frames the two and the oracle's filter (app.c:341-356) agree bit for bit, state carried."""
+    from edison_amd.stream import Stream
+    rng = np.random.default_rng(41)
+    audio = np.clip(rng.normal(0, 3000, 200 * 512), -32768, 32767).astype(np.int16)
+    s1 = Stream(ctx, hop=512, chunk_frames=1, output_filter=True)
+    s5 = Stream(ctx, hop=512, chunk_frames=5, output_filter=True)
+    o1 = [s1.push(audio[i * 512:(i + 1) * 512]) for i in range(200)]
+    o5 = [s5.push(audio[i * 2560:(i + 1) * 2560]) for i in range(40)]
+    soft = np.concatenate([o["softmax"] for o in o1])
+    assert np.array_equal(soft, np.concatenate([o["softmax"] for o in o5]))
+    filt, likely, spotted, _ = oracle_mod.output_filter(soft)
+    for outs in (o1, o5):
+        assert np.array_equal(np.concatenate([o["filtered"] for o in outs]).view(np.uint32), filt.view(np.uint32))
+        assert np.array_equal(np.concatenate([o["likely"] for o in outs]), likely)
+        assert np.array_equal(np.concatenate([o["spotted"] for o in outs]), spotted)
+    s1.close()
+    s5.close()
+
+
 def test_kws_live_replay(ctx, kws_golden, oracle_mod, oracle_model, tmp_path, capsys):
     """`kws live mcu <wav>`: the firmware's continuous loop on a file -- features (variant C), sliding window, network,
     output filter, FSM. The reference wav says "edison": the filtered wake-word output crosses the threshold, the FSM
