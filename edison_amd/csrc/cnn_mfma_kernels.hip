@@ -64,6 +64,16 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
+/* Wave priority per phase of a group (see ED2_PRIO in mfcc_kernels.hip), two bits per point: 0 input rows, 1 conv1, 2 conv2,
+ * 3 conv3, 4 conv4, 5 dense, 6 softmax / stores. Two waves per SIMD: +0.9 ... +1.1 % only. 0 = none */
+#ifndef EDM_PRIO
+#define EDM_PRIO 0x3f93
+#endif
+#if EDM_PRIO
+#define EDM_PR(pt) __builtin_amdgcn_s_setprio((EDM_PRIO >> (2 * (pt))) & 3);
+#else
+#define EDM_PR(pt)
+#endif
 __device__ __forceinline__ v4i edm_ld16(const unsigned char *p) { return *reinterpret_cast<const v4i *>(p); }
 
 __device__ __forceinline__ int edm_med3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -260,6 +270,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		const int64_t b_cur = (g_lo + idx) * EDM_G;
 		const int nb_cur = (int)((n_utt - b_cur) < EDM_G ? (n_utt - b_cur) : EDM_G);
 
+		EDM_PR(0)
 		/* ---- input: feat[u][31][13] -> in'[u][31][16] (3 zero bytes of padding per row) */
 #pragma unroll
 		for (int pass = 0; pass < 2; pass++)
@@ -280,6 +291,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		}
 		edm_wave_sync();
 
+		EDM_PR(1)
 		/* ---- conv1 5x5x1->16 + ReLU + pool(2,1): Toeplitz GEMM, 144 rows (x,o) x 80 k (5 padded input rows).
 		 *      columns = (utt, pooled row py): 4 x 13 = 52 in 2 column tiles; two accumulators = input rows 2py / 2py+1 */
 		{
@@ -348,6 +360,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		}
 		edm_wave_sync();
 
+		EDM_PR(2)
 		/* ---- conv2 3x3x16->32 + ReLU + pool(2,1): K = 9 taps x 16 ch (5 k-steps of 2 taps); columns =
 		 *      (utt, py, x): 4 x 35 = 140 in 5 column tiles; two accumulators = conv rows 2py / 2py+1 */
 		{
@@ -430,6 +443,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		}
 		edm_wave_sync();
 
+		EDM_PR(3)
 		/* ---- conv3 3x3x32->64 + ReLU: 9 k-steps (tap, 16-channel half); columns = (utt, y, x): 4 x 15 = 60 in 2
 		 *      column tiles; two accumulators = output channels 0-31 / 32-63 */
 		{
@@ -483,6 +497,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		}
 		edm_wave_sync();
 
+		EDM_PR(4)
 		/* ---- conv4 3x3x64->32 + ReLU on v_mfma_i32_16x16x64_i8: columns = (utt, x): 4 x 3 = 12 of a 16-column tile, two row
 		 *      tiles of 16 channels, 9 k-steps = taps (64 input channels each: lane quarter kq reads plane kq of c3). A
 		 *      32 x 32 x 32 tile was 5/8 padding here: 18 MFMAs of 32 cycles, now 18 of 16, and 8 accumulators to requantise
@@ -512,6 +527,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		}
 		edm_wave_sync();
 
+		EDM_PR(5)
 		/* ---- dense 96->10, same tile shape: rows = 10 logits of 16, columns = utterances (4 live), K = 96 in two k-steps of
 		 *      64: bytes 0..95 of c4 and 32 bytes behind it that meet zero weights. Lane (utt, kq) holds logits 4 kq .. +3
 		 *      (kq = 2: 8, 9 and two padding rows; kq = 3: padding only): parked as 10 int8 per utterance */
@@ -535,6 +551,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		}
 		edm_wave_sync();
 
+		EDM_PR(6)
 		/* ---- softmax + argmax + stores for the parked utterances: every EDM_PARK groups, and after the wave's last */
 		if (parked == EDM_PARK || next >= cnt)
 		{

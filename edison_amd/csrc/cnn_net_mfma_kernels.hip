@@ -176,6 +176,18 @@ __device__ __forceinline__ v4i emm_gather16(const lds8 *a, int soff, int keep)
 #ifndef EMM_PB
 /* images per wave the prefetch covers: 4 in a graph's own kernel (unused slots fold away), 2 here -- the general kernel sits at
  * its 168-register limit, two more images' registers go to scratch (+3 % at 2, measured on the planner's usual batch of 2) */
+/* A wave's priority rises with the layer it is in (the waves of a workgroup walk their own batches; see ED2_PRIO in
+ * mfcc_kernels.hip): +8.7 % on the general kernel, +8.0 % on a graph's own (kws_conv, interleaved A/B). 0 = none; 2..4: lab */
+#ifndef EMM_PRIO
+#define EMM_PRIO 1
+#endif
+#if EMM_PRIO
+#define EMM_PRIO_OF(li, n) (EMM_PRIO == 1 ? ((li) * 4) / (n) : EMM_PRIO == 2 ? (li) : EMM_PRIO == 3 ? (li) - ((n) - 4) : EMM_PRIO == 4 ? ((li) * 3) / (n) + 1 : ((li) * 8) / (n) - 2)
+#define EMM_PR(li, n) { const int p_ = EMM_PRIO_OF(li, n); if (p_ <= 0) __builtin_amdgcn_s_setprio(0); else if (p_ == 1) __builtin_amdgcn_s_setprio(1); \
+	else if (p_ == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+#else
+#define EMM_PR(li, n)
+#endif
 #define EMM_PB (EMM_SPEC ? 4 : 2)
 #endif
 __device__ __forceinline__ void emm_load_image(const int8_t *src, int in_n, int lane, uint32_t (&x)[EMM_PRE])
@@ -723,6 +735,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 			/* one wave-uniform run record per layer, worked out by the planner: two scalar loads (copies in LDS cost a
 			 * ds_read + v_readfirstlane per field; deriving it here from the layer records took a chain of dependent
 			 * scalar loads and ~100 scalar instructions per layer and input) */
+			EMM_PR(li, n_layers)
 			const ed_mm_run_t R = EMM_RUN(li);
 			if (R.kind == ED_RUN_SKIP) continue; /* a MaxPool taken in the epilogue of the layer in front of it */
 			const lds8 *a = slice + R.in_off;

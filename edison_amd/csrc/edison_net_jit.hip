@@ -7,7 +7,7 @@
  * that bookkeeping is a fifth of its time (98 spilled scalars, a dependent scalar-load chain per layer). Here the same
  * source text is compiled by hipRTC with the plans' scalars and layer records in front of it as C++ constants (net_spec.c):
  * the layer loop unrolls, every choice is made by the compiler, nothing spills. Same arithmetic, bit-identical outputs
- * (tests/test_gpu_net_jit.py); kws_conv graph: 198 -> 236 M inputs/s on one box.
+ * (tests/test_gpu_net_jit.py); kws_conv graph: 262-276 M inputs/s on the general kernel, 505-642 M on its own.
  *
  * The kernel text and the two headers it includes are compiled into the library (build.py: net_jit_sources.c). Two compilers,
  * EDISON_JIT_COMPILER=hipcc|hiprtc picks one, the default tries them in this order:
@@ -182,8 +182,12 @@ static int compile_with_hipcc(edison_ctx *ctx, const char *spec, char **code, si
 		/* device code only, a plain ELF code object (no offload bundle). -pragma-unroll-threshold: the layer loop's body holds every
 		 * tile shape until it is unrolled and the layer records become constants; LLVM's default cap on a "#pragma unroll" refuses a
 		 * body that size, and everything the specialisation is for hangs on that unroll (335 -> 589 M inputs/s on kws_conv) */
+		/* EDISON_JIT_DEFINE=NAME=VALUE: one more -D for A/B work on the kernel's knobs (tools/lab; part of the cache key) */
+		char extra[128];
+		const char *xd = getenv("EDISON_JIT_DEFINE");
+		snprintf(extra, sizeof(extra), "-D%s", xd && xd[0] ? xd : "EMM_NO_EXTRA_DEFINE=1");
 		const char *argv[] = {hipcc, "--offload-arch=gfx950", "--cuda-device-only", "--no-gpu-bundle-output", "-O3", "-std=c++17", "-fno-slp-vectorize",
-		                      "-DEMM_JIT=1", "-DEMM_SPEC=1", "-DEMM_SPEC_HEADER=\"emm_spec.h\"", "-mllvm", "-pragma-unroll-threshold=1000000", "-include", "hip/hip_runtime.h", inc, "-x", "hip", "-c", src, "-o", out, NULL};
+		                      "-DEMM_JIT=1", "-DEMM_SPEC=1", "-DEMM_SPEC_HEADER=\"emm_spec.h\"", extra, "-mllvm", "-pragma-unroll-threshold=1000000", "-include", "hip/hip_runtime.h", inc, "-x", "hip", "-c", src, "-o", out, NULL};
 		posix_spawn_file_actions_t fa;
 		posix_spawn_file_actions_init(&fa);
 		posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
@@ -304,6 +308,7 @@ static int specialize(edison_ctx *ctx, int cache_only)
 	source = fnv(source, ed_jit_src_edison_internal_h, ed_jit_src_edison_internal_h_len);
 	source = fnv(source, k_stdint_h, sizeof(k_stdint_h));
 	source = fnv(source, "pragma-unroll-threshold=1000000", 31); /* the compiler options are part of what a cache entry was made from */
+	if (getenv("EDISON_JIT_DEFINE") && getenv("EDISON_JIT_DEFINE")[0]) source = fnv(source, getenv("EDISON_JIT_DEFINE"), strlen(getenv("EDISON_JIT_DEFINE")));
 
 	const char *want = getenv("EDISON_JIT_COMPILER");
 	const int try_hipcc = !want || !want[0] || !strcmp(want, "hipcc"), try_rtc = !want || !want[0] || !strcmp(want, "hiprtc");

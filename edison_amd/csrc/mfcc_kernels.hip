@@ -145,6 +145,17 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
                            * (16 v_mov_b32 per pair). */
 #endif
 
+/* Wave priorities (round 3): s_setprio at the phase boundaries of ed_mfcc2_kernel's loop, two bits per boundary (boundary i = end of
+ * phase i: 0 unpack + loads of the next pair, 1 pass 1, 2 transpose 1, 3 pass 2, 4 transpose 2 (LDS), 5 pass 3, 6 split, 7 spectrum
+ * to LDS, 8 mel, 9 fold, 10 DCT (LDS), 11 store). A SIMD issues from its oldest ready wave; with equal priorities the three waves
+ * of a SIMD end up in the same phase (all in their arithmetic, then all waiting for LDS) -- a priority that RISES with the progress
+ * through a pair (0 in pass 1, 1 in pass 2, 2 in pass 3, 3 from the split to the next pair's loads) lets the wave that is ahead
+ * stay ahead, so the waves spread over the phases and one wave's LDS phases lie under the others' arithmetic: +5.3 ... +6.1 %
+ * (interleaved A/B on three boxes, tools/lab/ab_mfcc.py; bit-identical). The gradient over the three passes is what counts: high
+ * priority for the tail alone, or for the memory phases alone, gives +0.1 ... +0.9 %, the reverse order -0.3 %. 0 = none. */
+#ifndef ED2_PRIO
+#define ED2_PRIO 0xfffa50
+#endif
 /* Diagnostic build only (-DED2_STAMP=1, tools/lab): s_memtime stamps at the phase boundaries of ed_mfcc2_kernel; per-wave
  * cycle sums per phase go to a debug buffer that nothing else reads. The product build contains no stamp. */
 #ifndef ED2_STAMP
@@ -170,6 +181,8 @@ __device__ __forceinline__ unsigned long long ed2_now()
 #else /* 2: only the loop as a whole (clock, fixed cost per launch) */
 #define ED2_ST(i)
 #endif
+#elif ED2_PRIO
+#define ED2_ST(i) __builtin_amdgcn_s_setprio((ED2_PRIO >> (2 * (i))) & 3);
 #else
 #define ED2_ST(i)
 #endif

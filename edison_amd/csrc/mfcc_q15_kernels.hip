@@ -44,6 +44,17 @@
 #define EQ_BUF 1088              /* 1024 complex values + one pad dword per 16                        */
 #define EQ_P(p) ((p) + ((p) >> 4))
 #define EQ_NB 16                 /* frames whose DCT stage a wavefront runs together                  */
+/* Wave priorities rising with the progress through a frame (see ED2_PRIO in mfcc_kernels.hip; +2.9 ... +3.2 % here), two bits per
+ * point: 0 top of the loop (global loads + reads of stages 2+3), 1 stage 2+3 arithmetic, 2 its write-back + reads of 4+5,
+ * 3 stage 4+5 + magnitudes, 4 spectrum store + mel, 5 the next frame's stage 1 (at priority 0 the gain is gone). 0 = none. */
+#ifndef EQ_PRIO
+#define EQ_PRIO 0xe50
+#endif
+#if EQ_PRIO
+#define EQ_PR(pt) __builtin_amdgcn_s_setprio((EQ_PRIO >> (2 * (pt))) & 3)
+#else
+#define EQ_PR(pt) ((void)0)
+#endif
 /* timing-only ablations for A/B work (results are WRONG when non-zero): 1 no sqrt, 2 no DCT stage, 4 no mel taps,
  * 8 no FFT stages 2-5, 16 no stage-1 butterflies */
 #ifndef EQ_ABLATE
@@ -517,6 +528,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 	{
 		const uint32_t f = s0 + i_cur;
 		u32 e[16];
+		EQ_PR(0);
 		/* the next frame's samples: unconditional (a wave's last iteration re-reads the slice's last frame, an L2 hit, and
 		 * never uses it) */
 		eq_load_frame<ALIGNED>(eq_frame_ptr(a, s0 + (i_next < cnt ? i_next : cnt - 1)), lane, raw);
@@ -529,10 +541,12 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 			for (int aa = 0; aa < 4; aa++)
 #pragma unroll
 				for (int b = 0; b < 4; b++) e[4 * aa + b] = buf[EQ_P(256 * U + j3 + 16 * aa + 64 * b)];
+			EQ_PR(1);
 #pragma unroll
 			for (int aa = 0; aa < 4; aa++) eq_bf_mid<false>(e[4 * aa], e[4 * aa + 1], e[4 * aa + 2], e[4 * aa + 3], EQ_TW12(1, aa, t2[aa]));
 #pragma unroll
 			for (int b = 0; b < 4; b++) eq_bf_mid<false>(e[b], e[4 + b], e[8 + b], e[12 + b], EQ_TW3(t3));
+			EQ_PR(2);
 #pragma unroll
 			for (int aa = 0; aa < 4; aa++)
 #pragma unroll
@@ -542,6 +556,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 			/* ---- stages 4 + 5 on the 16 consecutive elements of this lane */
 #pragma unroll
 			for (int m = 0; m < 16; m++) e[m] = buf[17 * lane + m]; /* EQ_P(16 lane + m) */
+			EQ_PR(3);
 #pragma unroll
 			for (int j = 0; j < 4; j++) eq_bf_mid<true>(e[j], e[4 + j], e[8 + j], e[12 + j], t4[j]);
 #pragma unroll
@@ -576,6 +591,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 					if (!ok[kk]) mag[kk] = eq_mag_fix(pw[kk], mag[kk], s_sqbit);
 			}
 		}
+		EQ_PR(4);
 #pragma unroll
 		for (int kk = 0; kk < 8; kk++)
 		{
@@ -638,6 +654,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 		eq_wave_sync();
 
 		/* ---- the next frame's stage 1 (see the prologue): the transform buffer is free from here on */
+		EQ_PR(5);
 		if (i_next < cnt) stage1(raw);
 
 		/* ---- dct2_q15, deferred: run it when 16 frames are parked or the wave has no frame left */
