@@ -164,6 +164,16 @@ extern "C" int ed_launch_mfcc_f32(const ed_mfcc_f32_args_t *args, const ed_f32_t
 #define EF2_XBUF_FLOATS 2208
 #define EF2_TAB_FLOATS (2 * 7 * 64 * 2 + ED_F32_MAX_W + ED_F32_NUM_FBANK * ED_F32_NUM_FBANK + 4) /* twiddles | mel_w | dct */
 
+/* wave priority rising with the progress through a pair (see ED2_PRIO in mfcc_kernels.hip): 0 in pass 1, 1 in pass 2, 2 in pass 3,
+ * 3 from the magnitudes to the next pair's loads. EF2_PRIO=0: none (A/B) */
+#ifndef EF2_PRIO
+#define EF2_PRIO 1
+#endif
+#if EF2_PRIO
+#define EF2_PR(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define EF2_PR(p) ((void)0)
+#endif
 __global__ __launch_bounds__(64 * EF2_WPB) void ed_mfcc_f32_fast_kernel(ed_mfcc_f32_args_t a, const ed_f32_tables_t *__restrict__ T,
                                                                       const ed_mfcc_tables_t *__restrict__ F)
 {
@@ -250,6 +260,7 @@ __global__ __launch_bounds__(64 * EF2_WPB) void ed_mfcc_f32_fast_kernel(ed_mfcc_
 		uint32_t drawn = 0;
 		if (lane == 0) drawn = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 
+		EF2_PR(0);
 		/* ---- 2. 512-point complex FFT: pass 1 + twiddles, transpose 1 (VALU), pass 2 + twiddles, transpose 2 (LDS), pass 3 */
 		ed_radix8_2(re, im);
 #pragma unroll
@@ -260,6 +271,7 @@ __global__ __launch_bounds__(64 * EF2_WPB) void ed_mfcc_f32_fast_kernel(ed_mfcc_
 			re[q] = xr * wr - xi * wi;
 			im[q] = xr * wi + xi * wr;
 		}
+		EF2_PR(1);
 		ed_transpose8_2<3, 4, 5>(re, lane);
 		ed_transpose8_2<3, 4, 5>(im, lane);
 		ed_radix8_2(re, im);
@@ -271,6 +283,7 @@ __global__ __launch_bounds__(64 * EF2_WPB) void ed_mfcc_f32_fast_kernel(ed_mfcc_
 			re[q] = xr * wr - xi * wi;
 			im[q] = xr * wi + xi * wr;
 		}
+		EF2_PR(2);
 #pragma unroll
 		for (int q = 0; q < 8; q++) xc4[66 * lo3 + hi3 + 8 * q] = make_float4(re[q].x, re[q].y, im[q].x, im[q].y);
 		ed_wave_sync();
@@ -283,6 +296,7 @@ __global__ __launch_bounds__(64 * EF2_WPB) void ed_mfcc_f32_fast_kernel(ed_mfcc_
 		ed_wave_sync();
 		ed_radix8_2(re, im);
 
+		EF2_PR(3);
 		/* ---- 3. |X[k]|, k = lane + 64 r (r < 4), and k = 256 (lane 0, r = 4): sqrtf(re^2 + im^2) (mfcc.c:196-206) */
 #pragma unroll
 		for (int r = 0; r < 4; r++)
