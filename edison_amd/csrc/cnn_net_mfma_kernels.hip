@@ -183,7 +183,7 @@ __device__ __forceinline__ v4i emm_gather16(const lds8 *a, int soff, int keep)
 #endif
 #if EMM_PRIO
 #define EMM_PRIO_OF(li, n) (EMM_PRIO == 1 ? ((li) * 4) / (n) : EMM_PRIO == 2 ? (li) : EMM_PRIO == 3 ? (li) - ((n) - 4) : EMM_PRIO == 4 ? ((li) * 3) / (n) + 1 : ((li) * 8) / (n) - 2)
-#define EMM_PR(li, n) { const int p_ = EMM_PRIO_OF(li, n); if (p_ <= 0) __builtin_amdgcn_s_setprio(0); else if (p_ == 1) __builtin_amdgcn_s_setprio(1); \
+#define EMM_PR(li, n) if (EMM_PRIO != 6) { const int p_ = EMM_PRIO_OF(li, n); if (p_ <= 0) __builtin_amdgcn_s_setprio(0); else if (p_ == 1) __builtin_amdgcn_s_setprio(1); \
 	else if (p_ == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
 #else
 #define EMM_PR(li, n)
@@ -589,6 +589,9 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 	lds8 *emm_lds = (lds8 *)emm_lds_generic;
 	EMM_CONST int n_layers = EMM_NL_EXPR, batch = EMM_MF(batch), buf_bytes = EMM_MF(buf_bytes);
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if EMM_PRIO == 6 /* lab: a fixed priority per wave of a SIMD */
+	if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1); else if ((wave >> 2) >= 2) __builtin_amdgcn_s_setprio(2);
+#endif
 	const int n_threads = blockDim.x, n_waves = n_threads >> 6;
 	/* small tables, copied once per workgroup: chunk offsets of every layer | seeds | column, expansion, input tables; then
 	 * the weight fragments (when resident); then one slice per wave: the activation region and the expansion

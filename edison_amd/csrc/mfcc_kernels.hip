@@ -227,6 +227,9 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef ED2_PRIO_FIXED /* lab: a fixed priority per wave of a SIMD instead of one that follows the progress (build with -DED2_PRIO=0) */
+	if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1); else if ((wave >> 2) >= 2) __builtin_amdgcn_s_setprio(2);
+#endif
 	const float4 *dctl = reinterpret_cast<const float4 *>(smem);                     /* [2][64] x 4 coefficients */
 	const float2 *tpl = reinterpret_cast<const float2 *>(smem + 512);                /* [4][64] split twiddles   */
 	const float4 *melw4 = reinterpret_cast<const float4 *>(smem + ED_FIXTAB_FLOATS); /* [NLO+NHI][64] quads      */
