@@ -237,7 +237,11 @@ __global__ __launch_bounds__(64 * EF2_WPB) void ed_mfcc_f32_fast_kernel(ed_mfcc_
 		const uint32_t fA = 2 * pr, fB = fA + 1 < n_frames ? fA + 1 : fA;
 		const int16_t *pa = a.audio + (int64_t)fA * a.frame_step, *pb = a.audio + (int64_t)fB * a.frame_step;
 #pragma unroll
+#ifdef EF2_LOAD_NT /* lab: non-temporal loads (frames overlap by half at hop 256: every sample is read by two frames) */
+		for (int q = 0; q < 8; q++) { xa[q] = __builtin_nontemporal_load(pa + off0[q]); ya[q] = __builtin_nontemporal_load(pa + off1[q]); xb[q] = __builtin_nontemporal_load(pb + off0[q]); yb[q] = __builtin_nontemporal_load(pb + off1[q]); }
+#else
 		for (int q = 0; q < 8; q++) { xa[q] = pa[off0[q]]; ya[q] = pa[off1[q]]; xb[q] = pb[off0[q]]; yb[q] = pb[off1[q]]; }
+#endif
 	};
 
 	uint32_t i_cur = wave, i_next = wave + EF2_WPB;

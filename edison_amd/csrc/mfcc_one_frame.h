@@ -45,14 +45,21 @@ __device__ __forceinline__ const int16_t *ed_frame_ptr(const ed_mfcc_args_t &a, 
 	return a.audio + ((int64_t)g * a.group_stride + (int64_t)i * a.frame_step);
 }
 
+#ifndef ED_LOAD_NT
+#define ED_LOAD_NT 1
+#endif
 template <bool ALIGNED>
 __device__ __forceinline__ void ed_load_frame(const int16_t *fp, int lane, uint32_t (&v)[8])
 {
 	if (ALIGNED)
 	{
 		const uint32_t *fp32 = reinterpret_cast<const uint32_t *>(fp);
+		/* the samples are read once: non-temporal loads (global_load_dword ... nt) keep them from displacing what the caches are
+		 * for (tables, the feature rows the CNN reads next): +2.2 ... +2.6 % on the 65 536-frame launch, +1.0 % on the Q15
+		 * kernel (interleaved A/B, profiles/r03_wave_priorities.txt); agent- / system-scope loads (sc1, sc0 sc1) and
+		 * non-temporal STORES of the coefficients measure -0.4 ... -0.8 %. ED_LOAD_NT=0: plain loads (A/B) */
 #pragma unroll
-		for (int a = 0; a < 8; a++) v[a] = fp32[lane + 64 * a];
+		for (int a = 0; a < 8; a++) v[a] = ED_LOAD_NT ? __builtin_nontemporal_load(fp32 + lane + 64 * a) : fp32[lane + 64 * a];
 	}
 	else
 	{

@@ -155,6 +155,9 @@ __device__ __forceinline__ void eq_bf_first_real2(u32 a0, u32 a1, u32 a2, u32 a3
 }
 
 /* the samples of one frame as stage 1 wants them: x[4 v + q] = samples (2 lane + 128 v + 256 q, and the next one) */
+#ifndef EQ_LOAD_NT
+#define EQ_LOAD_NT 1
+#endif
 template <bool ALIGNED>
 __device__ __forceinline__ void eq_load_frame(const int16_t *src, int lane, u32 (&x)[8])
 {
@@ -162,7 +165,8 @@ __device__ __forceinline__ void eq_load_frame(const int16_t *src, int lane, u32 
 	for (int i = 0; i < 8; i++)
 	{
 		const int at = 2 * lane + 128 * (i >> 2) + 256 * (i & 3);
-		if (ALIGNED) x[i] = *reinterpret_cast<const u32 *>(src + at);
+		/* read once: non-temporal (see ed_load_frame in mfcc_one_frame.h; +1.0 % here). EQ_LOAD_NT=0: plain (A/B) */
+		if (ALIGNED) x[i] = EQ_LOAD_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32 *>(src + at)) : *reinterpret_cast<const u32 *>(src + at);
 		else x[i] = (u32)(unsigned short)src[at] | ((u32)(unsigned short)src[at + 1] << 16);
 	}
 }
