@@ -39,16 +39,16 @@
 #include "edison_internal.h"
 
 #ifndef EQ_WPB
-#define EQ_WPB 12                /* wavefronts (= frames in flight) per workgroup: one workgroup per CU, 3 waves per SIMD */
+#define EQ_WPB 16                /* wavefronts (= frames in flight) per workgroup: one workgroup per CU, 4 waves per SIMD */
 #endif
 #define EQ_BUF 1088              /* 1024 complex values + one pad dword per 16                        */
 #define EQ_P(p) ((p) + ((p) >> 4))
 #define EQ_NB 16                 /* frames whose DCT stage a wavefront runs together                  */
 /* Wave priorities rising with the progress through a frame (see ED2_PRIO in mfcc_kernels.hip; +2.9 ... +3.2 % here), two bits per
- * point: 0 top of the loop (global loads + reads of stages 2+3), 1 stage 2+3 arithmetic, 2 its write-back + reads of 4+5,
+ * point (product table 0,1,1,2,2,3): 0 top of the loop (global loads + reads of stages 2+3), 1 stage 2+3 arithmetic, 2 its write-back + reads of 4+5,
  * 3 stage 4+5 + magnitudes, 4 spectrum store + mel, 5 the next frame's stage 1 (at priority 0 the gain is gone). 0 = none. */
 #ifndef EQ_PRIO
-#define EQ_PRIO 0xe50
+#define EQ_PRIO 0xe94
 #endif
 #if EQ_PRIO
 #define EQ_PR(pt) __builtin_amdgcn_s_setprio((EQ_PRIO >> (2 * (pt))) & 3)
@@ -377,8 +377,10 @@ __device__ __forceinline__ void eq_dct_batch(const ed_mfcc_q15_args_t &a, int *m
 
 /* 1: the per-lane coefficients of stages 1 and 2 are read from LDS in every frame instead of living in 48 VGPRs:
  * 216 -> 167 registers, 3 waves per SIMD instead of 2, +6.7 % (48 more conflict-free ds_read_b32 per frame) */
+/* 2 (round 3): stage 3's six as well -- 128 registers, 4 waves per SIMD. Without wave priorities the fourth wave bought nothing
+ * (89.8 us at 12 and at 16 waves); with them 89.9 -> 87.1 us (+3.3 %, profiles/r03_wave_priorities.txt) */
 #ifndef EQ_TW_LDS
-#define EQ_TW_LDS 1
+#define EQ_TW_LDS 2
 #endif
 #if EQ_TW_LDS
 #define EQ_TW12(stage, u, regs) eq_tw_from_lds(s_tw12 + ((stage) * 4 + (u)) * 6 * 64, lane)
@@ -398,7 +400,10 @@ __device__ __forceinline__ eq_tw3 eq_tw_from_lds(const u32 *t, int lane)
 	return r;
 }
 
-#ifdef EQ_WAVES_PER_EU /* tuning knob: ask the register allocator for this occupancy */
+#ifndef EQ_WAVES_PER_EU /* the occupancy the register allocator is asked for */
+#define EQ_WAVES_PER_EU (EQ_WPB / 4)
+#endif
+#if EQ_WAVES_PER_EU
 #define EQ_OCCUPANCY __attribute__((amdgpu_waves_per_eu(EQ_WAVES_PER_EU, EQ_WAVES_PER_EU)))
 #else
 #define EQ_OCCUPANCY
@@ -410,7 +415,7 @@ __device__ __forceinline__ eq_tw3 eq_tw_from_lds(const u32 *t, int lane)
 #define EQ_LDS_DWORDS(nlop, nhip) (((nlop) + (nhip)) * 64 + 1024 + EQ_TW_DWORDS + EQ_WPB * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB) + 4)
 
 /*
- * One workgroup per CU (EQ_WPB wavefronts, 3 per SIMD at 167 VGPRs) owns a contiguous slice of the launch's frames and
+ * One workgroup per CU (EQ_WPB wavefronts, 4 per SIMD at 128 VGPRs; 19 loop-invariant values of the deferred DCT stage live in scratch) owns a contiguous slice of the launch's frames and
  * hands them to its wavefronts through a counter in LDS: the vector ALU arbitrates oldest-first, so with a fixed
  * frame -> wave assignment the old waves of a SIMD finish long before the young ones and the tail of the launch runs
  * at one or two waves per SIMD (SQ_WAVE_CYCLES / SQ_WAVES was 78 % of the kernel's busy time); drawn from a queue, all
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 		}
 	}
 	const eq_tw3 t3 = eq_load_tw(T->tw1024, T->tw1024x, 16 * j3);     /* stage 3: ic = 16 j               */
-#if EQ_TW_LDS >= 2 /* stage 3's six as well (measured: no gain, 16 waves per CU run no faster than 12) */
+#if EQ_TW_LDS >= 2 /* stage 3's six as well */
 	if (w == 1 % EQ_WPB)
 	{
 #pragma unroll
