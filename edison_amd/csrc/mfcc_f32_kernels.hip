@@ -158,7 +158,9 @@ extern "C" int ed_launch_mfcc_f32(const ed_mfcc_f32_args_t *args, const ed_f32_t
  */
 #include "mfcc_fft.h"
 
-#define EF2_WPB 12
+#ifndef EF2_WPB
+#define EF2_WPB 16 /* 4 waves per SIMD at 128 VGPRs: +4.5 % over 12 once the wave priorities are in (1.33-1.37 -> 1.40-1.41 G frames/s) */
+#endif
 #define EF2_S_OFF 1088     /* float offset of the interleaved spectra S2[k] = (|X_A[k]|, |X_B[k]|), k = 0..256 */
 #define EF2_L_OFF 1664     /* log-mel energies of both frames, float2[32] */
 #define EF2_XBUF_FLOATS 2208
