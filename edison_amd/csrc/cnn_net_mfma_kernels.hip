@@ -177,9 +177,9 @@ __device__ __forceinline__ v4i emm_gather16(const lds8 *a, int soff, int keep)
 /* images per wave the prefetch covers: 4 in a graph's own kernel (unused slots fold away), 2 here -- the general kernel sits at
  * its 168-register limit, two more images' registers go to scratch (+3 % at 2, measured on the planner's usual batch of 2) */
 /* A wave's priority rises with the layer it is in (the waves of a workgroup walk their own batches; see ED2_PRIO in
- * mfcc_kernels.hip): +8.7 % on the general kernel, +8.0 % on a graph's own (kws_conv, interleaved A/B). 0 = none; 2..4: lab */
+ * mfcc_kernels.hip): +9.5 % on the general kernel, +7.9 % on a graph's own (kws_conv, interleaved A/B). 0 = none; 3..6: lab */
 #ifndef EMM_PRIO
-#define EMM_PRIO 1
+#define EMM_PRIO (EMM_SPEC ? 1 : 2) /* own kernel: (4 li) / n (+7.9 %, min(li, 3): +6.9 %); general kernel: min(li, 3) (+9.5 %, (4 li) / n: +8.6 %) */
 #endif
 #if EMM_PRIO
 #define EMM_PRIO_OF(li, n) (EMM_PRIO == 1 ? ((li) * 4) / (n) : EMM_PRIO == 2 ? (li) : EMM_PRIO == 3 ? (li) - ((n) - 4) : EMM_PRIO == 4 ? ((li) * 3) / (n) + 1 : ((li) * 8) / (n) - 2)
