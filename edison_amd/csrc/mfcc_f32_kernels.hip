@@ -324,26 +324,30 @@ __global__ __launch_bounds__(64 * EF2_WPB) void ed_mfcc_f32_fast_kernel(ed_mfcc_
 		if (e.x == 0.0f) e.x = FLT_MIN;
 		if (e.y == 0.0f) e.y = FLT_MIN;
 		const ed_f2 lg = ed_mk2(logf(e.x), logf(e.y));
-		if (lane < ED_F32_NUM_FBANK)
+		/* the lane number is made opaque for the two output stages: the 64-bit per-lane output addresses derived from it would
+		 * otherwise be hoisted out of the loop and, at 128 registers (4 waves per SIMD), live in scratch */
+		int ln = lane;
+		asm volatile("" : "+v"(ln));
+		if (ln < ED_F32_NUM_FBANK)
 		{
-			LM[lane] = lg;
+			LM[ln] = lg;
 			if (a.logmel)
 			{
-				a.logmel[(int64_t)fA * ED_F32_NUM_FBANK + lane] = lg.x;
-				if (haveB) a.logmel[(int64_t)(fA + 1) * ED_F32_NUM_FBANK + lane] = lg.y;
+				a.logmel[(int64_t)fA * ED_F32_NUM_FBANK + ln] = lg.x;
+				if (haveB) a.logmel[(int64_t)(fA + 1) * ED_F32_NUM_FBANK + ln] = lg.y;
 			}
 		}
 		ed_wave_sync();
 
 		/* ---- 5. DCT rows, scale, round half away from zero, saturate to q7 (mfcc.c:234-254) */
-		if (lane < n_out)
+		if (ln < n_out)
 		{
 			ed_f2 sum = ed_splat(0.0f);
 #pragma unroll
 			for (int j = 0; j < ED_F32_NUM_FBANK; j++) sum = ed_fma2(ed_splat(dctl[dct_row + j]), LM[j], sum);
 			sum = sum * ed_splat(scale);
 			const float ra = roundf(sum.x), rb = roundf(sum.y);
-			const int64_t oa = (int64_t)fA * n_out + lane;
+			const int64_t oa = (int64_t)fA * n_out + ln;
 			a.out[oa] = (int8_t)(ra >= 127.0f ? 127 : (ra <= -128.0f ? -128 : (int)ra));
 			if (a.out_f32) a.out_f32[oa] = sum.x;
 			if (haveB)

@@ -297,6 +297,9 @@ __device__ __forceinline__ const int16_t *eq_frame_ptr(const ed_mfcc_q15_args_t 
 __device__ __forceinline__ void eq_dct_batch(const ed_mfcc_q15_args_t &a, int *melb, u32 *zb, int nb, const u32 *fid,
                                              int lane, const ed_q15_tables_t *__restrict__ T)
 {
+	/* the lane number is made opaque here: everything this stage derives from it (a dozen and a half addresses and indices) would
+	 * otherwise be hoisted out of the frame loop and, at 128 registers, spilled -- 20 MB of scratch writes per launch */
+	asm volatile("" : "+v"(lane));
 	/* once per 16 frames: the constants of this stage are fetched here (L2 hits) instead of holding 8 registers */
 	const eq_tw3 t16 = eq_load_tw(T->tw16, T->tw16x, lane & 3);
 	const u32 rfa_l = T->rfa[lane & 15], rfb_l = T->rfb[lane & 15];
@@ -377,7 +380,7 @@ __device__ __forceinline__ void eq_dct_batch(const ed_mfcc_q15_args_t &a, int *m
 
 /* 1: the per-lane coefficients of stages 1 and 2 are read from LDS in every frame instead of living in 48 VGPRs:
  * 216 -> 167 registers, 3 waves per SIMD instead of 2, +6.7 % (48 more conflict-free ds_read_b32 per frame) */
-/* 2 (round 3): stage 3's six as well -- 128 registers, 4 waves per SIMD. Without wave priorities the fourth wave bought nothing
+/* 2 (round 3): stage 3's six as well -- 106 registers, 4 waves per SIMD. Without wave priorities the fourth wave bought nothing
  * (89.8 us at 12 and at 16 waves); with them 89.9 -> 87.1 us (+3.3 %, profiles/r03_wave_priorities.txt) */
 #ifndef EQ_TW_LDS
 #define EQ_TW_LDS 2
@@ -415,7 +418,7 @@ __device__ __forceinline__ eq_tw3 eq_tw_from_lds(const u32 *t, int lane)
 #define EQ_LDS_DWORDS(nlop, nhip) (((nlop) + (nhip)) * 64 + 1024 + EQ_TW_DWORDS + EQ_WPB * (EQ_BUF + EQ_NB * 32 + EQ_NB * 16 + EQ_NB) + 4)
 
 /*
- * One workgroup per CU (EQ_WPB wavefronts, 4 per SIMD at 128 VGPRs; 19 loop-invariant values of the deferred DCT stage live in scratch) owns a contiguous slice of the launch's frames and
+ * One workgroup per CU (EQ_WPB wavefronts, 4 per SIMD at 106 VGPRs) owns a contiguous slice of the launch's frames and
  * hands them to its wavefronts through a counter in LDS: the vector ALU arbitrates oldest-first, so with a fixed
  * frame -> wave assignment the old waves of a SIMD finish long before the young ones and the tail of the launch runs
  * at one or two waves per SIMD (SQ_WAVE_CYCLES / SQ_WAVES was 78 % of the kernel's busy time); drawn from a queue, all
