@@ -500,3 +500,38 @@ def test_own_kernel_compiles_for_every_fixture_graph(built_lib, name):
     assert r == 0, log[:2000]
     assert b"ed_net_mfma_spec" in code and len(code) > 4096
     assert "loop not unrolled" not in log, log[:2000]   # the layer loop MUST unroll: the layer records only become constants then
+
+
+def test_hot_kernels_use_no_scratch(tmp_path):
+    """The frame loops of the hot kernels hold everything in registers. A 16-wave build of the Q15 kernel once ran with 19 registers of
+    hoisted per-lane addresses in scratch (20 MB of writes per launch that only the HBM counters showed, profiles/r03_wave_priorities.txt):
+    the compiler's resource remarks are checked here, on the build flags the library uses (hipcc cross-compiles without a GPU)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from edison_amd import build as B
+    want = {  # file -> (substring of the mangled kernel name, maximum VGPRs for the occupancy the launch code assumes)
+        "mfcc_kernels.hip": ("ed_mfcc2_kernel", 168),       # 12 waves per CU
+        "mfcc_q15_kernels.hip": ("ed_mfcc_q15_kernelILb0E", 128),  # 16 waves per CU; the stage-dump instances (ILb1E) are diagnostics
+        "cnn_mfma_kernels.hip": ("ed_cnn_mfma_kernel", 256),   # 8 waves per CU (LDS-bound)
+    }
+
+    def remarks(name):
+        cmd = [B._hipcc(), "--offload-arch=" + B.ARCH, "--cuda-device-only", "-c", "-std=c++17", "-fno-slp-vectorize", "-O3", "-I" + B.CSRC,
+               "-Rpass-analysis=kernel-resource-usage"] + B.PER_FILE_FLAGS.get(name, []) + ["-x", "hip", os.path.join(B.CSRC, name), "-o", str(tmp_path / (name + ".o"))]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        texts = dict(zip(want, ex.map(remarks, want)))
+    for name, (kernel, max_vgprs) in want.items():
+        blocks = re.split(r"remark: Function Name: ", texts[name])[1:]
+        seen = 0
+        for b in blocks:
+            if kernel not in b.split()[0]:
+                continue
+            seen += 1
+            scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+            vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+            assert scratch == 0, (name, b.split()[0], "scratch bytes per lane", scratch)
+            assert vgprs <= max_vgprs, (name, b.split()[0], vgprs)
+        assert seen >= 1, (name, kernel)
