@@ -17,7 +17,8 @@
  *           wheel bundles libamd_comgr.so of ROCm 7.0, and the same text comes out 30 % longer with 14 spilled scalars
  *           (211 M inputs/s instead of 236 M on kws_conv) -- which is why the child process goes first.
  * Code objects are cached on disk by (graph hash, source hash, compiler): $EDISON_JIT_CACHE, else $XDG_CACHE_HOME/edison_amd,
- * else $HOME/.cache/edison_amd; EDISON_JIT_CACHE=off disables the cache. Without a compiler, or when the compilation fails,
+ * else $HOME/.cache/edison_amd; EDISON_JIT_CACHE=off disables the cache. (EDISON_JIT_DEFINE=NAME=VALUE adds one -D to the hipcc
+ * command line and to the cache key: A/B work on the kernel's compile-time knobs, tools/lab/ab_net_own.py.) Without a compiler, or when the compilation fails,
  * the call reports it and the graph stays on the general kernel -- the same algorithm on the same device, not other code.
  */
 #include <dlfcn.h>
