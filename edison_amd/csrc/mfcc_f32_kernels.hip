@@ -151,7 +151,7 @@ extern "C" int ed_launch_mfcc_f32(const ed_mfcc_f32_args_t *args, const ed_f32_t
  * needed, lane l ends with X[l + 64 r] in register r and bins 0..256 are registers 0..3 (+ register 4 of lane 0).
  * Two frames ride in the two halves of packed fp32 registers (v_pk_*_f32): independent lanes of arithmetic, so a silent
  * frame next to a loud one stays exactly silent (which pairing two real frames into ONE complex transform would not
- * give). Frames are handed to the 12 waves of a CU-wide workgroup through a counter in LDS, as in ed_mfcc2_kernel.
+ * give). Frames are handed to the 16 waves of a CU-wide workgroup through a counter in LDS, as in ed_mfcc2_kernel.
  * Mel: two lanes per band (first / second half of the band's taps), log, DCT row per lane, scale, round half away,
  * saturate -- float32 like the firmware; the order of the partial sums differs from its serial loops, inside the bars
  * tests/test_gpu_f32.py states (the variant is pinned on the reference's compiled mfcc_compute + CMSIS transform: tests/golden/mfccf32_golden.npz).
