@@ -99,6 +99,24 @@ def test_one_launch_push_filters_like_the_filter_kernel(ctx, oracle_mod):
     s5.close()
 
 
+@pytest.mark.parametrize("alpha,threshold", [(0.0, 0.0), (1.0, 0.0), (0.25, 126.5)])
+def test_one_launch_push_filter_edge_parameters(ctx, oracle_mod, alpha, threshold):
+    """alpha 0 (the filtered value IS the newest softmax), alpha 1 (the state never leaves zero) and a threshold nothing reaches, on the
+    one-launch path (chunk 1) and on the filter kernel (chunk 3): equal to the oracle's filter bit for bit."""
+    from edison_amd.stream import Stream
+    rng = np.random.default_rng(int(alpha * 100) + 5)
+    audio = np.clip(rng.normal(0, 6000, 60 * 512), -32768, 32767).astype(np.int16)
+    for chunk in (1, 3):
+        st = Stream(ctx, hop=512, chunk_frames=chunk, output_filter=True, alpha=alpha, threshold=threshold)
+        outs = [st.push(audio[i * chunk * 512:(i + 1) * chunk * 512]) for i in range(60 // chunk)]
+        soft = np.concatenate([o["softmax"] for o in outs])
+        filt, likely, spotted, _ = oracle_mod.output_filter(soft, alpha=alpha, threshold=threshold)
+        assert np.array_equal(np.concatenate([o["filtered"] for o in outs]).view(np.uint32), filt.view(np.uint32))
+        assert np.array_equal(np.concatenate([o["likely"] for o in outs]), likely)
+        assert np.array_equal(np.concatenate([o["spotted"] for o in outs]), spotted)
+        st.close()
+
+
 def test_kws_live_replay(ctx, kws_golden, oracle_mod, oracle_model, tmp_path, capsys):
     """`kws live mcu <wav>`: the firmware's continuous loop on a file -- features (variant C), sliding window, network,
     output filter, FSM. The reference wav says "edison": the filtered wake-word output crosses the threshold, the FSM
