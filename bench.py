@@ -416,6 +416,33 @@ def launch_ranks(args):
     return rc
 
 
+WATCHDOG_EXIT_CODE = 3
+
+
+def guarded_leg(rank, line, where, leg, timeout_s):
+    """Run `leg()` (something that may hang inside a GPU / collective call that no Python exception will ever leave: a second
+    RCCL communicator's init, an all-gather on the context's stream) under a watchdog. If it does not return within
+    timeout_s, rank 0 prints the JSON line as it stands with `where`["cabi_collective"].status = "timed out ..." and EVERY rank
+    leaves with WATCHDOG_EXIT_CODE (non-zero: a process that gave up on a stuck call must not report success; launch_ranks
+    and the driver then see the failure). No re-exec, no restart: the process has touched the GPU. Returns leg()'s result."""
+    import threading
+
+    def bail():
+        if rank == 0:
+            where["cabi_collective"] = dict(status="timed out after %g s; the figures above use torch.distributed's collective" % timeout_s)
+            print(json.dumps(line), flush=True)
+        else:
+            time.sleep(1.0)   # rank 0's line first: a parent that sees this rank fail stops the others by PID
+        os._exit(WATCHDOG_EXIT_CODE)
+    dog = threading.Timer(timeout_s, bail)
+    dog.daemon = True
+    dog.start()
+    try:
+        return leg()
+    finally:
+        dog.cancel()
+
+
 def dry_run(args):
     """The N > 1 control flow WITHOUT GPUs (gloo, CPU tensors): what can be rehearsed in a container that has no device.
     Every rank: rendezvous -> can RCCL be bound (edison_dist_available)? -> rank 0's 128-byte RCCL id reaches every rank
@@ -472,17 +499,30 @@ def dry_run(args):
     if world > 1:
         dist.all_reduce(good, op=dist.ReduceOp.MIN)
         dist.barrier()
+    line = dict(metric="MFCC frames/sec + KWS inferences/sec (whole node) at 1/2/4/8 MI355X", value=None, unit="frames/s",
+                n_gpus=world, steps=min(args.steps, 20), warmup=min(args.warmup, 5), ms_per_step=None, higher_is_better=True,
+                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", dry_run=True,
+                config=dict(workload="DRY RUN on CPU over gloo: control flow of the N > 1 bench only, no kernels, no numbers",
+                            parallelism="dp%d" % world, collective="all_gather int8 logits (gloo stand-in for RCCL)"),
+                checks=dict(rccl_bindable=rccl, rccl_id_reached_every_rank=id_ok, shard_ranges_rank0=shards,
+                            gathered_logits_correct=bool(int(good.item())), ranks=world))
+
+    # the leg that sits behind the watchdog in the real run (the collective behind the C-ABI), rehearsed with the gloo stand-in.
+    # EDISON_BENCH_CABI_HANG_S makes it sleep (on EDISON_BENCH_CABI_HANG_RANK, default every rank) as a stuck ncclCommInitRank /
+    # ncclAllGather would: with EDISON_BENCH_WATCHDOG_S shorter than that the run must print its line AND leave non-zero.
+    def cabi_rehearsal():
+        hang = float(os.environ.get("EDISON_BENCH_CABI_HANG_S", "0"))
+        if hang > 0 and os.environ.get("EDISON_BENCH_CABI_HANG_RANK", str(rank)) == str(rank):
+            time.sleep(hang)
+        got = gather(logits_of(rank, 0))
+        return dict(status="ok (dry run: gloo stand-in)" if torch.equal(got, torch.cat([logits_of(r, 0) for r in range(world)])) else "MISMATCH")
+    cabi = guarded_leg(rank, line, line["checks"], cabi_rehearsal, float(os.environ.get("EDISON_BENCH_WATCHDOG_S", "120")))
+    line["checks"]["cabi_collective"] = cabi
     if rank == 0:
-        print(json.dumps(dict(metric="MFCC frames/sec + KWS inferences/sec (whole node) at 1/2/4/8 MI355X", value=None, unit="frames/s",
-                              n_gpus=world, steps=min(args.steps, 20), warmup=min(args.warmup, 5), ms_per_step=None, higher_is_better=True,
-                              scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", dry_run=True,
-                              config=dict(workload="DRY RUN on CPU over gloo: control flow of the N > 1 bench only, no kernels, no numbers",
-                                          parallelism="dp%d" % world, collective="all_gather int8 logits (gloo stand-in for RCCL)"),
-                              checks=dict(rccl_bindable=rccl, rccl_id_reached_every_rank=id_ok, shard_ranges_rank0=shards,
-                                          gathered_logits_correct=bool(int(good.item())), ranks=world))), flush=True)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    return 0 if int(good.item()) == 1 and id_ok is not False else 1
+    return 0 if int(good.item()) == 1 and id_ok is not False and cabi["status"].startswith("ok") else 1
 
 
 def main():
@@ -729,6 +769,7 @@ def main():
             cpu = dict(error=repr(e))
 
     line = None
+    exit_code = 0
     if rank == 0:
         line = dict(metric="MFCC frames/sec + KWS inferences/sec (whole node) at 1/2/4/8 MI355X",
                     value=round(frames_per_s, 1), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -762,49 +803,47 @@ def main():
     if world > 1 and kws is not None:
         # ---- the same KWS step with the collective behind the C-ABI. Never run at N > 1 before the first multi-GPU node:
         # everything that could hang (ncclCommInitRank on a second communicator, ncclAllGather on the context's stream)
-        # sits behind a watchdog that prints the line as it stands and ends every rank.
-        import threading
-
-        def bail():
-            if rank == 0:
-                line["kws"]["cabi_collective"] = dict(status="timed out after 120 s; the figures above use torch.distributed's collective")
-                print(json.dumps(line), flush=True)
-            os._exit(0)
-        dog = threading.Timer(120.0, bail)
-        dog.daemon = True
-        dog.start()
-        cabi = dict(status="not available")
-        try:
-            ok = torch.tensor([1 if parallel.dist_available() else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 1:
-                parallel.init_context_comm(ctx, rank, world, dev)       # raises on every rank if any rank failed
-                logits_all = torch.empty((world * nu, 10), dtype=torch.int8, device=dev)
-                ctx.kws_sharded_t(audio, nu, 31 * 1024, logits_all, feat=feat, logits=logits, softmax=soft, argmax=am)
-                ref_all = gather(logits).clone()
-                torch.cuda.synchronize()
-                same = torch.tensor([1 if torch.equal(ref_all, logits_all) else 0], dtype=torch.int32, device=dev)
-                dist.all_reduce(same, op=dist.ReduceOp.MIN)
-                if int(same.item()) == 1:
-                    def kws_cabi_step(i):
-                        ctx.kws_sharded_t(audio, nu, 31 * 1024, logits_all, feat=feat, logits=logits, softmax=soft, argmax=am)
-                    c_ms, _ = timed_region(kws_cabi_step, args.steps, min(args.warmup, 50), world)
-                    cabi = dict(status="ok: rows identical to torch.distributed's all-gather on every rank", value=round(world * nu / (c_ms * 1e-3), 1),
-                                unit="inferences/s", ms_per_step=round(c_ms, 4),
-                                what="edison_kws_batch_sharded_dev: MFCC + CNN + ncclAllGather on the context's stream, one call per rank per step")
-                else:
-                    cabi = dict(status="MISMATCH against torch.distributed's all-gather on the first step: not timed")
-        except Exception as e:  # noqa: BLE001
-            cabi = dict(status="failed: %r" % (e,))
-        dog.cancel()
+        # sits behind a watchdog that prints the line as it stands and ends every rank with a NON-ZERO code (guarded_leg).
+        def cabi_leg():
+            cabi = dict(status="not available")
+            try:
+                ok = torch.tensor([1 if parallel.dist_available() else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 1:
+                    parallel.init_context_comm(ctx, rank, world, dev)       # raises on every rank if any rank failed
+                    logits_all = torch.empty((world * nu, 10), dtype=torch.int8, device=dev)
+                    ctx.kws_sharded_t(audio, nu, 31 * 1024, logits_all, feat=feat, logits=logits, softmax=soft, argmax=am)
+                    ref_all = gather(logits).clone()
+                    torch.cuda.synchronize()
+                    same = torch.tensor([1 if torch.equal(ref_all, logits_all) else 0], dtype=torch.int32, device=dev)
+                    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                    if int(same.item()) == 1:
+                        def kws_cabi_step(i):
+                            ctx.kws_sharded_t(audio, nu, 31 * 1024, logits_all, feat=feat, logits=logits, softmax=soft, argmax=am)
+                        c_ms, _ = timed_region(kws_cabi_step, args.steps, min(args.warmup, 50), world)
+                        cabi = dict(status="ok: rows identical to torch.distributed's all-gather on every rank", value=round(world * nu / (c_ms * 1e-3), 1),
+                                    unit="inferences/s", ms_per_step=round(c_ms, 4),
+                                    what="edison_kws_batch_sharded_dev: MFCC + CNN + ncclAllGather on the context's stream, one call per rank per step")
+                    else:
+                        cabi = dict(status="MISMATCH against torch.distributed's all-gather on the first step: not timed")
+            except Exception as e:  # noqa: BLE001
+                cabi = dict(status="failed: %r" % (e,))
+            return cabi
+        cabi = guarded_leg(rank, line, line["kws"] if rank == 0 else {}, cabi_leg, float(os.environ.get("EDISON_BENCH_WATCHDOG_S", "120")))
         if rank == 0:
             line["kws"]["cabi_collective"] = cabi
+        # the line is printed either way (the figures above do not depend on this leg), but a collective behind the C-ABI that
+        # failed or disagreed on ANY rank is a failed run: every rank learns it and leaves non-zero after the line
+        bad = torch.tensor([0 if cabi["status"].startswith(("ok", "not available")) else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        exit_code = 4 if int(bad.item()) else 0
     if rank == 0:
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    return exit_code
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -185,3 +185,27 @@ def test_bench_launcher_reports_a_failed_rank():
     """If a rank dies the parent stops the others and exits non-zero (here: rank 1 is told to fail before the rendezvous)."""
     r = _run_bench(["--gpus", "2", "--dry-run"], env_extra=dict(EDISON_BENCH_FAIL_RANK="1"), timeout=120)
     assert r.returncode != 0 and _json_lines(r.stdout) == []
+
+
+@pytest.mark.parametrize("hang_rank", [None, "1"])
+def test_bench_stuck_collective_prints_the_line_and_exits_non_zero(hang_rank):
+    """The leg behind the watchdog (the collective behind the C-ABI: a second RCCL communicator, ncclAllGather on the context's
+    stream -- never run at N > 1 on hardware) hangs past the watchdog: rank 0 must still print the ONE line, with the
+    time-out recorded in it, and the run must end NON-zero -- a process that gave up on a stuck call does not report success
+    (round-3 review: `os._exit(0)` recorded a hang as rc 0). Either every rank hangs, or one does and the others wait for it
+    inside the collective; under bench.py's own launcher and with the exit code of the watchdog (3) reaching the caller."""
+    env = dict(EDISON_BENCH_CABI_HANG_S="30", EDISON_BENCH_WATCHDOG_S="2")
+    if hang_rank is not None:
+        env["EDISON_BENCH_CABI_HANG_RANK"] = hang_rank
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"], env_extra=env, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    assert lines[0]["n_gpus"] == 2 and "timed out" in lines[0]["checks"]["cabi_collective"]["status"]
+
+
+def test_bench_guarded_leg_that_returns_is_not_disturbed():
+    """The same leg without a hang: status ok on the line, exit code 0, and the watchdog timer is gone (the run ends at once)."""
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"], env_extra=dict(EDISON_BENCH_WATCHDOG_S="60"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert _json_lines(r.stdout)[0]["checks"]["cabi_collective"]["status"].startswith("ok")
