@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from edison_amd import _lib
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=65536); ap.add_argument("--name", default="stamp")
-ap.add_argument("--wpb", type=int, default=4)
+ap.add_argument("--wpb", type=int, default=12)
 a = ap.parse_args()
 _lib._share_torch_hip_runtime()
 L = ctypes.CDLL(os.path.join(ROOT, "edison_amd/csrc/abl/libedison_hip_%s.so" % a.name))
@@ -24,7 +24,7 @@ L.ed_set_debug_buffer(ctypes.c_void_p(dbg.data_ptr())); torch.cuda.synchronize()
 g = torch.Generator(device=dev); g.manual_seed(1)
 bufs = [(torch.randn((a.frames, 1024), generator=g, device=dev) * 3000).clamp_(-32768, 32767).to(torch.int16) for _ in range(3)]
 out = torch.empty((a.frames, 13), dtype=torch.float32, device=dev)
-for i in range(3000): L.edison_mfcc_batch_dev(h, bufs[i % 3].data_ptr(), a.frames, 1024, _lib.MFCC_B, 13, out.data_ptr(), None, 1.0)
+for i in range(3000 if a.frames <= 131072 else max(6, 200000000 // a.frames)): L.edison_mfcc_batch_dev(h, bufs[i % 3].data_ptr(), a.frames, 1024, _lib.MFCC_B, 13, out.data_ptr(), None, 1.0)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().astype(np.float64)
 nw = int((d[:, 12] > 0).sum())
@@ -66,6 +66,7 @@ for i, n in enumerate(names):
 print("  loop: %.0f cycles per pair per wave" % (np.median(d[:, 12]) / pairs))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for i in range(300): L.edison_mfcc_batch_dev(h, bufs[i % 3].data_ptr(), a.frames, 1024, _lib.MFCC_B, 13, out.data_ptr(), None, 1.0)
+NREP = 300 if a.frames <= 131072 else 6
+for i in range(NREP): L.edison_mfcc_batch_dev(h, bufs[i % 3].data_ptr(), a.frames, 1024, _lib.MFCC_B, 13, out.data_ptr(), None, 1.0)
 e1.record(); torch.cuda.synchronize()
-print("  launch-to-launch time of this build: %.2f us" % (e0.elapsed_time(e1) / 300 * 1e3))
+print("  launch-to-launch time of this build: %.2f us" % (e0.elapsed_time(e1) / NREP * 1e3))
