@@ -35,6 +35,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "edison_internal.h"
 
@@ -105,6 +106,22 @@ __device__ __forceinline__ uint32_t edm_pack_relu(int a0, int a1, int a2, int a3
 	return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
 #endif
 }
+
+/* The same for an output shift of exactly 8 (conv1 and conv2 of the shipped model), with or without the max-pool partner o:
+ * ssat8(a >> 8) is the HIGH BYTE of a saturated to int16 -- clamp(a, -32768, 32767) >> 8 lies in -128..127 and equals a >> 8
+ * inside the range -- so v_cvt_pk_i16_i32 (two accumulators saturated into one dword) does shift, narrowing and saturation at
+ * once, v_max3_i32(e, o, 0) does the pool maximum and the ReLU (both commute with the monotone requantisation), and one
+ * v_perm_b32 picks the four high bytes: 7 instructions per packed dword (5 without pooling) instead of 15 (11). 60 of the 80
+ * dwords a lane requantises per group are conv1's and conv2's. */
+__device__ __forceinline__ uint32_t edm_pack_relu8(int a0, int a1, int a2, int a3)
+{
+	typedef short s2 __attribute__((ext_vector_type(2)));
+	const s2 p01 = __builtin_amdgcn_cvt_pk_i16(a0, a1), p23 = __builtin_amdgcn_cvt_pk_i16(a2, a3);
+	uint32_t u01, u23;
+	__builtin_memcpy(&u01, &p01, 4); __builtin_memcpy(&u23, &p23, 4);
+	return __builtin_amdgcn_perm(u23, u01, 0x07050301u); /* bytes 1, 3 of p01, then bytes 1, 3 of p23 */
+}
+__device__ __forceinline__ int edm_max3z(int a, int b) { const int m = a > b ? a : b; return m > 0 ? m : 0; } /* v_max3_i32 a, b, 0 */
 
 /* the accumulator tile that starts a 32-row output tile: D register r of lane half h is row (r&3) + 8*(r>>2) + 4*h, so
  * register group g (4 registers) is rows 8*g + 4*h .. +3 */
@@ -222,7 +239,8 @@ __device__ __forceinline__ void edm_prologue(const ed_cnn_mfma_model_t *__restri
 	}
 }
 
-template <bool HAS_FILTER>
+/* F8: the output shifts of conv1 and conv2 are both 8 (edm_pack_relu8); the kernels choose the instantiation from the model */
+template <bool HAS_FILTER, bool F8>
 __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_t n_utt, int64_t feat_stride, int8_t *__restrict__ logits,
                                          int8_t *__restrict__ softmax, int32_t *__restrict__ argmax, unsigned *done_flag, unsigned done_seq,
                                          unsigned char *smem, uint4 (&rows)[2], const unsigned char *row30, const ed_out_filter_t &flt, int with_filter)
@@ -347,13 +365,15 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 					uint32_t d[4];
 #pragma unroll
 					for (int g = 0; g < 4; g++)
-						d[g] = edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
-						                     edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs1);
+						d[g] = F8 ? edm_pack_relu8(edm_max3z(e[4 * g], o[4 * g]), edm_max3z(e[4 * g + 1], o[4 * g + 1]),
+						                           edm_max3z(e[4 * g + 2], o[4 * g + 2]), edm_max3z(e[4 * g + 3], o[4 * g + 3]))
+						          : edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
+						                          edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs1);
 					/* groups 0, 1 are channels 4h.. and 8+4h.. of x = 2 rt, groups 2, 3 the same of x = 2 rt + 1: after the
 					 * exchange lane half h owns the whole 16-byte record of x = 2 rt + h */
 					const uint4 rec = edm_gather16(d[0], d[1], d[2], d[3]);
 					*reinterpret_cast<uint4 *>((2 * rt + h < 9 && live) ? p1 + (2 * rt + h) * 16 : dummy) = rec;
-					if (rt + 1 < 5) { EDM_WEAVE(6, 13) }
+					if (rt + 1 < 5) { if (F8) { EDM_WEAVE(6, 7) } else { EDM_WEAVE(6, 13) } }
 					__builtin_amdgcn_sched_barrier(0);
 				}
 			}
@@ -401,13 +421,16 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 					ao[bs] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A2[s], B1[bs][s], ao[bs], 0, 0, 0);
 				}
 			};
-			auto requant = [&](int bs, int ls) {
+			auto requant = [&](int bs, int ls, auto f8_) {
+				constexpr bool R8 = decltype(f8_)::value; /* (the partial-group road below keeps the general form) */
 				const v16i &e = ae[bs], &o = ao[bs];
 				uint32_t d[4];
 #pragma unroll
 				for (int g = 0; g < 4; g++)
-					d[g] = edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
-					                     edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs2);
+					d[g] = R8 ? edm_pack_relu8(edm_max3z(e[4 * g], o[4 * g]), edm_max3z(e[4 * g + 1], o[4 * g + 1]),
+					                           edm_max3z(e[4 * g + 2], o[4 * g + 2]), edm_max3z(e[4 * g + 3], o[4 * g + 3]))
+					          : edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
+					                          edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs2);
 				const uint4 rec = edm_gather16(d[0], d[1], d[2], d[3]); /* channels 16h .. 16h + 15 */
 				*reinterpret_cast<uint4 *>(live[ls] ? p2[ls] + EDM_P2_PLANE * h : dummy) = rec;
 			};
@@ -422,8 +445,8 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 					if (t + 1 < 5) mma((t + 1) & 1);
 					EDM_FENCE();
 					if (t + 2 < 5) fetch(t + 2, t & 1, (t + 2) % 3); /* into the fragment registers tile t's MFMAs have consumed */
-					requant(t & 1, t % 3);
-					if (t + 1 < 5) { EDM_WEAVE(10, 7) }
+					requant(t & 1, t % 3, std::integral_constant<bool, F8>());
+					if (t + 1 < 5) { if (F8) { EDM_WEAVE(10, 4) } else { EDM_WEAVE(10, 7) } }
 					__builtin_amdgcn_sched_barrier(0);
 				}
 			}
@@ -437,7 +460,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 				{
 					fetch(t, 0, 0);
 					mma(0);
-					requant(0, 0);
+					requant(0, 0, std::false_type());
 				}
 			}
 		}
@@ -642,7 +665,10 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 	uint4 rows[2];
 	edm_prologue(model, feat, n_utt, feat_stride, smem, rows);
 	const ed_out_filter_t none = {0.0, 0.0, 0.0, nullptr, nullptr, nullptr, nullptr};
-	edm_main<false>(feat, n_utt, feat_stride, logits, softmax, argmax, done_flag, done_seq, smem, rows, nullptr, none, 0);
+	if (model->rs1 == 8 && model->rs2 == 8) /* uniform, from the kernel argument: the shipped model and any retrained one with these shifts */
+		edm_main<false, true>(feat, n_utt, feat_stride, logits, softmax, argmax, done_flag, done_seq, smem, rows, nullptr, none, 0);
+	else
+		edm_main<false, false>(feat, n_utt, feat_stride, logits, softmax, argmax, done_flag, done_seq, smem, rows, nullptr, none, 0);
 }
 
 /*
@@ -677,7 +703,7 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_kws1_kernel(ed_mfcc_args_t mar
 	/* (ALIGNED: the launcher checks that the frame starts on a dword -- the host's ring does -- so the samples come over the bus
 	 * as 8 dword loads per lane instead of 16 halfword loads) */
 	ed_mfcc1_body<false, true, NLO, NHI>(margs, tab, msmem, 0, wave == 0 ? 0u : 1u, 1u << 30, reinterpret_cast<int8_t *>(row30) + 3);
-	edm_main<true>(feat, 1, ED_IN_W, logits, softmax, argmax, done_flag, done_seq, smem, rows, row30, flt, with_filter);
+	edm_main<true, false>(feat, 1, ED_IN_W, logits, softmax, argmax, done_flag, done_seq, smem, rows, row30, flt, with_filter); /* one window: latency, not throughput */
 }
 
 extern "C" int ed_launch_kws1(const ed_mfcc_args_t *margs, const ed_mfcc_tables_t *dev_tab, const ed_cnn_mfma_model_t *dev_model, const int8_t *feat,
