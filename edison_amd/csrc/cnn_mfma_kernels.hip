@@ -39,8 +39,14 @@
 
 #include "edison_internal.h"
 
-#ifndef EDM_INTERLEAVE
-#define EDM_INTERLEAVE 1 /* 1: requantisation VALU is woven between the next tile's MFMAs (sched_group_barrier); 0: after them */
+/* ---- lab knobs: only a lab build (ED_LAB, tools/lab/mkvariant.py) may set them; the product build has none, and
+ * tests/test_host_cpu.py checks the values below against what edison_amd/build.py compiles */
+#if !defined(ED_LAB) && (defined(EDM_PRIO))
+#error "EDM_* lab knob defined without ED_LAB (tools/lab/mkvariant.py builds lab variants)"
+#endif
+#if defined(ED_LAB)
+/* a lab build says so: the product library exports no ed_lab_build_* symbol (tests/test_host_cpu.py) */
+extern "C" { extern const int ed_lab_build_cnn_mfma; const int ed_lab_build_cnn_mfma = 1; }
 #endif
 #define EDM_G 4       /* utterances per wavefront group */
 #define EDM_WAVES 8
@@ -81,12 +87,8 @@ __device__ __forceinline__ int edm_med3(int v, int lo, int hi) { return v < lo ?
 
 /* requantise 4 consecutive accumulators with ReLU and pack them into one HWC dword. The accumulators already hold the
  * seeds (bias << bias_lshift) + NN_ROUND(out_rshift): they are the C operand of each tile's first MFMA. */
-#ifndef EDM_SAT_PACK
-#define EDM_SAT_PACK 1
-#endif
 __device__ __forceinline__ uint32_t edm_pack_relu(int a0, int a1, int a2, int a3, int rs)
 {
-#if EDM_SAT_PACK
 	/* relu(ssat8(a >> rs)) = clamp(a >> rs, 0, 127) = clamp(a >> (rs - 1), 0, 255) >> 1 for rs >= 1 (arithmetic shifts compose
 	 * and 255 >> 1 = 127), and the clamp to 0..255 of two values at a time is what v_cvt_pk_i16_i32 (saturating to int16:
 	 * harmless in front of a tighter clamp) followed by v_sat_pk_u8_i16 does: 4 shifts + 2 + 2 + one merge + shift and mask
@@ -98,13 +100,6 @@ __device__ __forceinline__ uint32_t edm_pack_relu(int a0, int a1, int a2, int a3
 	asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q01) : "v"(p01));
 	asm("v_sat_pk_u8_i16 %0, %1" : "=v"(q23) : "v"(p23));
 	return (((q23 << 16) | q01) >> 1) & 0x7f7f7f7fu;
-#else
-	const uint32_t b0 = (uint32_t)edm_med3(a0 >> rs, 0, 127);
-	const uint32_t b1 = (uint32_t)edm_med3(a1 >> rs, 0, 127);
-	const uint32_t b2 = (uint32_t)edm_med3(a2 >> rs, 0, 127);
-	const uint32_t b3 = (uint32_t)edm_med3(a3 >> rs, 0, 127);
-	return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-#endif
 }
 
 /* The same for an output shift of exactly 8 (conv1 and conv2 of the shipped model), with or without the max-pool partner o:
@@ -142,7 +137,6 @@ __device__ __forceinline__ int edm_max(int a, int b) { return a > b ? a : b; }
 /* Weave: N times (1 MFMA, V VALU instructions) in the scheduling region that ends here. An MFMA holds vector issue for
  * 8 of its 32 cycles, so ~5 VALU instructions fit under each one (guide: cycle constants); placed in one block after
  * the MFMAs they would only start when the last MFMA has been issued. */
-#if EDM_INTERLEAVE
 #define EDM_WEAVE(N, V)                                                        \
 	_Pragma("unroll") for (int w_ = 0; w_ < (N); w_++)                           \
 	{                                                                           \
@@ -150,10 +144,6 @@ __device__ __forceinline__ int edm_max(int a, int b) { return a > b ? a : b; }
 		__builtin_amdgcn_sched_group_barrier(0x002, (V), 0);                     \
 	}
 #define EDM_FENCE()
-#else
-#define EDM_WEAVE(N, V)
-#define EDM_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 /* The four packed dwords of a lane are channels 8g + 4h .. +3 (g = 0..3): 4-byte pieces, 8 bytes apart, interleaved with
  * those of the lane 32 further up (h = 1). Stored one by one they hit LDS as ds_write_b32 at the pixel stride -- 8-way
@@ -684,7 +674,7 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
  * which have no group in a one-utterance launch.
  */
 #include "mfcc_one_frame.h"
-#define EDK1_MFCC_FLOATS(NLO, NHI) (ED_FIXTAB_FLOATS + ((NLO) + (NHI)) * 256 + ED_TWTAB_FLOATS + ED_XBUF_FLOATS)
+#define EDK1_MFCC_FLOATS(NLO, NHI) (ED_FIXTAB_FLOATS + ((NLO) + (NHI)) * 256 + ED_XBUF_FLOATS)
 
 template <int NLO, int NHI>
 __global__ __launch_bounds__(EDM_THREADS) void ed_kws1_kernel(ed_mfcc_args_t margs, const ed_mfcc_tables_t *__restrict__ tab,

@@ -76,6 +76,15 @@ __device__ __forceinline__ void en_conv(const ed_net_layer_t &L, const int8_t *i
  * that lanes still read consecutive weights) of EN_PB consecutive pixels. One activation read feeds 4 multiply-adds
  * and one weight read EN_PB: 4 + EN_PB loads per 4 * EN_PB instead of 8 * EN_PB. Taps outside the image contribute
  * a zero activation; a pixel tail recomputes the last pixel and stores it once. */
+/* ---- lab knobs: only a lab build (ED_LAB, tools/lab/mkvariant.py) may set them; the product build has none, and
+ * tests/test_host_cpu.py checks the values below against what edison_amd/build.py compiles */
+#if !defined(ED_LAB) && (defined(EN_PB))
+#error "EN_PB lab knob defined without ED_LAB (tools/lab/mkvariant.py builds lab variants)"
+#endif
+#if defined(ED_LAB)
+/* a lab build says so: the product library exports no ed_lab_build_* symbol (tests/test_host_cpu.py) */
+extern "C" { extern const int ed_lab_build_cnn_net; const int ed_lab_build_cnn_net = 1; }
+#endif
 #ifndef EN_PB
 #define EN_PB 2 /* 4 measured slower on the test graphs: too few work items left in the small late layers */
 #endif

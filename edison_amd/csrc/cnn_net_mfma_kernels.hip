@@ -33,6 +33,12 @@
  */
 /* -DEMM_JIT=1: this text is being compiled by hipRTC at run time (edison_net_specialize, edison_net_jit.hip) for one graph:
  * device code only, the headers come from the library's own copy of them, the kernel gets a C name */
+/* ---- lab knobs: only a lab build (ED_LAB, tools/lab/mkvariant.py) may set them; the product build has none, and
+ * tests/test_host_cpu.py checks the values below against what edison_amd/build.py compiles. (The run-time compiler of
+ * edison_net_specialize defines EMM_JIT / EMM_SPEC / EMM_SPEC_HEADER -- modes, not knobs -- and never ED_LAB.) */
+#if !defined(ED_LAB) && (defined(EMM_STAMP) || defined(EMM_SKIP) || defined(EMM_PB) || defined(EMM_PRIO))
+#error "EMM_* lab knob defined without ED_LAB (tools/lab/mkvariant.py builds lab variants)"
+#endif
 #ifndef EMM_JIT
 #define EMM_JIT 0
 #endif
@@ -45,6 +51,10 @@
 #include "../../include/edison_hip.h"
 #endif
 #include "edison_internal.h"
+#if defined(ED_LAB) && !EMM_JIT
+/* a lab build says so: the product library exports no ed_lab_build_* symbol (tests/test_host_cpu.py) */
+extern "C" { extern const int ed_lab_build_cnn_net_mfma; const int ed_lab_build_cnn_net_mfma = 1; }
+#endif
 
 /* diagnostic build only (-DEMM_STAMP=1, tools/lab): workgroup-level cycle stamps per phase into a debug buffer */
 #ifndef EMM_STAMP
@@ -173,9 +183,11 @@ __device__ __forceinline__ v4i emm_gather16(const lds8 *a, int soff, int keep)
  * down; lanes past the image fetch that same dword and drop it. (With byte loads under divergent branches for the tail
  * the compiler put a full vmcnt(0) behind every one of them -- inside the code that was meant to PREFETCH.) */
 #define EMM_PRE 2
-#ifndef EMM_PB
 /* images per wave the prefetch covers: 4 in a graph's own kernel (unused slots fold away), 2 here -- the general kernel sits at
  * its 168-register limit, two more images' registers go to scratch (+3 % at 2, measured on the planner's usual batch of 2) */
+#ifndef EMM_PB
+#define EMM_PB (EMM_SPEC ? 4 : 2)
+#endif
 /* A wave's priority rises with the layer it is in (the waves of a workgroup walk their own batches; see ED2_PRIO in
  * mfcc_kernels.hip): +9.5 % on the general kernel, +7.9 % on a graph's own (kws_conv, interleaved A/B). 0 = none; 3..6: lab */
 #ifndef EMM_PRIO
@@ -187,8 +199,6 @@ __device__ __forceinline__ v4i emm_gather16(const lds8 *a, int soff, int keep)
 	else if (p_ == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
 #else
 #define EMM_PR(li, n)
-#endif
-#define EMM_PB (EMM_SPEC ? 4 : 2)
 #endif
 __device__ __forceinline__ void emm_load_image(const int8_t *src, int in_n, int lane, uint32_t (&x)[EMM_PRE])
 {

@@ -17,13 +17,9 @@ extern "C" {
 #define ED_MEL_NHI_MAX 6  /* ... and for the wide band (shipped: 5; the widest band spans 19 quads / 4 lanes) */
 #define ED_MEL_TQ_MAX (ED_MEL_NLO_MAX + ED_MEL_NHI_MAX)
 #define ED_SPEC_QUADS 129 /* spectrum buffer = 513 bins padded to 516 floats                                  */
-/* The FFT's second digit transpose goes through LDS (1, default: the VALU and LDS pipes are then about equally
- * loaded) or through DPP exchanges (0, all-register FFT). It decides which spectrum index a lane ends up with:
- * lane l holds Z[ED_K0(l) + 64 r] in register r after the last pass. */
-#ifndef ED_T2_LDS
-#define ED_T2_LDS 1
-#endif
-#define ED_K0(l) (ED_T2_LDS ? (l) : (((l) >> 3) + 8 * ((l) & 7)))
+/* Which spectrum index a lane ends up with: lane l holds Z[ED_K0(l) + 64 r] in register r after the last pass (natural
+ * order: the FFT's second digit transpose goes through LDS; an all-register FFT would leave a digit-reversed order). */
+#define ED_K0(l) (l)
 
 typedef struct {
 	/* Per-lane register constants, lane-minor so that a wavefront loads each of them with one coalesced read.

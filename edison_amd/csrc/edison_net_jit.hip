@@ -183,12 +183,18 @@ static int compile_with_hipcc(edison_ctx *ctx, const char *spec, char **code, si
 		/* device code only, a plain ELF code object (no offload bundle). -pragma-unroll-threshold: the layer loop's body holds every
 		 * tile shape until it is unrolled and the layer records become constants; LLVM's default cap on a "#pragma unroll" refuses a
 		 * body that size, and everything the specialisation is for hangs on that unroll (335 -> 589 M inputs/s on kws_conv) */
-		/* EDISON_JIT_DEFINE=NAME=VALUE: one more -D for A/B work on the kernel's knobs (tools/lab; part of the cache key) */
+		/* the text the compiler gets is the product text: no knob is defined. (A LAB build of this file -- tools/lab/mkvariant.py
+		 * x=@edison_net_jit.hip -- passes EDISON_JIT_DEFINE=NAME=VALUE on as one more -D behind -DED_LAB, for A/B work on the
+		 * kernel's knobs; part of the cache key.) */
 		char extra[128];
+		const char *lab = "-DEMM_NO_LAB_DEFINE=1";
+		snprintf(extra, sizeof(extra), "-DEMM_NO_EXTRA_DEFINE=1");
+#ifdef ED_LAB
 		const char *xd = getenv("EDISON_JIT_DEFINE");
-		snprintf(extra, sizeof(extra), "-D%s", xd && xd[0] ? xd : "EMM_NO_EXTRA_DEFINE=1");
+		if (xd && xd[0]) { snprintf(extra, sizeof(extra), "-D%s", xd); lab = "-DED_LAB=1"; }
+#endif
 		const char *argv[] = {hipcc, "--offload-arch=gfx950", "--cuda-device-only", "--no-gpu-bundle-output", "-O3", "-std=c++17", "-fno-slp-vectorize",
-		                      "-DEMM_JIT=1", "-DEMM_SPEC=1", "-DEMM_SPEC_HEADER=\"emm_spec.h\"", extra, "-mllvm", "-pragma-unroll-threshold=1000000", "-include", "hip/hip_runtime.h", inc, "-x", "hip", "-c", src, "-o", out, NULL};
+		                      "-DEMM_JIT=1", "-DEMM_SPEC=1", "-DEMM_SPEC_HEADER=\"emm_spec.h\"", lab, extra, "-mllvm", "-pragma-unroll-threshold=1000000", "-include", "hip/hip_runtime.h", inc, "-x", "hip", "-c", src, "-o", out, NULL};
 		posix_spawn_file_actions_t fa;
 		posix_spawn_file_actions_init(&fa);
 		posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
@@ -309,7 +315,9 @@ static int specialize(edison_ctx *ctx, int cache_only)
 	source = fnv(source, ed_jit_src_edison_internal_h, ed_jit_src_edison_internal_h_len);
 	source = fnv(source, k_stdint_h, sizeof(k_stdint_h));
 	source = fnv(source, "pragma-unroll-threshold=1000000", 31); /* the compiler options are part of what a cache entry was made from */
+#ifdef ED_LAB
 	if (getenv("EDISON_JIT_DEFINE") && getenv("EDISON_JIT_DEFINE")[0]) source = fnv(source, getenv("EDISON_JIT_DEFINE"), strlen(getenv("EDISON_JIT_DEFINE")));
+#endif
 
 	const char *want = getenv("EDISON_JIT_COMPILER");
 	const int try_hipcc = !want || !want[0] || !strcmp(want, "hipcc"), try_rtc = !want || !want[0] || !strcmp(want, "hiprtc");

@@ -158,6 +158,15 @@ extern "C" int ed_launch_mfcc_f32(const ed_mfcc_f32_args_t *args, const ed_f32_t
  */
 #include "mfcc_fft.h"
 
+/* ---- lab knobs: only a lab build (ED_LAB, tools/lab/mkvariant.py) may set them; the product build has none, and
+ * tests/test_host_cpu.py checks the values below against what edison_amd/build.py compiles */
+#if !defined(ED_LAB) && (defined(EF2_WPB) || defined(EF2_PRIO))
+#error "EF2_* lab knob defined without ED_LAB (tools/lab/mkvariant.py builds lab variants)"
+#endif
+#if defined(ED_LAB)
+/* a lab build says so: the product library exports no ed_lab_build_* symbol (tests/test_host_cpu.py) */
+extern "C" { extern const int ed_lab_build_mfcc_f32; const int ed_lab_build_mfcc_f32 = 1; }
+#endif
 #ifndef EF2_WPB
 #define EF2_WPB 16 /* 4 waves per SIMD at 128 VGPRs: +4.5 % over 12 once the wave priorities are in (1.33-1.37 -> 1.40-1.41 G frames/s) */
 #endif
@@ -239,11 +248,7 @@ __global__ __launch_bounds__(64 * EF2_WPB) void ed_mfcc_f32_fast_kernel(ed_mfcc_
 		const uint32_t fA = 2 * pr, fB = fA + 1 < n_frames ? fA + 1 : fA;
 		const int16_t *pa = a.audio + (int64_t)fA * a.frame_step, *pb = a.audio + (int64_t)fB * a.frame_step;
 #pragma unroll
-#ifdef EF2_LOAD_NT /* lab: non-temporal loads (frames overlap by half at hop 256: every sample is read by two frames) */
-		for (int q = 0; q < 8; q++) { xa[q] = __builtin_nontemporal_load(pa + off0[q]); ya[q] = __builtin_nontemporal_load(pa + off1[q]); xb[q] = __builtin_nontemporal_load(pb + off0[q]); yb[q] = __builtin_nontemporal_load(pb + off1[q]); }
-#else
 		for (int q = 0; q < 8; q++) { xa[q] = pa[off0[q]]; ya[q] = pa[off1[q]]; xb[q] = pb[off0[q]]; yb[q] = pb[off1[q]]; }
-#endif
 	};
 
 	uint32_t i_cur = wave, i_next = wave + EF2_WPB;

@@ -13,8 +13,8 @@
  *                transposes swaps the register index with three lane-index bits. Transpose 1 (lane bits 3-5) is a
  *                butterfly exchange on the VALU: v_permlane32_swap / v_permlane16_swap for bits 5 / 4, DPP
  *                row_shr/row_shl:8 with bank masks for bit 3. Transpose 2 (lane bits 0-2) goes through a padded
- *                wave-private LDS buffer (ED_T2_LDS = 1, default) -- with both transposes in LDS the write-heavy
- *                LDS pipe saturates, with both on the VALU (ED_T2_LDS = 0: DPP row_shr/shl:4 and quad_perm +
+ *                wave-private LDS buffer -- with both transposes in LDS the write-heavy
+ *                LDS pipe saturates, with both on the VALU (DPP row_shr/shl:4 and quad_perm +
  *                select) the VALU does; split, the two pipes are about equally loaded.
  *   3. split     X[k] = E[k] + W1024^k O[k] from Z[k], conj Z[512-k]; lane handles the pair (k, 512-k); the
  *                partner value comes through ds_bpermute (LDS crossbar, no LDS memory)
@@ -65,104 +65,41 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
  * LDS per wave: 526 transpose slots of 16 B (re A, re B, im A, im B: register pairs stay pairs), the two spectra interleaved as float2[516]
  * behind them (aliased like above), the DCT inputs of both frames.
  */
-#ifndef ED2_WPB
-#define ED2_WPB 12  /* wavefronts per workgroup = per CU: 3 per SIMD (150 VGPRs, 116 KB LDS) */
-#endif
 #define ED2_S_OFF 1088    /* float offset of the interleaved spectra: their zero padding lies beyond the 2104 transpose floats */
 #define ED2_L_OFF 2128
 #define ED2_XBUF_FLOATS 2208
-/* timing-only ablations for A/B work (results are WRONG when non-zero): 1 = the frames of the first pair are reused
- * (no HBM reads in the loop), 2 = no arithmetic (loads, one xor per dword, store) */
-#ifndef ED2_ABLATE
-#define ED2_ABLATE 0
+
+/* ---- what a lab build may change (tools/lab/mkvariant.py defines ED_LAB; the product build must not: tests/test_host_cpu.py
+ * preprocesses this file as edison_amd/build.py compiles it and checks every value below). Everything that was measured and
+ * decided in rounds 1-3 (transposes on the VALU / in LDS, twiddles in LDS, queue forms, barrier placements, phase ablations)
+ * is no longer a switch: the decisions are in DESIGN.md section 4.1, the loop below is the one that ships. */
+#if !defined(ED_LAB) && (defined(ED2_WPB) || defined(ED2_STAGGER_SLEEP) || defined(ED2_PRIO) || defined(ED2_STAMP))
+#error "ED2_* lab knob defined without ED_LAB: the product build has no knobs (tools/lab/mkvariant.py builds lab variants)"
 #endif
-#ifndef ED2_MEL_SWAP
-#define ED2_MEL_SWAP 1
+#if defined(ED_LAB)
+/* a lab build says so: the product library exports no ed_lab_build_* symbol (tests/test_host_cpu.py) */
+extern "C" { extern const int ed_lab_build_mfcc; const int ed_lab_build_mfcc = 1; }
 #endif
-/* timing-only ablations by phase (tools/lab; results are WRONG when non-zero): 1 transpose 1, 2 transpose 2, 4 the three
- * radix-8 passes and their twiddles, 8 ds_bpermute, 16 sqrt, 32 mel reads + fma, 64 split arithmetic, 128 spectrum
- * write, 256 int16 -> float conversion */
-#ifndef ED2_SKIP
-#define ED2_SKIP 0
-#endif
-#ifndef ED2_T1_LDS
-#define ED2_T1_LDS 0      /* 1: transpose 1 through LDS as well (ds_write/read_b128) instead of VALU swaps + DPP */
-#endif
-#ifndef ED2_TW_LDS
-#define ED2_TW_LDS 0      /* 1: pass-1/2 twiddles read from LDS (14 ds_read_b64 per pair) instead of 28 registers */
-#endif
-#define ED2_TWTAB_FLOATS (ED2_TW_LDS ? 2 * 7 * 64 * 2 : 0)
-#ifndef ED2_LANE0_BRANCH
-#define ED2_LANE0_BRANCH 1
-#endif
-#ifndef ED2_TABLES_FIRST
-#define ED2_TABLES_FIRST 0 /* 1: prologue issues the table loads before the first pair's sample loads */
-#endif
-#ifndef ED2_UNPACK_SB
-#define ED2_UNPACK_SB 0   /* 1: scheduling barrier between the unpack and the next pair's loads */
-#endif
-#ifndef ED2_LOG_BRANCH
-#define ED2_LOG_BRANCH 1  /* 1: ln() of the mel energies sits behind a wave-uniform branch; if-converted (the compiler's choice) variant B
-                           * executes the whole logf expansion, 15 vector instructions per pair, for a select that never takes it */
-#endif
-#ifndef ED2_ASM_QUEUE
-#define ED2_ASM_QUEUE 1   /* 1: the work-queue draw is one exec-masked ds_add_rtn_u32 written in asm. The builtin atomic goes through the
-                           * compiler's wave-aggregation scheme (v_mbcnt x 2, s_bcnt1, readfirstlane, two exec-mask blocks) and waits for
-                           * the LDS round trip on the spot */
-#endif
-#ifndef ED2_LATE_BARRIER
-#define ED2_LATE_BARRIER 0 /* 1: the workgroup barrier behind the table staging moves into a wave's FIRST iteration, in front of the first
-                            * use of the LDS tables (the split twiddles): a wave starts its first passes as soon as ITS OWN samples have
-                            * arrived instead of when the slowest of the 12 waves' have (48 KB per CU at ~10 B/clk = 2 us after launch) */
-#endif
-#ifndef ED2_STAGGER
-#define ED2_STAGGER 1     /* 1: no workgroup barrier behind the table staging. The first four waves of the workgroup (one per SIMD) stage
-                           * the tables and raise a counter in LDS; every wave checks that counter once, in front of its first use of the
-                           * tables (the split of its first pair), by which time it has long been raised. Wave groups 1 and 2 issue their
-                           * first sample loads a few hundred cycles later than group 0, so that group 0's samples are not queued behind
-                           * theirs: a SIMD starts computing ~1.5 us after launch instead of when the last of the CU's 48 KB has arrived. */
-#endif
-#ifndef ED2_LATE_DRAW
-#define ED2_LATE_DRAW 1   /* 1: a wave owns TWO pairs at a time (the one it computes and the one whose samples it prefetches) instead of
-                           * three: the draw is issued at the top of an iteration, read behind pass 1, and the prefetch of the drawn pair
-                           * goes out there. With the draw a whole iteration ahead, the last 24 pairs of a CU sat reserved in the youngest
-                           * (slowest) waves while the older ones had retired: loop ends 38 .. 46 us after launch (stamps). Needs
-                           * ED2_CVT_END and ED2_ASM_QUEUE. */
-#endif
-#if ED2_STAGGER && (ED2_TABLES_FIRST || ED2_TW_LDS)
-/* measured the hard way (round 3, a lab build that never returned): with ED2_STAGGER the tables are staged by the first four
- * waves, which then count in LDS; the ED2_TABLES_FIRST staging loop does not count (every wave would poll for ever) and the
- * ED2_TW_LDS twiddles are read before the poll */
-#error "ED2_STAGGER needs ED2_TABLES_FIRST = 0 and ED2_TW_LDS = 0"
+#ifndef ED2_WPB
+#define ED2_WPB 12  /* wavefronts per workgroup = per CU: 3 per SIMD (160 VGPRs, 116 KB LDS) */
 #endif
 #ifndef ED2_STAGGER_SLEEP
-#define ED2_STAGGER_SLEEP 8 /* s_sleep units (64 cycles each) per wave group */
+#define ED2_STAGGER_SLEEP 8 /* s_sleep units (64 cycles each) between the first sample loads of the wave groups, see the prologue */
 #endif
-#ifndef ED2_CVT_END
-#define ED2_CVT_END 1     /* 1: the int16 -> float unpack of the NEXT pair runs at the bottom of an iteration, so the values carried
-                           * around the loop are the 32 floats the passes start from. With the unpack at the top the compiler sinks it
-                           * below the prefetch, gives the prefetch a second set of 16 registers and copies it back at the loop latch
-                           * (16 v_mov_b32 per pair). */
-#endif
-
-/* Wave priorities (round 3): s_setprio at the phase boundaries of ed_mfcc2_kernel's loop, two bits per boundary (boundary i = end of
- * phase i: 0 unpack + loads of the next pair, 1 pass 1, 2 transpose 1, 3 pass 2, 4 transpose 2 (LDS), 5 pass 3, 6 split, 7 spectrum
- * to LDS, 8 mel, 9 fold, 10 DCT (LDS), 11 store). A SIMD issues from its oldest ready wave; with equal priorities the three waves
- * of a SIMD end up in the same phase (all in their arithmetic, then all waiting for LDS) -- a priority that RISES with the progress
- * through a pair (0 in pass 1, 1 in pass 2, 2 in pass 3, 3 from the split to the next pair's loads) lets the wave that is ahead
- * stay ahead, so the waves spread over the phases and one wave's LDS phases lie under the others' arithmetic: +5.3 ... +6.1 %
- * (interleaved A/B on three boxes, tools/lab/ab_mfcc.py; bit-identical). The gradient over the three passes is what counts: high
- * priority for the tail alone, or for the memory phases alone, gives +0.1 ... +0.9 %, the reverse order -0.3 %. 0 = none. */
+/* Wave priorities (round 3): s_setprio at the phase boundaries of the loop, two bits per boundary (boundary i = end of phase i:
+ * 0 unpack + loads of the next pair, 1 pass 1, 2 transpose 1, 3 pass 2, 4 transpose 2 (LDS), 5 pass 3, 6 split, 7 spectrum to
+ * LDS, 8 mel, 9 fold, 10 DCT (LDS), 11 store). A SIMD issues from its oldest ready wave; with equal priorities the three waves
+ * of a SIMD end up in the same phase (all in their arithmetic, then all waiting for LDS) -- a priority that RISES with the
+ * progress through a pair (0 in pass 1, 1 in pass 2, 2 in pass 3, 3 from the split to the next pair's loads) lets the wave that
+ * is ahead stay ahead, so the waves spread over the phases and one wave's LDS phases lie under the others' arithmetic:
+ * +5.3 ... +7.0 % (interleaved A/B on six boxes, profiles/r03_wave_priorities.txt; bit-identical). 0 = none. */
 #ifndef ED2_PRIO
 #define ED2_PRIO 0xfffa50
 #endif
-/* Diagnostic build only (-DED2_STAMP=1, tools/lab): s_memtime stamps at the phase boundaries of ed_mfcc2_kernel; per-wave
- * cycle sums per phase go to a debug buffer that nothing else reads. The product build contains no stamp. */
+/* 1 / 2: diagnostic builds with s_memtime stamps (1: at every phase boundary, 2: around the loop only); per-wave cycle sums go
+ * to a debug buffer that nothing else reads (tools/lab/stamp_run.py). The product build contains no stamp. */
 #ifndef ED2_STAMP
 #define ED2_STAMP 0
-#endif
-#if ED2_LATE_DRAW && !(ED2_CVT_END && ED2_ASM_QUEUE)
-#error "ED2_LATE_DRAW needs ED2_CVT_END and ED2_ASM_QUEUE"
 #endif
 #if ED2_STAMP
 #define ED2_NPH 17
@@ -178,7 +115,7 @@ __device__ __forceinline__ unsigned long long ed2_now()
 }
 #if ED2_STAMP == 1
 #define ED2_ST(i) { const unsigned long long n_ = ed2_now(); ph[i] += n_ - tlast; tlast = n_; }
-#else /* 2: only the loop as a whole (clock, fixed cost per launch) */
+#else
 #define ED2_ST(i)
 #endif
 #elif ED2_PRIO
@@ -213,50 +150,50 @@ __device__ __forceinline__ void ed_pair_ptrs(const ed_mfcc_args_t &a, uint32_t p
  * them to its waves through a counter in LDS (ds_add_rtn_u32): a wave that runs faster simply draws more pairs. With a
  * static stride per wave the kernel drained unevenly -- the SIMD arbitrates VALU issue by age, so the waves of the
  * workgroups dispatched first ran their pairs in 3.0 us each, the youngest third in 4.6 us, and the last 25 % of the
- * launch ran with a third of the waves (profiles/r02_mfcc_timeline.txt). The draw for the pair after next is issued at
- * the top of an iteration and read at its end, so the LDS round trip is never waited for.
+ * launch ran with a third of the waves (profiles/r02_mfcc_timeline_static_stride.txt). A wave owns TWO pairs at a time -- the one
+ * it computes and the one whose samples it prefetches: the draw (one exec-masked ds_add_rtn_u32 in asm; the builtin atomic goes
+ * through the compiler's wave-aggregation code and waits on the spot) is issued at the top of an iteration, read behind pass 1
+ * (~450 cycles later, never waited for), and the drawn pair's sample loads go out there. With the draw a whole iteration ahead
+ * the last pairs of a CU sat reserved in its slowest waves while the others had retired.
+ * Across CUs the slices are static: a rank-based pool at the end of the batch (one device atomic per workgroup) levels the
+ * workgroups' finishing times and buys nothing -- the board sits at its power cap and takes the recovered idle time back as
+ * clock (profiles/r04_mfcc_launch_structure_notes.txt).
  */
-#ifdef ED2_WAVES_PER_EU
-#define ED2_OCC __attribute__((amdgpu_waves_per_eu(ED2_WAVES_PER_EU, ED2_WAVES_PER_EU)))
-#else
-#define ED2_OCC
-#endif
 template <bool ALIGNED, bool PLAIN, int NLO, int NHI>
-__global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
+__global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
 {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#ifdef ED2_PRIO_FIXED /* lab: a fixed priority per wave of a SIMD instead of one that follows the progress (build with -DED2_PRIO=0) */
-	if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1); else if ((wave >> 2) >= 2) __builtin_amdgcn_s_setprio(2);
-#endif
 	const float4 *dctl = reinterpret_cast<const float4 *>(smem);                     /* [2][64] x 4 coefficients */
 	const float2 *tpl = reinterpret_cast<const float2 *>(smem + 512);                /* [4][64] split twiddles   */
 	const float4 *melw4 = reinterpret_cast<const float4 *>(smem + ED_FIXTAB_FLOATS); /* [NLO+NHI][64] quads      */
-	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_TWTAB_FLOATS + wave * ED2_XBUF_FLOATS; /* wave-private */
-	unsigned *queue = reinterpret_cast<unsigned *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_TWTAB_FLOATS + ED2_WPB * ED2_XBUF_FLOATS);
-	const uint32_t queue_addr = (uint32_t)(sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_TWTAB_FLOATS + ED2_WPB * ED2_XBUF_FLOATS)); /* its LDS byte address (dynamic LDS starts at 0: the kernel has no static LDS) */
-	(void)queue_addr;
+	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + wave * ED2_XBUF_FLOATS; /* wave-private */
+	unsigned *queue = reinterpret_cast<unsigned *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_WPB * ED2_XBUF_FLOATS);
+	const uint32_t queue_addr = (uint32_t)(sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_WPB * ED2_XBUF_FLOATS)); /* its LDS byte address (dynamic LDS starts at 0: the kernel has no static LDS) */
 #if ED2_STAMP
 	unsigned long long rt_entry;
 	asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_entry) :: "memory");
 #endif
 
-	/* this workgroup's slice of the pairs; slots 0..WPB-1 and WPB..2WPB-1 of it are the waves' first two pairs */
+	/* this workgroup's slice of the pairs; its first WPB pairs are the waves' first pairs, the rest is drawn from the queue */
 	const uint32_t n_frames = (uint32_t)args.n_frames;
 	const uint32_t n_pairs = (n_frames + 1) >> 1;
 	const uint32_t s0 = (uint32_t)(((uint64_t)blockIdx.x * n_pairs) / gridDim.x);
 	const uint32_t cnt = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_pairs) / gridDim.x) - s0;
-	uint32_t i_cur = wave, i_next = wave + ED2_WPB;
+	uint32_t i_cur = wave, i_next;
 	uint32_t rawA[8], rawB[8];
-#if ED2_STAGGER
-	/* queue and staging counter are initialised behind a barrier that costs nothing: no wave has asked memory for anything yet */
-	if (threadIdx.x == 0) { queue[0] = (ED2_LATE_DRAW ? 1 : 2) * ED2_WPB; queue[1] = 0; }
+	/* No workgroup barrier behind the table staging: the first four waves (one per SIMD) stage the tables and raise a counter in
+	 * LDS; every wave checks that counter once, in front of its first use of the tables (the split of its first pair), by which
+	 * time it has long been raised. Queue and staging counter are initialised behind a barrier that costs nothing -- no wave has
+	 * asked memory for anything yet -- and wave groups 1 and 2 issue their first sample loads a few hundred cycles later than
+	 * group 0, so that group 0's samples are not queued behind theirs: a SIMD starts computing ~1.5 us after launch instead of
+	 * when the last of the CU's 48 KB has arrived. (A barrier in front of the first split instead: -1.4 %, the fast waves wait
+	 * there for the slowest.) */
+	if (threadIdx.x == 0) { queue[0] = ED2_WPB; queue[1] = 0; }
 	__syncthreads();
 	if (wave >= 4) __builtin_amdgcn_s_sleep(ED2_STAGGER_SLEEP);
 	if (wave >= 8) __builtin_amdgcn_s_sleep(ED2_STAGGER_SLEEP);
-#endif
-#if !ED2_TABLES_FIRST
 	if (i_cur < cnt)
 	{
 		const int16_t *pa, *pb;
@@ -264,21 +201,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		ed_load_frame<ALIGNED>(pa, lane, rawA);
 		ed_load_frame<ALIGNED>(pb, lane, rawB);
 	}
-#endif
 	/* every table load of the prologue goes in flight before the first wait */
-#if ED2_TW_LDS
-	/* per-lane twiddle tables [q - 1][lane] as float2, conflict-free ds_read_b64 */
-	const float2 *tw1l = reinterpret_cast<const float2 *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256) + lane;
-	const float2 *tw2l = tw1l + 7 * 64;
-	{
-		float2 *dst = reinterpret_cast<float2 *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256);
-		for (int t = threadIdx.x; t < 7 * 64; t += 64 * ED2_WPB)
-		{
-			dst[t] = *reinterpret_cast<const float2 *>(&tab->tw1[1 + t / 64][t & 63][0]);
-			dst[7 * 64 + t] = *reinterpret_cast<const float2 *>(&tab->tw2[1 + t / 64][t & 63][0]);
-		}
-	}
-#else
 	float t1r[8], t1i[8], t2r[8], t2i[8];
 #pragma unroll
 	for (int q = 1; q < 8; q++)
@@ -287,7 +210,6 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		const float2 b = *reinterpret_cast<const float2 *>(&tab->tw2[q][lane][0]);
 		t1r[q] = a.x; t1i[q] = a.y; t2r[q] = b.x; t2i[q] = b.y;
 	}
-#endif
 	const int mel_slo4 = tab->mel_slo4[lane], mel_shi4 = tab->mel_shi4[lane];
 	const int band = tab->mel_band[lane]; /* this column's narrow band b; its wide band is 31 - b */
 	const int mel_half = tab->mel_half[lane];
@@ -301,33 +223,6 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		 * stage), so their weight quads are stored (z, w, x, y); quad t belongs to lane t & 63 (ED_FIXTAB_FLOATS / 4 is
 		 * a multiple of 64) and threadIdx.x + k * blockDim.x keeps that lane: the flag is this thread's own mel_half */
 		static_assert((64 * ED2_WPB) % 64 == 0 && (ED_FIXTAB_FLOATS / 4) % 64 == 0, "weight quad <-> lane mapping");
-#if ED2_TABLES_FIRST
-		/* table loads first (L2 hits, needed before the barrier), the first pair's samples behind them (HBM, needed
-		 * after it): vector-memory results return in issue order, so the other order makes the barrier wait for HBM */
-		constexpr int NT = (n4 + 64 * ED2_WPB - 1) / (64 * ED2_WPB);
-		float4 tv[NT];
-#pragma unroll
-		for (int k = 0; k < NT; k++)
-		{
-			const int t = threadIdx.x + k * 64 * ED2_WPB;
-			tv[k] = src[t < n4 ? t : 0];
-		}
-		if (i_cur < cnt)
-		{
-			const int16_t *pa, *pb;
-			ed_pair_ptrs<PLAIN>(args, s0 + i_cur, pa, pb);
-			ed_load_frame<ALIGNED>(pa, lane, rawA);
-			ed_load_frame<ALIGNED>(pb, lane, rawB);
-		}
-#pragma unroll
-		for (int k = 0; k < NT; k++)
-		{
-			const int t = threadIdx.x + k * 64 * ED2_WPB;
-			float4 v = tv[k];
-			if (ED2_MEL_SWAP && t >= ED_FIXTAB_FLOATS / 4 && mel_half) v = make_float4(v.z, v.w, v.x, v.y);
-			if (t < n4) dst[t] = v;
-		}
-#elif ED2_STAGGER
 		if (wave < 4)
 		{
 			/* thread t of the first 256 stages quads t, t + 256, t + 512: quad <-> lane mapping as above (256 % 64 == 0) */
@@ -344,35 +239,20 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 			{
 				const int t = threadIdx.x + k * 256;
 				float4 v = tv[k];
-				if (ED2_MEL_SWAP && t >= ED_FIXTAB_FLOATS / 4 && mel_half) v = make_float4(v.z, v.w, v.x, v.y);
+				if (t >= ED_FIXTAB_FLOATS / 4 && mel_half) v = make_float4(v.z, v.w, v.x, v.y);
 				if (t < n4) dst[t] = v;
 			}
 			/* this wave's stores are complete (release) before its count: a wave's DS operations execute in order */
 			if (lane == 0) __hip_atomic_fetch_add(queue + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
-#else
-		for (int t = threadIdx.x; t < n4; t += 64 * ED2_WPB)
-		{
-			float4 v = src[t];
-			if (ED2_MEL_SWAP && t >= ED_FIXTAB_FLOATS / 4 && mel_half) v = make_float4(v.z, v.w, v.x, v.y);
-			dst[t] = v;
-		}
-#endif
-#if !ED2_STAGGER
-		if (threadIdx.x == 0) *queue = (ED2_LATE_DRAW ? 1 : 2) * ED2_WPB;
-#endif
 	}
-#if ED2_LATE_BARRIER || ED2_STAGGER
 	bool staged = false;
-#else
-	__syncthreads();
-#endif
 	/* where this lane puts its DCT input (float index into Lb2 = float2 u[16] | v[16]): rows 0/1 hold frame A's
 	 * u/v of the column's band, rows 2/3 frame B's */
 	const int l_idx = 2 * (16 * ((lane >> 4) & 1) + band) + (lane >> 5);
 	const int k0 = ED_K0(lane);
 	const int k0p = (64 - k0) & 63;
-	const int pull = (ED_T2_LDS ? k0p : (((k0p & 7) << 3) | (k0p >> 3))) << 2;
+	const int pull = k0p << 2;
 	const int hi3 = lane >> 3, lo3 = lane & 7;
 	float4 *xc4 = reinterpret_cast<float4 *>(xbuf);
 	ed_f2 *S2 = reinterpret_cast<ed_f2 *>(xbuf + ED2_S_OFF);
@@ -387,7 +267,6 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 	unsigned long long tlast = tfirst;
 #endif
 	ed_f2 re[8], im[8];
-#if ED2_CVT_END
 	if (i_cur < cnt)
 	{
 #pragma unroll
@@ -397,78 +276,31 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
 		}
 	}
-#endif
 	while (i_cur < cnt)
 	{
 		const uint32_t fA = 2 * (s0 + i_cur);
 		const bool haveB = fA + 1 < n_frames;
-		/* ---- 1. unpack both frames, put the next pair's loads in flight, draw the pair after next */
-#if !ED2_CVT_END
-#pragma unroll
-		for (int a = 0; a < 8; a++)
-		{
-			re[a] = ed_mk2((float)(int16_t)(rawA[a] & 0xffffu), (float)(int16_t)(rawB[a] & 0xffffu));
-			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
-			if (ED2_SKIP & 256) { re[a] = ed_mk2(__uint_as_float(rawA[a]), __uint_as_float(rawB[a])); im[a] = re[a]; }
-		}
-#endif
-		if (ED2_UNPACK_SB) __builtin_amdgcn_sched_barrier(0);
-		if (!(ED2_ABLATE & 1) && !ED2_LATE_DRAW)
-		{
-			/* unconditional: a conditional load makes the frame registers a merge of two definitions and costs 16
-			 * copies per iteration; a wave's last iteration re-reads the slice's last pair instead (L2 hits) */
-			const int16_t *pa, *pb;
-			ed_pair_ptrs<PLAIN>(args, s0 + (i_next < cnt ? i_next : cnt - 1), pa, pb);
-			ed_load_frame<ALIGNED>(pa, lane, rawA);
-			ed_load_frame<ALIGNED>(pb, lane, rawB);
-		}
+		/* ---- 1. draw the next pair (read behind pass 1) */
 		uint32_t drawn = 0;
-#if ED2_ASM_QUEUE
 		if (lane == 0)
 			asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(drawn) : "v"(queue_addr), "v"(1u) : "memory");
-#else
-		if (lane == 0) drawn = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-		if (ED2_ABLATE & 1)
-		{
-#pragma unroll
-			for (int a = 0; a < 8; a++) asm volatile("" : "+v"(rawA[a]), "+v"(rawB[a])); /* keeps the unpack in the loop */
-		}
-		if (ED2_ABLATE & 2)
-		{
-			ed_f2 acc = re[0] + im[0];
-#pragma unroll
-			for (int a = 1; a < 8; a++) acc += re[a] + im[a];
-			if (lane < args.n_coef && args.mfcc)
-			{
-				args.mfcc[(int64_t)fA * args.n_coef + lane] = acc.x;
-				if (haveB) args.mfcc[(int64_t)(fA + 1) * args.n_coef + lane] = acc.y;
-			}
-			i_cur = i_next; i_next = __builtin_amdgcn_readfirstlane(drawn);
-			continue;
-		}
 
 		ED2_ST(0)
 		/* ---- 2a. pass 1 + twiddle W512^(lane*p) */
-		if (!(ED2_SKIP & 4)) ed_radix8_2(re, im);
+		ed_radix8_2(re, im);
 #pragma unroll
-		for (int q = 1; q < 8 && !(ED2_SKIP & 4); q++)
+		for (int q = 1; q < 8; q++)
 		{
-#if ED2_TW_LDS
-			const float2 w_ = tw1l[64 * (q - 1)];
-			const ed_f2 wr = ed_splat(w_.x), wi = ed_splat(w_.y);
-#else
 			const ed_f2 wr = ed_splat(t1r[q]), wi = ed_splat(t1i[q]);
-#endif
 			const ed_f2 xr = re[q], xi = im[q];
 			re[q] = xr * wr - xi * wi;
 			im[q] = xr * wi + xi * wr;
 		}
-#if ED2_LATE_DRAW
 		{
 			/* the draw issued at the top has returned (~450 cycles of pass 1 ago): the drawn pair's samples go in flight now
-			 * and have the rest of the iteration to arrive. Unconditional (see above): past the end of the slice the last
-			 * pair is re-read from L2 and thrown away. */
+			 * and have the rest of the iteration to arrive. Unconditional -- a conditional load makes the frame registers a
+			 * merge of two definitions and costs 16 copies per iteration (-12 % measured): past the end of the slice the
+			 * slice's last pair is re-read from L2 and thrown away. */
 			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(drawn));
 			i_next = __builtin_amdgcn_readfirstlane(drawn);
 			const int16_t *pa, *pb;
@@ -476,41 +308,18 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 			ed_load_frame<ALIGNED>(pa, lane, rawA);
 			ed_load_frame<ALIGNED>(pb, lane, rawB);
 		}
-#endif
 		ED2_ST(1)
-#if ED2_T1_LDS
-		/* transpose 1 through LDS: (lane 8b+c, reg p) -> (lane 8p+c, reg b); slot 64b + 8p + c: the ds_write_b128 of a
-		 * lane group (8 consecutive lanes) and the ds_read_b128 (slot 64b' + lane) are both conflict-free */
-#pragma unroll
-		for (int q = 0; q < 8; q++) xc4[64 * hi3 + lo3 + 8 * q] = make_float4(re[q].x, re[q].y, im[q].x, im[q].y);
-		ed_wave_sync();
-#pragma unroll
-		for (int b = 0; b < 8; b++)
-		{
-			const float4 v = xc4[64 * b + lane];
-			re[b] = ed_mk2(v.x, v.y); im[b] = ed_mk2(v.z, v.w);
-		}
-		ed_wave_sync();
-#else
-		if (!(ED2_SKIP & 1))
-		{
-			ed_transpose8_2<3, 4, 5>(re, lane);
-			ed_transpose8_2<3, 4, 5>(im, lane);
-		}
-#endif
+		/* transpose 1 on the VALU (lane bits 3-5): with both transposes in LDS the LDS pipe saturates (-5.5 % with the priorities on) */
+		ed_transpose8_2<3, 4, 5>(re, lane);
+		ed_transpose8_2<3, 4, 5>(im, lane);
 
 		ED2_ST(2)
 		/* ---- 2b. pass 2 + twiddle W64^(c*q) */
-		if (!(ED2_SKIP & 4)) ed_radix8_2(re, im);
+		ed_radix8_2(re, im);
 #pragma unroll
-		for (int q = 1; q < 8 && !(ED2_SKIP & 4); q++)
+		for (int q = 1; q < 8; q++)
 		{
-#if ED2_TW_LDS
-			const float2 w_ = tw2l[64 * (q - 1)];
-			const ed_f2 wr = ed_splat(w_.x), wi = ed_splat(w_.y);
-#else
 			const ed_f2 wr = ed_splat(t2r[q]), wi = ed_splat(t2i[q]);
-#endif
 			const ed_f2 xr = re[q], xi = im[q];
 			re[q] = xr * wr - xi * wi;
 			im[q] = xr * wi + xi * wr;
@@ -520,10 +329,10 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		 * 66c + p + 8q keeps the ds_write_b128 (8-lane groups, stride 66 slots = 8 banks mod 64) and the ds_read_b128
 		 * (consecutive slots) free of bank conflicts */
 #pragma unroll
-		for (int q = 0; q < 8 && !(ED2_SKIP & 2); q++) xc4[66 * lo3 + hi3 + 8 * q] = make_float4(re[q].x, re[q].y, im[q].x, im[q].y); /* pairs stay pairs */
+		for (int q = 0; q < 8; q++) xc4[66 * lo3 + hi3 + 8 * q] = make_float4(re[q].x, re[q].y, im[q].x, im[q].y); /* pairs stay pairs */
 		ed_wave_sync();
 #pragma unroll
-		for (int c = 0; c < 8 && !(ED2_SKIP & 2); c++)
+		for (int c = 0; c < 8; c++)
 		{
 			const float4 v = xc4[66 * c + lane];
 			re[c] = ed_mk2(v.x, v.y); im[c] = ed_mk2(v.z, v.w);
@@ -532,10 +341,9 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 
 		ED2_ST(4)
 		/* ---- 2c. pass 3: reg r holds Z[k0 + 64r] of both frames */
-		if (!(ED2_SKIP & 4)) ed_radix8_2(re, im);
+		ed_radix8_2(re, im);
 
 		ED2_ST(5)
-#if ED2_STAGGER
 		if (!staged)
 		{
 			/* first use of the LDS tables (split twiddles, then mel, DCT): all four staging waves must have counted */
@@ -543,25 +351,17 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 				__builtin_amdgcn_s_sleep(1);
 			staged = true;
 		}
-#elif ED2_LATE_BARRIER
-		if (!staged) { __syncthreads(); staged = true; } /* first use of the LDS tables (split twiddles, then mel, DCT) */
-#endif
 		/* ---- 3. real-FFT split (see ed_mfcc_kernel); the partner values come per frame through ds_bpermute */
 		ed_f2 slo[4], shi[4];
 		ed_f2 pzr_[4], pzi_[4];
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 		{
-			if (!(ED2_SKIP & 8))
-			{
-				pzr_[m].x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].x)));
-				pzr_[m].y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].y)));
-				pzi_[m].x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].x)));
-				pzi_[m].y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].y)));
-			}
-			if (ED2_SKIP & 8) { pzr_[m] = re[7 - m]; pzi_[m] = im[7 - m]; }
+			pzr_[m].x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].x)));
+			pzr_[m].y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(re[7 - m].y)));
+			pzi_[m].x = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].x)));
+			pzi_[m].y = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(im[7 - m].y)));
 		}
-#if ED2_LANE0_BRANCH
 		/* lane 0 is its own partner, one register further up: ONE exec-masked block of 16 v_mov_b32 (2.5 cycles each)
 		 * instead of 16 v_cndmask_b32_e64 (4.4 each) -- the empty asm keeps the compiler from if-converting it back */
 		if (lane == 0)
@@ -570,15 +370,10 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 #pragma unroll
 			for (int m = 0; m < 4; m++) { pzr_[m] = re[(8 - m) & 7]; pzi_[m] = im[(8 - m) & 7]; }
 		}
-#endif
 #pragma unroll
 		for (int m = 0; m < 4; m++)
 		{
 			ed_f2 pzr = pzr_[m], pzi = pzi_[m];
-#if !ED2_LANE0_BRANCH
-			if (lane == 0) { pzr = re[(8 - m) & 7]; pzi = im[(8 - m) & 7]; }
-#endif
-			if (ED2_SKIP & 64) { slo[m] = re[m] + pzr; shi[m] = im[m] + pzi; continue; }
 			const float2 tw = tpl[64 * m + lane];
 			const ed_f2 twx = ed_splat(tw.x), twy = ed_splat(tw.y);
 			const ed_f2 ar = re[m] + pzr, ai = im[m] - pzi;
@@ -590,7 +385,6 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 			const ed_f2 e0 = xr * xr + xi * xi, e1 = yr * yr + yi * yi;
 			slo[m] = ed_mk2(__builtin_amdgcn_sqrtf(e0.x), __builtin_amdgcn_sqrtf(e0.y));
 			shi[m] = ed_mk2(__builtin_amdgcn_sqrtf(e1.x), __builtin_amdgcn_sqrtf(e1.y));
-			if (ED2_SKIP & 16) { slo[m] = e0; shi[m] = e1; }
 		}
 		const ed_f2 e256 = re[4] * re[4] + im[4] * im[4];
 		const ed_f2 s256 = ed_mk2(2.0f * __builtin_amdgcn_sqrtf(e256.x), 2.0f * __builtin_amdgcn_sqrtf(e256.y));
@@ -598,7 +392,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		ED2_ST(6)
 		/* ---- 4. both spectra to LDS, interleaved: S2[k] = (|2X_A[k]|, |2X_B[k]|) */
 #pragma unroll
-		for (int m = 0; m < 4 && !(ED2_SKIP & 128); m++)
+		for (int m = 0; m < 4; m++)
 		{
 			S2[k0 + 64 * m] = slo[m];
 			S2[512 - k0 - 64 * m] = shi[m];
@@ -612,20 +406,19 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		/* Every ds_read_b128 serves 16 lanes from 16 slots of 16 bytes; if all lanes took the first half of their quad,
 		 * only the even slots would be used. Half of the lanes therefore start with the second half (their weights are
 		 * swapped to match); tables.c picks them, and the column order, to minimise the passes (mel_half, mel_band). */
-		const int half = ED2_MEL_SWAP ? mel_half : 0;
+		const int half = mel_half;
 		const int qlo_a = 2 * mel_slo4 + half, qlo_b = 2 * mel_slo4 + 1 - half;
 		const int qhi_a = 2 * mel_shi4 + half, qhi_b = 2 * mel_shi4 + 1 - half;
 		ed_f2 alo0 = ed_splat(0.0f), alo1 = alo0, ahi0 = alo0, ahi1 = alo0;
-		if (ED2_SKIP & 32) { alo0 = slo[0] + slo[1]; alo1 = slo[2] + slo[3]; ahi0 = shi[0] + shi[1]; ahi1 = shi[2] + shi[3]; }
 #pragma unroll
-		for (int t = 0; t < NLO && !(ED2_SKIP & 32); t++)
+		for (int t = 0; t < NLO; t++)
 		{
 			const float4 sa = S4[qlo_a + 2 * t], sb = S4[qlo_b + 2 * t], w = melw4[t * 64 + lane];
 			alo0 = ed_fma2(ed_mk2(sa.x, sa.y), ed_splat(w.x), alo0); alo1 = ed_fma2(ed_mk2(sa.z, sa.w), ed_splat(w.y), alo1);
 			alo0 = ed_fma2(ed_mk2(sb.x, sb.y), ed_splat(w.z), alo0); alo1 = ed_fma2(ed_mk2(sb.z, sb.w), ed_splat(w.w), alo1);
 		}
 #pragma unroll
-		for (int t = 0; t < NHI && !(ED2_SKIP & 32); t++)
+		for (int t = 0; t < NHI; t++)
 		{
 			if (t % 2 == 0) __builtin_amdgcn_sched_barrier(0); /* bounds the registers this stage holds in flight */
 			const float4 sa = S4[qhi_a + 2 * t], sb = S4[qhi_b + 2 * t], w = melw4[(NLO + t) * 64 + lane];
@@ -640,11 +433,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 		ED2_ST(8)
 		const ed_f2 plo = alo0 + alo1, phi = ahi0 + ahi1;
 		float t = ed_fold_rows(ed_fold_halves(plo.x, plo.y), ed_fold_halves(phi.x, phi.y));
-#if ED2_LOG_BRANCH
 		if (do_log) { asm volatile(""); t = __logf(t + log_offset); } /* the empty asm keeps this a branch (wave-uniform) */
-#else
-		if (do_log) t = __logf(t + log_offset);
-#endif
 
 		ED2_ST(9)
 		/* ---- 6. DCT-II through cos symmetry, both frames: u = L[b] + L[31-b] (even rows), v = L[b] - L[31-b] (odd) */
@@ -678,30 +467,15 @@ __global__ __launch_bounds__(64 * ED2_WPB) ED2_OCC void ed_mfcc2_kernel(ed_mfcc_
 			if (args.feat) args.feat[at] = (int8_t)__float2int_rn(fminf(fmaxf(coef * args.feat_scale, -128.0f), 127.0f));
 		}
 		ED2_ST(11)
-#if ED2_CVT_END
 		/* the next pair's samples (requested at the top of this iteration) become the floats the next iteration starts from */
 #pragma unroll
 		for (int a = 0; a < 8; a++)
 		{
 			re[a] = ed_mk2((float)(int16_t)(rawA[a] & 0xffffu), (float)(int16_t)(rawB[a] & 0xffffu));
 			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
-			if (ED2_SKIP & 256) { re[a] = ed_mk2(__uint_as_float(rawA[a]), __uint_as_float(rawB[a])); im[a] = re[a]; }
 		}
-#endif
-#if ED2_LATE_DRAW
 		i_cur = i_next;
-#else
-#if ED2_ASM_QUEUE
-		/* the draw was issued ~2 800 cycles ago and every later LDS read of this wave has returned behind it (a wave's DS
-		 * operations complete in order); the compiler does not know about it, hence the explicit (free) wait */
-		asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(drawn));
-#endif
-		i_cur = i_next; i_next = __builtin_amdgcn_readfirstlane(drawn);
-#endif
 	}
-#if ED2_LATE_BARRIER && !ED2_STAGGER
-	if (!staged) __syncthreads(); /* a wave without a single pair: the workgroup still waits for its part of the tables */
-#endif
 #if ED2_STAMP
 	asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) :: "memory");
 	ph[12] = ed2_now() - tfirst; ph[13] = rt1 - rt0; ph[14] = rt_entry; ph[15] = rt0; ph[16] = rt1;
@@ -723,7 +497,7 @@ template <int NLO, int NHI>
 static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
                                 hipStream_t stream, int *blocks_per_cu)
 {
-	const size_t lds = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED_TWTAB_FLOATS + ED_WPB * ED_XBUF_FLOATS);
+	const size_t lds = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED_WPB * ED_XBUF_FLOATS);
 	if (*blocks_per_cu <= 0)
 	{
 		/* persistent grid = exactly what is resident; sized once from the fast kernel's occupancy */
@@ -744,7 +518,7 @@ static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables
 	if (!stages && !one_frame)
 	{
 		/* the fast path: two frames per wavefront in packed fp32, one ED2_WPB-wave workgroup per CU */
-		const size_t lds2 = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_TWTAB_FLOATS + ED2_WPB * ED2_XBUF_FLOATS) + 16 /* queue */;
+		const size_t lds2 = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_WPB * ED2_XBUF_FLOATS) + 16 /* queue */;
 		const bool plain = args->frames_per_group >= args->n_frames;
 		const void *fn = aligned ? (plain ? (const void *)ed_mfcc2_kernel<true, true, NLO, NHI> : (const void *)ed_mfcc2_kernel<true, false, NLO, NHI>)
 		                         : (plain ? (const void *)ed_mfcc2_kernel<false, true, NLO, NHI> : (const void *)ed_mfcc2_kernel<false, false, NLO, NHI>);
@@ -759,17 +533,11 @@ static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * ED2_WPB, lds2) != hipSuccess || nb < 1) nb = 1;
 			const char *env = getenv("ED_MFCC_BLOCKS_PER_CU");
 			if (env && atoi(env) > 0 && atoi(env) < nb) nb = atoi(env);
-#ifdef ED2_MAX_BPC /* A/B knob (tools/lab): cap the resident workgroups per CU at compile time */
-			if (nb > ED2_MAX_BPC) nb = ED2_MAX_BPC;
-#endif
 			*bpc2 = nb;
 		}
 		const int64_t n_pairs = (args->n_frames + 1) / 2;
 		int64_t blocks2 = (n_pairs + ED2_WPB - 1) / ED2_WPB;
 		if (blocks2 > (int64_t)n_cu * *bpc2) blocks2 = (int64_t)n_cu * *bpc2;
-#ifdef ED2_MAX_WGS /* A/B knob (tools/lab): run on a part of the chip */
-		if (blocks2 > ED2_MAX_WGS) blocks2 = ED2_MAX_WGS;
-#endif
 		void *kargs[] = {(void *)args, (void *)&dev_tab};
 		return (int)hipLaunchKernel(fn, dim3((unsigned)blocks2), dim3(64 * ED2_WPB), kargs, lds2, stream);
 	}

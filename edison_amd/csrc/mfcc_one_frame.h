@@ -6,30 +6,21 @@
 #ifndef ED_MFCC_ONE_FRAME_H
 #define ED_MFCC_ONE_FRAME_H
 
+/* ---- lab knobs: only a lab build (ED_LAB, tools/lab/mkvariant.py) may set them; the product build has none, and
+ * tests/test_host_cpu.py checks the values below against what edison_amd/build.py compiles */
+#if !defined(ED_LAB) && (defined(ED_WPB))
+#error "ED_WPB lab knob defined without ED_LAB (tools/lab/mkvariant.py builds lab variants)"
+#endif
 #ifndef ED_WPB
 #define ED_WPB 8                 /* waves (= frames in flight) per workgroup                               */
 #endif
-#if ED_T2_LDS
 #define ED_XBUF_FLOATS 1160      /* per-wave LDS: 526 complex transpose slots | spectrum S[516] at 576 | u,v at 1104 */
 #define ED_S_OFF 576
 #define ED_L_OFF 1104
-#else
-#define ED_XBUF_FLOATS 576       /* per-wave LDS: spectrum S[516] | DCT input u[16], v[16] | pad            */
-#define ED_S_OFF 0
-#define ED_L_OFF 528
-#endif
 #define ED_FIXTAB_FLOATS (2 * 64 * 4 + 4 * 64 * 2) /* dct | split twiddles, then (NLO+NHI) x 64 weight quads */
 
-#ifndef ED_TW_LDS
-#define ED_TW_LDS 0              /* 1: pass-1/2 twiddles read from LDS instead of living in 28 registers      */
-#endif
-#define ED_TWTAB_FLOATS (ED_TW_LDS ? 2048 : 0)
 
-#ifdef ED_MIN_WAVES
-#define ED_MFCC_BOUNDS __launch_bounds__(64 * ED_WPB, ED_MIN_WAVES)
-#else
 #define ED_MFCC_BOUNDS __launch_bounds__(64 * ED_WPB)
-#endif
 
 #include "mfcc_fft.h"
 
@@ -45,9 +36,6 @@ __device__ __forceinline__ const int16_t *ed_frame_ptr(const ed_mfcc_args_t &a, 
 	return a.audio + ((int64_t)g * a.group_stride + (int64_t)i * a.frame_step);
 }
 
-#ifndef ED_LOAD_NT
-#define ED_LOAD_NT 1
-#endif
 template <bool ALIGNED>
 __device__ __forceinline__ void ed_load_frame(const int16_t *fp, int lane, uint32_t (&v)[8])
 {
@@ -57,9 +45,9 @@ __device__ __forceinline__ void ed_load_frame(const int16_t *fp, int lane, uint3
 		/* the samples are read once: non-temporal loads (global_load_dword ... nt) keep them from displacing what the caches are
 		 * for (tables, the feature rows the CNN reads next): +2.2 ... +2.6 % on the 65 536-frame launch, +1.0 % on the Q15
 		 * kernel (interleaved A/B, profiles/r03_wave_priorities.txt); agent- / system-scope loads (sc1, sc0 sc1) and
-		 * non-temporal STORES of the coefficients measure -0.4 ... -0.8 %. ED_LOAD_NT=0: plain loads (A/B) */
+		 * non-temporal STORES of the coefficients measure -0.4 ... -0.8 %. */
 #pragma unroll
-		for (int a = 0; a < 8; a++) v[a] = ED_LOAD_NT ? __builtin_nontemporal_load(fp32 + lane + 64 * a) : fp32[lane + 64 * a];
+		for (int a = 0; a < 8; a++) v[a] = __builtin_nontemporal_load(fp32 + lane + 64 * a);
 	}
 	else
 	{
@@ -83,7 +71,7 @@ __device__ __forceinline__ void ed_mfcc1_body(const ed_mfcc_args_t &args, const 
 	const float4 *dctl = reinterpret_cast<const float4 *>(smem);                 /* [2][64] x 4 coefficients */
 	const float2 *tpl = reinterpret_cast<const float2 *>(smem + 512);            /* [4][64] split twiddles   */
 	const float4 *melw4 = reinterpret_cast<const float4 *>(smem + ED_FIXTAB_FLOATS); /* [NLO+NHI][64] quads   */
-	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED_TWTAB_FLOATS + wave * ED_XBUF_FLOATS; /* wave-private */
+	float *xbuf = smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + wave * ED_XBUF_FLOATS; /* wave-private */
 
 	/* the first frame's samples go in flight before anything else: their HBM latency hides under the table staging */
 	const uint32_t n_frames = (uint32_t)args.n_frames;
@@ -98,16 +86,6 @@ __device__ __forceinline__ void ed_mfcc1_body(const ed_mfcc_args_t &args, const 
 		for (int t = threadIdx.x; t < (ED_FIXTAB_FLOATS + (NLO + NHI) * 256) / 4; t += blockDim.x) dst[t] = src[t];
 	}
 
-#if ED_TW_LDS
-	/* pass-1/2 twiddles: per-lane LDS tables [p][lane] (conflict-free ds_read_b64), 28 registers saved */
-	const float2 *tw1l = reinterpret_cast<const float2 *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256) + lane;
-	const float2 *tw2l = tw1l + 512;
-	{
-		const float4 *src = reinterpret_cast<const float4 *>(&tab->tw1[0][0][0]); /* tw1 | tw2 are adjacent */
-		float4 *dst = reinterpret_cast<float4 *>(smem + ED_FIXTAB_FLOATS + (NLO + NHI) * 256);
-		for (int t = threadIdx.x; t < 2048 / 4; t += blockDim.x) dst[t] = src[t];
-	}
-#else
 	/* pass-1/2 twiddles: resident in registers for the whole persistent loop */
 	float t1r[8], t1i[8], t2r[8], t2i[8];
 #pragma unroll
@@ -117,7 +95,6 @@ __device__ __forceinline__ void ed_mfcc1_body(const ed_mfcc_args_t &args, const 
 		const float2 b = *reinterpret_cast<const float2 *>(&tab->tw2[p][lane][0]);
 		t1r[p] = a.x; t1i[p] = a.y; t2r[p] = b.x; t2i[p] = b.y;
 	}
-#endif
 	__syncthreads();
 	const int mel_slo4 = tab->mel_slo4[lane], mel_shi4 = tab->mel_shi4[lane];
 	const int band = tab->mel_band[lane]; /* this column's narrow band b; its wide band is 31 - b */
@@ -128,7 +105,7 @@ __device__ __forceinline__ void ed_mfcc1_body(const ed_mfcc_args_t &args, const 
 	 * transpose, octal-digit-swapped with the DPP one) */
 	const int k0 = ED_K0(lane);
 	const int k0p = (64 - k0) & 63;                          /* low 6 bits of the partner index 512 - k    */
-	const int pull = (ED_T2_LDS ? k0p : (((k0p & 7) << 3) | (k0p >> 3))) << 2; /* lane that holds it, as a byte address */
+	const int pull = k0p << 2; /* lane that holds it, as a byte address */
 	const int hi3 = lane >> 3, lo3 = lane & 7;
 	float2 *xc = reinterpret_cast<float2 *>(xbuf);
 	(void)hi3; (void)lo3; (void)xc;
@@ -151,12 +128,7 @@ __device__ __forceinline__ void ed_mfcc1_body(const ed_mfcc_args_t &args, const 
 #pragma unroll
 		for (int p = 1; p < 8; p++)
 		{
-#if ED_TW_LDS
-			const float2 w = tw1l[64 * p];
-			const float wr = w.x, wi = w.y;
-#else
 			const float wr = t1r[p], wi = t1i[p];
-#endif
 			float xr = re[p], xi = im[p];
 			re[p] = xr * wr - xi * wi;
 			im[p] = xr * wi + xi * wr;
@@ -170,17 +142,11 @@ __device__ __forceinline__ void ed_mfcc1_body(const ed_mfcc_args_t &args, const 
 #pragma unroll
 		for (int q = 1; q < 8; q++)
 		{
-#if ED_TW_LDS
-			const float2 w = tw2l[64 * q];
-			const float wr = w.x, wi = w.y;
-#else
 			const float wr = t2r[q], wi = t2i[q];
-#endif
 			float xr = re[q], xi = im[q];
 			re[q] = xr * wr - xi * wi;
 			im[q] = xr * wi + xi * wr;
 		}
-#if ED_T2_LDS
 		/* transpose 2 through the wave-private LDS buffer: (lane 8p+c, reg q) -> (lane p+8q, reg c); slot
 		 * 66c + p + 8q is conflict-free for the ds_write_b64 (16-lane groups) and the ds_read_b64 alike */
 #pragma unroll
@@ -193,11 +159,6 @@ __device__ __forceinline__ void ed_mfcc1_body(const ed_mfcc_args_t &args, const 
 			re[c] = v.x; im[c] = v.y;
 		}
 		ed_wave_sync();
-#else
-		/* transpose 2: register q <-> lane bits 0..2 (c): (lane 8p+c, reg q) -> (lane 8p+q, reg c) */
-		ed_transpose8<0, 1, 2>(re, lane);
-		ed_transpose8<0, 1, 2>(im, lane);
-#endif
 
 		/* ---- 2c. pass 3: DFT over c  ->  reg r holds Z[k0 + 64r], k0 = p + 8q */
 		ed_radix8(re, im);

@@ -38,6 +38,15 @@
 #include "../../include/edison_hip.h"
 #include "edison_internal.h"
 
+/* ---- lab knobs: only a lab build (ED_LAB, tools/lab/mkvariant.py) may set them; the product build has none, and
+ * tests/test_host_cpu.py checks the values below against what edison_amd/build.py compiles */
+#if !defined(ED_LAB) && (defined(EQ_WPB) || defined(EQ_PRIO) || defined(EQ_ABLATE) || defined(EQ_WAVES_PER_EU))
+#error "EQ_* lab knob defined without ED_LAB (tools/lab/mkvariant.py builds lab variants)"
+#endif
+#if defined(ED_LAB)
+/* a lab build says so: the product library exports no ed_lab_build_* symbol (tests/test_host_cpu.py) */
+extern "C" { extern const int ed_lab_build_mfcc_q15; const int ed_lab_build_mfcc_q15 = 1; }
+#endif
 #ifndef EQ_WPB
 #define EQ_WPB 16                /* wavefronts (= frames in flight) per workgroup: one workgroup per CU, 4 waves per SIMD */
 #endif
@@ -155,9 +164,6 @@ __device__ __forceinline__ void eq_bf_first_real2(u32 a0, u32 a1, u32 a2, u32 a3
 }
 
 /* the samples of one frame as stage 1 wants them: x[4 v + q] = samples (2 lane + 128 v + 256 q, and the next one) */
-#ifndef EQ_LOAD_NT
-#define EQ_LOAD_NT 1
-#endif
 template <bool ALIGNED>
 __device__ __forceinline__ void eq_load_frame(const int16_t *src, int lane, u32 (&x)[8])
 {
@@ -165,8 +171,8 @@ __device__ __forceinline__ void eq_load_frame(const int16_t *src, int lane, u32 
 	for (int i = 0; i < 8; i++)
 	{
 		const int at = 2 * lane + 128 * (i >> 2) + 256 * (i & 3);
-		/* read once: non-temporal (see ed_load_frame in mfcc_one_frame.h; +1.0 % here). EQ_LOAD_NT=0: plain (A/B) */
-		if (ALIGNED) x[i] = EQ_LOAD_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32 *>(src + at)) : *reinterpret_cast<const u32 *>(src + at);
+		/* read once: non-temporal (see ed_load_frame in mfcc_one_frame.h; +1.0 % here). */
+		if (ALIGNED) x[i] = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(src + at));
 		else x[i] = (u32)(unsigned short)src[at] | ((u32)(unsigned short)src[at + 1] << 16);
 	}
 }
@@ -382,19 +388,8 @@ __device__ __forceinline__ void eq_dct_batch(const ed_mfcc_q15_args_t &a, int *m
  * 216 -> 167 registers, 3 waves per SIMD instead of 2, +6.7 % (48 more conflict-free ds_read_b32 per frame) */
 /* 2 (round 3): stage 3's six as well -- 106 registers, 4 waves per SIMD. Without wave priorities the fourth wave bought nothing
  * (89.8 us at 12 and at 16 waves); with them 89.9 -> 87.1 us (+3.3 %, profiles/r03_wave_priorities.txt) */
-#ifndef EQ_TW_LDS
-#define EQ_TW_LDS 2
-#endif
-#if EQ_TW_LDS
 #define EQ_TW12(stage, u, regs) eq_tw_from_lds(s_tw12 + ((stage) * 4 + (u)) * 6 * 64, lane)
-#else
-#define EQ_TW12(stage, u, regs) (regs)
-#endif
-#if EQ_TW_LDS >= 2
 #define EQ_TW3(regs) eq_tw_from_lds(s_tw12 + 8 * 6 * 64, lane)
-#else
-#define EQ_TW3(regs) (regs)
-#endif
 __device__ __forceinline__ eq_tw3 eq_tw_from_lds(const u32 *t, int lane)
 {
 	eq_tw3 r;
@@ -458,7 +453,6 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 		t1[u].w[1] = (u & 1) ? t1[u].w[1] << 16 : t1[u].w[1] & 0xffffu;
 		t1[u].wx[1] = (u & 1) ? t1[u].wx[1] << 16 : t1[u].wx[1] & 0xffffu;
 		t2[u] = eq_load_tw(T->tw1024, T->tw1024x, 4 * (j3 + 16 * u)); /* stage 2: ic = 4 j, j = j3 + 16a  */
-#if EQ_TW_LDS
 		/* the per-lane coefficients of stages 1 and 2 (48 registers) live in LDS instead, one conflict-free
 		 * ds_read_b32 each per frame: every wave of the workgroup needs the same values in the same lanes */
 		if (w == 0)
@@ -470,7 +464,6 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 				s_tw12[((1 * 4 + u) * 6 + i) * 64 + lane] = t2[u].w[i]; s_tw12[((1 * 4 + u) * 6 + 3 + i) * 64 + lane] = t2[u].wx[i];
 			}
 		}
-#endif
 		t4[u] = eq_load_tw(T->tw1024, T->tw1024x, 64 * u);            /* stage 4: ic = 64 j (uniform)     */
 #pragma unroll
 		for (int i = 0; i < 3; i++)
@@ -480,16 +473,12 @@ __global__ __launch_bounds__(64 * EQ_WPB) EQ_OCCUPANCY void ed_mfcc_q15_kernel(e
 		}
 	}
 	const eq_tw3 t3 = eq_load_tw(T->tw1024, T->tw1024x, 16 * j3);     /* stage 3: ic = 16 j               */
-#if EQ_TW_LDS >= 2 /* stage 3's six as well */
 	if (w == 1 % EQ_WPB)
 	{
 #pragma unroll
 		for (int i = 0; i < 3; i++) { s_tw12[(8 * 6 + i) * 64 + lane] = t3.w[i]; s_tw12[(8 * 6 + 3 + i) * 64 + lane] = t3.wx[i]; }
 	}
-#endif
-#if EQ_TW_LDS
 	__syncthreads(); /* s_tw12 was written by waves 0 and 1 */
-#endif
 	const int mel_lo_pair = T->mel_lo_pair[lane], mel_hi_pair = T->mel_hi_pair[lane];
 	const int mel_scale = T->mel_scale;
 	/* the firmware divides by MEL_MTX_SCALE = 128 (mel_constants.h:7): a power of two is an add and a shift (C's division

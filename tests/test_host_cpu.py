@@ -535,3 +535,87 @@ def test_hot_kernels_use_no_scratch(tmp_path):
             assert scratch == 0, (name, b.split()[0], "scratch bytes per lane", scratch)
             assert vgprs <= max_vgprs, (name, b.split()[0], vgprs)
         assert seen >= 1, (name, kernel)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# lab knobs never reach the product library (round-3 review: "nothing tests that the shipped .so was built with every knob
+# at its default")
+KNOB_FILES = ["mfcc_kernels.hip", "mfcc_one_frame.h", "mfcc_q15_kernels.hip", "mfcc_f32_kernels.hip", "cnn_mfma_kernels.hip",
+              "cnn_net_kernels.hip", "cnn_net_mfma_kernels.hip"]
+# macros with an `#ifndef X / #define X` default that are MODES set by the library itself, not knobs: the run-time compiler of
+# edison_net_specialize defines them (edison_net_jit.hip)
+MODE_MACROS = {"EMM_JIT", "EMM_SPEC"}
+
+
+def _knobs_of(text):
+    """(guarded names, {name: default}) of a kernel file: the names in its `#if !defined(ED_LAB) && (defined(A) || ...)` guard and
+    every `#ifndef NAME / #define NAME value` default block it holds."""
+    g = re.search(r"#if !defined\(ED_LAB\) && \(([^\n]*)\)\n#error", text)
+    guarded = set(re.findall(r"defined\((\w+)\)", g.group(1))) if g else set()
+    defaults = dict(re.findall(r"#ifndef (E[A-Z0-9]*_\w+)[^\n]*\n#define \1[ \t]+([^\n/]*?)[ \t]*(?:/\*[^\n]*)?\n", text))
+    return guarded, defaults
+
+
+def test_every_compile_time_knob_of_a_kernel_file_is_behind_ed_lab():
+    """A macro a kernel file gives a default to (`#ifndef X / #define X v`) is either a mode the library sets itself or a lab knob --
+    and a lab knob must be named in the file's guard, which refuses it in a build without ED_LAB."""
+    from edison_amd import build as B
+    seen = 0
+    for f in KNOB_FILES:
+        guarded, defaults = _knobs_of(open(os.path.join(B.CSRC, f)).read())
+        free = set(defaults) - guarded - MODE_MACROS
+        assert not free, (f, "knobs outside the ED_LAB guard", sorted(free))
+        assert guarded <= set(defaults) | {"EQ_WAVES_PER_EU"}, (f, sorted(guarded - set(defaults)))
+        seen += len(guarded)
+    assert seen >= 15
+    # the retired switches are gone for good: nothing may bring back a "results are WRONG when non-zero" macro without the guard
+    mk = open(os.path.join(B.CSRC, "mfcc_kernels.hip")).read()
+    for gone in ("ED2_ABLATE", "ED2_SKIP", "ED2_T1_LDS", "ED2_TW_LDS", "ED2_LATE_DRAW", "ED2_STAGGER ", "ED2_MAX_WGS"):
+        assert gone not in mk, gone
+
+
+def test_product_compile_refuses_a_lab_knob_and_a_lab_build_says_so(tmp_path):
+    """Preprocess kernel files the way edison_amd/build.py compiles them: (1) as they are -- every knob has the value its file gives
+    it and ED_LAB is undefined; (2) with a knob on the command line -- the guard's #error; (3) the same with -DED_LAB -- accepted,
+    and the translation unit then carries the ed_lab_build_* marker a product library must not export."""
+    from edison_amd import build as B
+
+    def pp(name, extra, want_ok):
+        cmd = [B._hipcc(), "--offload-arch=" + B.ARCH, "--cuda-device-only", "-std=c++17", "-I" + B.CSRC, "-E", "-dD"] + extra + ["-x", "hip", os.path.join(B.CSRC, name)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert (r.returncode == 0) == want_ok, (name, extra, r.stderr[-1500:])
+        return r.stdout if want_ok else r.stderr
+
+    for name, knob in (("mfcc_kernels.hip", "ED2_PRIO"), ("mfcc_q15_kernels.hip", "EQ_ABLATE"), ("cnn_mfma_kernels.hip", "EDM_PRIO"),
+                       ("cnn_net_mfma_kernels.hip", "EMM_SKIP")):
+        text = open(os.path.join(B.CSRC, name)).read()
+        guarded, defaults = _knobs_of(text)
+        out = pp(name, [], True)
+        assert not re.search(r"#define ED_LAB\b", out), name
+        for k in guarded & set(defaults):
+            m = re.findall(r"#define %s[ \t]+([^\n]*)" % k, out)
+            assert m and m[-1].split("/*")[0].strip() == defaults[k].strip(), (name, k, m, defaults[k])
+        assert "ed_lab_build_" not in re.sub(r"/\*.*?\*/", "", out, flags=re.S).split("#define")[0] or True
+        assert not re.search(r"const int ed_lab_build_\w+ = 1", out), name
+        err = pp(name, ["-D%s=0" % knob], False)
+        assert "lab knob defined without ED_LAB" in err, err[-500:]
+        lab = pp(name, ["-DED_LAB", "-D%s=0" % knob], True)
+        assert re.search(r"const int ed_lab_build_\w+ = 1", lab), name
+
+
+def test_product_library_is_not_a_lab_build_and_build_py_refuses_lab_flags(monkeypatch):
+    from edison_amd import build as B, _lib
+    r = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0
+    assert "ed_lab_build_" not in r.stdout, [l for l in r.stdout.splitlines() if "ed_lab_build_" in l]
+    for flags in ("-DED2_PRIO=0", "-O2 -DEQ_ABLATE=4", "-DED_LAB", "-UEMM_PRIO"):
+        monkeypatch.setenv("ED_CFLAGS", flags)
+        with pytest.raises(RuntimeError, match="lab macros"):
+            B.product_flags()
+    monkeypatch.setenv("ED_CFLAGS", "-g -fno-omit-frame-pointer")
+    assert B.product_flags() == ["-g", "-fno-omit-frame-pointer"]
+    # the text the run-time compiler of edison_net_specialize receives is the product text, and it is handed no knob
+    jit = open(os.path.join(B.CSRC, "edison_net_jit.hip")).read()
+    i = jit.index('getenv("EDISON_JIT_DEFINE")')
+    assert "#ifdef ED_LAB" in jit[i - 200:i], "EDISON_JIT_DEFINE must only exist in a lab build of edison_net_jit.hip"
+    assert B.JIT_TEXTS[0][1].endswith("cnn_net_mfma_kernels.hip")

@@ -5,7 +5,8 @@
 
 Each variant recompiles the named kernel files (default mfcc_kernels.hip) with the extra FLAGS and links them with
 the product build's other objects (edison_amd/csrc/build/*.o) into edison_amd/csrc/abl/libedison_hip_<name>.so
-(git-ignored, travels to the GPU box). A file given as path:alt.hip replaces the source text, e.g.
+(git-ignored, travels to the GPU box). Every variant is compiled with -DED_LAB: the kernel files accept their knobs only then
+(and export an ed_lab_build_* marker, so that a lab library is never mistaken for the product one). A file given as path:alt.hip replaces the source text, e.g.
     new=-DX=1@mfcc_kernels.hip:tools/lab/mfcc_try.hip
 """
 import os, subprocess, sys
@@ -25,7 +26,7 @@ def one(spec):
         src = os.path.join(ROOT, alt) if alt else os.path.join(B.CSRC, base)
         obj = os.path.join(odir, base + ".o")
         cmd = [B._hipcc(), "--offload-arch=" + B.ARCH, "-std=c++17", "-fno-slp-vectorize", "-O3", "-fPIC", "-I" + B.CSRC,
-               "-Wno-unused-value"] + B.PER_FILE_FLAGS.get(base, []) + flags.split() + ["-x", "hip", "-c", src, "-o", obj]
+               "-Wno-unused-value", "-DED_LAB"] + B.PER_FILE_FLAGS.get(base, []) + flags.split() + ["-x", "hip", "-c", src, "-o", obj]
         subprocess.check_call(cmd)
         replaced.add(base + ".o"); objs.append(obj)
     for o in sorted(os.listdir(os.path.join(B.CSRC, "build"))):
