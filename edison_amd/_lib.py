@@ -25,7 +25,7 @@ c_void_p, c_int, c_int64, c_size_t, c_float, c_double, c_char_p = (
 class StreamOpts(ctypes.Structure):
     """edison_stream_opts"""
     _fields_ = [("hop", c_int), ("chunk_frames", c_int), ("mfcc_variant", c_int), ("filter", c_int),
-                ("filter_alpha", c_double), ("true_threshold", c_double), ("launch_mode", c_int), ("reserved_", c_int)]
+                ("filter_alpha", c_double), ("true_threshold", c_double), ("launch_mode", c_int), ("fsm", c_int)]
 
 
 class NetInfo(ctypes.Structure):
@@ -108,6 +108,11 @@ SIGNATURES = {
     "edison_stream_destroy": (None, [c_void_p]),
     "edison_stream_reset": (c_int, [c_void_p]),
     "edison_stream_push_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_stream_push_n_dev": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "edison_stream_fsm": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "edison_stream_fsm_dev": (c_int, [c_void_p, c_void_p]),
+    "edison_postproc": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_double, ctypes.c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edison_fsm_roles": (None, [c_void_p, c_void_p, c_void_p]),
     "edison_stream_push": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "edison_stream_frames_seen": (c_int64, [c_void_p]),
     "edison_stream_default_opts": (None, [ctypes.POINTER(StreamOpts)]),

@@ -306,6 +306,25 @@ class Context:
 _default = None
 
 
+def postproc(ctx, softmax, alpha=0.9, threshold=0.5, dt_us=64000, state=None, fsm=None):
+    """The firmware's post-processing chain (app.c:332-371) on consecutive int8 softmax rows, one GPU stage (edison_postproc):
+    returns dict(filtered [n,10] f32, likely [n], spotted [n], state [10] f32, fsm_states [n], fsm (the _lib.Fsm struct)).
+    state / fsm: carried in from an earlier call (None: zeros / a machine in RESET)."""
+    import ctypes
+    L = _lib.lib()
+    s = np.ascontiguousarray(softmax, dtype=np.int8).reshape(-1, 10)
+    n = s.shape[0]
+    st = np.zeros(10, np.float32) if state is None else np.array(state, dtype=np.float32)
+    if fsm is None:
+        fsm = _lib.Fsm()
+        L.edison_fsm_init(ctypes.byref(fsm))
+    filt = np.zeros((n, 10), np.float32)
+    likely, spotted, states = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    ctx._check(L.edison_postproc(ctx._h, s.ctypes.data, n, float(alpha), float(threshold), int(dt_us), st.ctypes.data, ctypes.byref(fsm),
+                                 filt.ctypes.data, likely.ctypes.data, spotted.ctypes.data, states.ctypes.data))
+    return dict(filtered=filt, likely=likely, spotted=spotted, state=st, fsm_states=states, fsm=fsm)
+
+
 def default_context():
     """Process-wide context on cuda:LOCAL_RANK (or 0); created on first use."""
     global _default

@@ -17,8 +17,9 @@
  *     aligned ds_read_b128 -- no im2col buffer;
  *   - C = the accumulator seeds (bias << bias_lshift) + NN_ROUND(out_rshift) of the tile's rows, so the epilogue is
  *     shift, clamp, pack;
- *   - D puts 4 consecutive output channels of one pixel into 4 consecutive registers of a lane, so the
- *     epilogue packs them into one dword and stores HWC int8 directly where the next layer reads.
+ *   - D puts 4 consecutive rows into 4 consecutive registers of a lane, and which output channel a ROW of a 32-row tile is, is
+ *     the host's choice (model.c tile_row): the four packed dwords of a lane are 16 consecutive output channels of its pixel, so
+ *     the epilogue stores one 16-byte record directly where the next layer reads -- no exchange between lanes.
  *   - the two rows of a max-pool window are computed as two accumulator tiles over the same lanes
  *     (even / odd input row), pooled by an element-wise max.
  *
@@ -35,36 +36,31 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include <type_traits>
 
 #include "edison_internal.h"
+#include "edison_fsm_core.h"
 
 /* ---- lab knobs: only a lab build (ED_LAB, tools/lab/mkvariant.py) may set them; the product build has none, and
  * tests/test_host_cpu.py checks the values below against what edison_amd/build.py compiles */
-#if !defined(ED_LAB) && (defined(EDM_PRIO))
+#if !defined(ED_LAB) && (defined(EDM_PRIO) || defined(EDM_SKIP))
 #error "EDM_* lab knob defined without ED_LAB (tools/lab/mkvariant.py builds lab variants)"
 #endif
 #if defined(ED_LAB)
 /* a lab build says so: the product library exports no ed_lab_build_* symbol (tests/test_host_cpu.py) */
 extern "C" { extern const int ed_lab_build_cnn_mfma; const int ed_lab_build_cnn_mfma = 1; }
 #endif
+/* lab only: timing / counter ablations by layer (results are WRONG when non-zero; tools/lab/cnn_lds_by_phase.sh): 1 conv1, 2 conv2,
+ * 4 conv3, 8 conv4, 16 dense */
+#ifndef EDM_SKIP
+#define EDM_SKIP 0
+#endif
 #define EDM_G 4       /* utterances per wavefront group */
 #define EDM_WAVES 8
 #define EDM_THREADS (64 * EDM_WAVES)
-/* Region A: in' = the 31 input rows padded to 16 bytes, EVEN rows then ODD rows (2 x 16 slots of 16 B = 512)  ->
- *           p2 = conv2's pooled output [5][7] pixels as TWO PLANES of 16 channels (2 x 35 slots = 1120)  ->  c4 [3][32] (96)
- * Region B: p1 [13][9][16] (1872)  ->  c3 = conv3's output [3][5] pixels as FOUR PLANES of 16 channels (4 x 15 slots = 960)
- * Planes instead of pixel-major records: a B operand is 16 bytes (16 channels of one tap) per lane, and the lanes of a
- * ds_read_b128 group are neighbouring columns = neighbouring pixels. With [pixel][32 or 64 channels] records they sat 32 / 64
- * bytes apart and used every second / fourth 16-byte bank group: 2-way (conv1's row pairs, conv3) and 4-way (conv4) bank
- * conflicts on every operand read, 39 % of all LDS cycles (profiles/r02_cnn_counters.txt). In a plane neighbouring pixels
- * are neighbouring 16-byte slots. */
-#define EDM_REGA 1120
-#define EDM_REGB 1872
-#define EDM_IN_ODD 256   /* byte offset of the odd input rows inside region A */
-#define EDM_P2_PLANE 560 /* bytes per 16-channel plane of p2 */
-#define EDM_C3_PLANE 240 /* bytes per 16-channel plane of c3 */
-#define EDM_UTT (EDM_REGA + EDM_REGB)
+/* (the LDS layout of an utterance -- EDM_REGA, EDM_REGB, EDM_IN_ODD, EDM_P2_PLANE, EDM_C3_PLANE, EDM_UTT -- is in edison_internal.h:
+ * model.c builds the column tables from it) */
 #define EDM_PARK 8    /* groups whose logits are parked before one softmax pass (8 x 4 = 32 lanes) */
 #define EDM_WAVE_LDS (EDM_G * EDM_UTT + EDM_PARK * EDM_G * 16 + 64)
 
@@ -144,18 +140,6 @@ __device__ __forceinline__ int edm_max(int a, int b) { return a > b ? a : b; }
 		__builtin_amdgcn_sched_group_barrier(0x002, (V), 0);                     \
 	}
 #define EDM_FENCE()
-
-/* The four packed dwords of a lane are channels 8g + 4h .. +3 (g = 0..3): 4-byte pieces, 8 bytes apart, interleaved with
- * those of the lane 32 further up (h = 1). Stored one by one they hit LDS as ds_write_b32 at the pixel stride -- 8-way
- * bank conflicts (55 % of all LDS cycles of the first version of this kernel, profiles/r02_cnn_counters.txt). Two
- * v_permlane32_swap trade pieces between the two lane halves so that lane h = 0 holds bytes 0..15 of its pixel record and
- * lane h = 1 bytes 16..31 (conv1: the record of the tile's second x position): one ds_write_b128 each. */
-__device__ __forceinline__ uint4 edm_gather16(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3)
-{
-	const auto r02 = __builtin_amdgcn_permlane32_swap(d0, d2, false, false); /* h0: d0(h0), d0(h1)   h1: d2(h0), d2(h1) */
-	const auto r13 = __builtin_amdgcn_permlane32_swap(d1, d3, false, false);
-	return make_uint4(r02[0], r02[1], r13[0], r13[1]);
-}
 
 /* Order this wave's LDS writes before its following LDS reads: DS instructions of a wave are issued and serviced in
  * order, the (code-less) wave barrier only keeps the compiler from moving memory operations across. */
@@ -277,6 +261,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		 * conv2: 35, conv3: 15), which is what a one-window launch's latency is made of */
 		const int64_t b_cur = (g_lo + idx) * EDM_G;
 		const int nb_cur = (int)((n_utt - b_cur) < EDM_G ? (n_utt - b_cur) : EDM_G);
+		const bool full = nb_cur == EDM_G; /* wave-uniform */
 
 		EDM_PR(0)
 		/* ---- input: feat[u][31][13] -> in'[u][31][16] (3 zero bytes of padding per row) */
@@ -302,13 +287,16 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		EDM_PR(1)
 		/* ---- conv1 5x5x1->16 + ReLU + pool(2,1): Toeplitz GEMM, 144 rows (x,o) x 80 k (5 padded input rows).
 		 *      columns = (utt, pooled row py): 4 x 13 = 52 in 2 column tiles; two accumulators = input rows 2py / 2py+1 */
+		if (!(EDM_SKIP & 1))
 		{
-			/* rows of a conv1 tile are (x, o): register group g holds channels 8*(g&1) + 4h .. +3 of x = 2 rt + (g >> 1) */
+			/* rows of a conv1 tile are (x, o) in the order model.c gives the A fragments (tile_row): lane half h owns x = 2 rt + h,
+			 * its register group g holds channels 4 g .. 4 g + 3 -- the seeds are the 16 channels in order */
 			v16i seed1;
+#pragma unroll
+			for (int g = 0; g < 4; g++)
 			{
-				const v4i s0 = *reinterpret_cast<const v4i *>(&M.b1[4 * h]), s1 = *reinterpret_cast<const v4i *>(&M.b1[8 + 4 * h]);
-				seed1[0] = s0.x; seed1[1] = s0.y; seed1[2] = s0.z; seed1[3] = s0.w; seed1[4] = s1.x; seed1[5] = s1.y; seed1[6] = s1.z; seed1[7] = s1.w;
-				seed1[8] = s0.x; seed1[9] = s0.y; seed1[10] = s0.z; seed1[11] = s0.w; seed1[12] = s1.x; seed1[13] = s1.y; seed1[14] = s1.z; seed1[15] = s1.w;
+				const v4i s_ = *reinterpret_cast<const v4i *>(&M.b1[4 * g]);
+				seed1[4 * g] = s_.x; seed1[4 * g + 1] = s_.y; seed1[4 * g + 2] = s_.z; seed1[4 * g + 3] = s_.w;
 			}
 			/* the 15 weight fragments stay in registers for both column tiles: the MFMA stream then never waits for LDS */
 			v4i A1[15];
@@ -318,11 +306,25 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 			for (int t = 0; t < 2; t++)
 			{
 				if (t * 32 >= nb_cur * 13) break; /* no live column in this tile */
-				const int q = t * 32 + col;
-				const bool live = q < EDM_G * 13;
-				const int qq = live ? q : EDM_G * 13 - 1; /* idle columns recompute the last one and store nothing */
-				const int u = qq / 13, py = qq - u * 13;
-				const unsigned char *inb = acts + u * EDM_UTT + py * 16; /* row 2 py of the even plane; row 2 py + 1 of the odd plane is EDM_IN_ODD further */
+				/* which column (utt, py) this lane computes: for a full group the order that keeps the LDS accesses of a lane group
+				 * on different banks (M.cols1, edison_internal.h), for a partial one the natural order (only the tiles that hold a
+				 * live utterance run) */
+				int rd_off, st_off;
+				bool live;
+				if (full)
+				{
+					const uint32_t e = M.cols1[t][col];
+					rd_off = (int)(e & 0x7fffu); st_off = (int)((e >> 16) & 0x7fffu); live = !(e & ED_CNN_COL_IDLE);
+				}
+				else
+				{
+					const int q = t * 32 + col;
+					live = q < EDM_G * 13;
+					const int qq = live ? q : EDM_G * 13 - 1; /* idle columns recompute the last one and store nothing */
+					const int u = qq / 13, py = qq - u * 13;
+					rd_off = u * EDM_UTT + py * 16; st_off = u * EDM_UTT + EDM_REGA + (py * 9) * 16;
+				}
+				const unsigned char *inb = acts + rd_off; /* row 2 py of the even plane; row 2 py + 1 of the odd plane is EDM_IN_ODD further */
 				v4i be[3], bo[3];
 #pragma unroll
 				for (int s = 0; s < 3; s++)
@@ -332,7 +334,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 					be[s] = edm_ld16(inb + (c & 1) * EDM_IN_ODD + (c >> 1) * 16);
 					bo[s] = edm_ld16(inb + ((c + 1) & 1) * EDM_IN_ODD + ((c + 1) >> 1) * 16);
 				}
-				unsigned char *p1 = acts + u * EDM_UTT + EDM_REGA + (py * 9) * 16;
+				unsigned char *p1 = acts + st_off;
 				/* software pipeline: the MFMAs of row tile rt + 1 are issued BEFORE the requantisation of row tile rt, so
 				 * that VALU work runs while the matrix pipe is busy (an MFMA blocks vector issue for 8 of its 32 cycles) */
 				v16i ae[2], ao[2];
@@ -359,9 +361,8 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 						                           edm_max3z(e[4 * g + 2], o[4 * g + 2]), edm_max3z(e[4 * g + 3], o[4 * g + 3]))
 						          : edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
 						                          edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs1);
-					/* groups 0, 1 are channels 4h.. and 8+4h.. of x = 2 rt, groups 2, 3 the same of x = 2 rt + 1: after the
-					 * exchange lane half h owns the whole 16-byte record of x = 2 rt + h */
-					const uint4 rec = edm_gather16(d[0], d[1], d[2], d[3]);
+					/* the whole 16-byte record of x = 2 rt + h, as it stands (row order of the A fragments: model.c tile_row) */
+					const uint4 rec = make_uint4(d[0], d[1], d[2], d[3]);
 					*reinterpret_cast<uint4 *>((2 * rt + h < 9 && live) ? p1 + (2 * rt + h) * 16 : dummy) = rec;
 					if (rt + 1 < 5) { if (F8) { EDM_WEAVE(6, 7) } else { EDM_WEAVE(6, 13) } }
 					__builtin_amdgcn_sched_barrier(0);
@@ -373,6 +374,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		EDM_PR(2)
 		/* ---- conv2 3x3x16->32 + ReLU + pool(2,1): K = 9 taps x 16 ch (5 k-steps of 2 taps); columns =
 		 *      (utt, py, x): 4 x 35 = 140 in 5 column tiles; two accumulators = conv rows 2py / 2py+1 */
+		if (!(EDM_SKIP & 2))
 		{
 			const v16i seed2 = edm_seed_tile(&M.b2[4 * h]);
 			/* three-stage software pipeline per column tile: fetch (LDS reads of the B fragments) two tiles ahead, MFMAs
@@ -386,13 +388,24 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 			unsigned char *p2[3];
 			bool live[3];
 			/* bs: which of the two fragment sets, ls: which of the three (live, p2) slots */
-			auto fetch = [&](int t, int bs, int ls) {
-				const int q = t * 32 + col;
-				live[ls] = q < nb_cur * 35;
-				const int qq = live[ls] ? q : nb_cur * 35 - 1;
-				const int u = qq / 35, r = qq - u * 35, py = r / 7, x = r - py * 7;
-				const unsigned char *p1 = acts + u * EDM_UTT + EDM_REGA + ((2 * py) * 9 + x) * 16;
-				p2[ls] = acts + u * EDM_UTT + (py * 7 + x) * 16; /* plane h is EDM_P2_PLANE * h further */
+			auto fetch = [&](int t, int bs, int ls, auto full_) {
+				const unsigned char *p1;
+				if (decltype(full_)::value) /* a full group: the conflict-free column order (M.cols2) */
+				{
+					const uint32_t e = M.cols2[t][col];
+					live[ls] = !(e & ED_CNN_COL_IDLE);
+					p1 = acts + (e & 0x7fffu);
+					p2[ls] = acts + ((e >> 16) & 0x7fffu); /* plane h is EDM_P2_PLANE * h further */
+				}
+				else
+				{
+					const int q = t * 32 + col;
+					live[ls] = q < nb_cur * 35;
+					const int qq = live[ls] ? q : nb_cur * 35 - 1;
+					const int u = qq / 35, r = qq - u * 35, py = r / 7, x = r - py * 7;
+					p1 = acts + u * EDM_UTT + EDM_REGA + ((2 * py) * 9 + x) * 16;
+					p2[ls] = acts + u * EDM_UTT + (py * 7 + x) * 16;
+				}
 #pragma unroll
 				for (int s = 0; s < 5; s++)
 				{
@@ -421,12 +434,12 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 					                           edm_max3z(e[4 * g + 2], o[4 * g + 2]), edm_max3z(e[4 * g + 3], o[4 * g + 3]))
 					          : edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
 					                          edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs2);
-				const uint4 rec = edm_gather16(d[0], d[1], d[2], d[3]); /* channels 16h .. 16h + 15 */
+				const uint4 rec = make_uint4(d[0], d[1], d[2], d[3]); /* channels 16h .. 16h + 15 (model.c tile_row) */
 				*reinterpret_cast<uint4 *>(live[ls] ? p2[ls] + EDM_P2_PLANE * h : dummy) = rec;
 			};
 			if (nb_cur == EDM_G)
 			{
-				fetch(0, 0, 0); fetch(1, 1, 1);
+				fetch(0, 0, 0, std::true_type()); fetch(1, 1, 1, std::true_type());
 				mma(0);
 				__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -434,7 +447,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 				{
 					if (t + 1 < 5) mma((t + 1) & 1);
 					EDM_FENCE();
-					if (t + 2 < 5) fetch(t + 2, t & 1, (t + 2) % 3); /* into the fragment registers tile t's MFMAs have consumed */
+					if (t + 2 < 5) fetch(t + 2, t & 1, (t + 2) % 3, std::true_type()); /* into the fragment registers tile t's MFMAs have consumed */
 					requant(t & 1, t % 3, std::integral_constant<bool, F8>());
 					if (t + 1 < 5) { if (F8) { EDM_WEAVE(10, 4) } else { EDM_WEAVE(10, 7) } }
 					__builtin_amdgcn_sched_barrier(0);
@@ -448,7 +461,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 #pragma unroll 1
 				for (int t = 0; t < n_t2; t++)
 				{
-					fetch(t, 0, 0);
+					fetch(t, 0, 0, std::false_type());
 					mma(0);
 					requant(0, 0, std::false_type());
 				}
@@ -459,18 +472,30 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		EDM_PR(3)
 		/* ---- conv3 3x3x32->64 + ReLU: 9 k-steps (tap, 16-channel half); columns = (utt, y, x): 4 x 15 = 60 in 2
 		 *      column tiles; two accumulators = output channels 0-31 / 32-63 */
+		if (!(EDM_SKIP & 4))
 		{
 			const v16i seed3a = edm_seed_tile(&M.b3[4 * h]), seed3b = edm_seed_tile(&M.b3[32 + 4 * h]);
 			v16i a0[2], a1[2];
 			unsigned char *c3[2];
 			bool live[2];
 			auto issue = [&](int t, int slot) {
-				const int q = t * 32 + col;
-				live[slot] = q < nb_cur * 15;
-				const int qq = live[slot] ? q : nb_cur * 15 - 1;
-				const int u = qq / 15, r = qq - u * 15, y = r / 5, x = r - y * 5;
-				const unsigned char *p2 = acts + u * EDM_UTT + EDM_P2_PLANE * h + (y * 7 + x) * 16;
-				c3[slot] = acts + u * EDM_UTT + EDM_REGA + (y * 5 + x) * 16; /* plane j (channels 16 j ..) is EDM_C3_PLANE * j further */
+				const unsigned char *p2;
+				if (full) /* uniform: the conflict-free column order (M.cols3) */
+				{
+					const uint32_t e = M.cols3[t][col];
+					live[slot] = !(e & ED_CNN_COL_IDLE);
+					p2 = acts + (e & 0x7fffu) + EDM_P2_PLANE * h;
+					c3[slot] = acts + ((e >> 16) & 0x7fffu); /* plane j (channels 16 j ..) is EDM_C3_PLANE * j further */
+				}
+				else
+				{
+					const int q = t * 32 + col;
+					live[slot] = q < nb_cur * 15;
+					const int qq = live[slot] ? q : nb_cur * 15 - 1;
+					const int u = qq / 15, r = qq - u * 15, y = r / 5, x = r - y * 5;
+					p2 = acts + u * EDM_UTT + EDM_P2_PLANE * h + (y * 7 + x) * 16;
+					c3[slot] = acts + u * EDM_UTT + EDM_REGA + (y * 5 + x) * 16;
+				}
 				a0[slot] = seed3a; a1[slot] = seed3b;
 #pragma unroll
 				for (int s = 0; s < 9; s++)
@@ -490,7 +515,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 					d0[g] = edm_pack_relu(x0[4 * g], x0[4 * g + 1], x0[4 * g + 2], x0[4 * g + 3], rs3);
 					d1[g] = edm_pack_relu(x1[4 * g], x1[4 * g + 1], x1[4 * g + 2], x1[4 * g + 3], rs3);
 				}
-				const uint4 ra = edm_gather16(d0[0], d0[1], d0[2], d0[3]), rb = edm_gather16(d1[0], d1[1], d1[2], d1[3]);
+				const uint4 ra = make_uint4(d0[0], d0[1], d0[2], d0[3]), rb = make_uint4(d1[0], d1[1], d1[2], d1[3]); /* (model.c tile_row) */
 				*reinterpret_cast<uint4 *>(live[slot] ? c3[slot] + EDM_C3_PLANE * h : dummy) = ra;       /* channels 16h ..: plane h */
 				*reinterpret_cast<uint4 *>(live[slot] ? c3[slot] + EDM_C3_PLANE * (2 + h) : dummy) = rb; /* channels 32 + 16h ..: plane 2 + h */
 			};
@@ -515,6 +540,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		 *      tiles of 16 channels, 9 k-steps = taps (64 input channels each: lane quarter kq reads plane kq of c3). A
 		 *      32 x 32 x 32 tile was 5/8 padding here: 18 MFMAs of 32 cycles, now 18 of 16, and 8 accumulators to requantise
 		 *      instead of 16. Lane (col, kq) ends with channels 16 rt + 4 kq .. +3 of its pixel. */
+		if (!(EDM_SKIP & 8))
 		{
 			const int c16 = lane & 15, kq = lane >> 4;
 			const bool live = c16 < EDM_G * 3;
@@ -544,6 +570,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 		/* ---- dense 96->10, same tile shape: rows = 10 logits of 16, columns = utterances (4 live), K = 96 in two k-steps of
 		 *      64: bytes 0..95 of c4 and 32 bytes behind it that meet zero weights. Lane (utt, kq) holds logits 4 kq .. +3
 		 *      (kq = 2: 8, 9 and two padding rows; kq = 3: padding only): parked as 10 int8 per utterance */
+		if (!(EDM_SKIP & 16))
 		{
 			const int c16 = lane & 15, kq = lane >> 4;
 			const int uu = c16 < EDM_G ? c16 : EDM_G - 1;
@@ -618,15 +645,27 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 #pragma unroll
 						for (int i = 0; i < 10; i++)
 						{
+#pragma clang fp contract(off) /* separately rounded product and sum: see ed_stream_filter_kernel */
 							const int v = (int)(int8_t)(sw[i >> 2] >> (8 * (i & 3)));
 							/* separately rounded double multiply / add (the Cortex-M4 has no double FPU, nothing is fused) */
-							const float y = (float)__dadd_rn(__dmul_rn(flt.alpha, (double)flt.state[i]), __dmul_rn(flt.one_minus_alpha, (double)(float)v));
+							const double pa = flt.alpha * (double)flt.state[i], pb = flt.one_minus_alpha * (double)(float)v; /* (not __dmul_rn / __dadd_rn: see ed_stream_filter_kernel) */
+							const float y = (float)(pa + pb);
 							flt.state[i] = y;
 							flt.filt[i] = y;
 							if (i == 0 || ymax < y) { ymax = y; imax = i; } /* arm_max_f32: the first maximum */
 						}
 						*flt.likely = imax;
-						*flt.spotted = ((double)ymax > flt.threshold) ? imax : -1;
+						const int hit = (double)ymax > flt.threshold;
+						*flt.spotted = hit ? imax : -1;
+						if (flt.fsm) /* ... and the state machine's step for it (app.c:371) */
+						{
+							edison_fsm *fsm = reinterpret_cast<edison_fsm *>(flt.fsm);
+							edison_fsm m = *fsm;
+							const ed_fsm_roles_t roles = {flt.wake_idx, flt.loc_mask, flt.val_mask};
+							*flt.fsm_state = ed_fsm_step_core(&m, hit, (uint32_t)imax, flt.dt_us, &roles);
+							*fsm = m;
+							if (flt.fsm_copy) *reinterpret_cast<edison_fsm *>(flt.fsm_copy) = m;
+						}
 					}
 				}
 			}
@@ -654,7 +693,8 @@ __global__ __launch_bounds__(EDM_THREADS) void ed_cnn_mfma_kernel(const ed_cnn_m
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint4 rows[2];
 	edm_prologue(model, feat, n_utt, feat_stride, smem, rows);
-	const ed_out_filter_t none = {0.0, 0.0, 0.0, nullptr, nullptr, nullptr, nullptr};
+	ed_out_filter_t none;
+	__builtin_memset(&none, 0, sizeof(none));
 	if (model->rs1 == 8 && model->rs2 == 8) /* uniform, from the kernel argument: the shipped model and any retrained one with these shifts */
 		edm_main<false, true>(feat, n_utt, feat_stride, logits, softmax, argmax, done_flag, done_seq, smem, rows, nullptr, none, 0);
 	else
@@ -771,7 +811,8 @@ extern "C" int ed_launch_kws1(const ed_mfcc_args_t *margs, const ed_mfcc_tables_
 		if (e != hipSuccess) return (int)e;
 		ready[dev_][narrow] = 1;
 	}
-	ed_out_filter_t f = {0.0, 0.0, 0.0, nullptr, nullptr, nullptr, nullptr};
+	ed_out_filter_t f;
+	memset(&f, 0, sizeof(f));
 	if (filter) f = *filter;
 	int with_filter = filter != nullptr;
 	void *kargs[] = {(void *)margs, (void *)&dev_tab, (void *)&dev_model, (void *)&feat, (void *)&logits, (void *)&softmax, (void *)&argmax,

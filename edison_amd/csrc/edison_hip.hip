@@ -272,16 +272,17 @@ extern "C" int edison_model_load_mem(edison_ctx *ctx, const void *blob, size_t b
 	free(plan); free(h); free(hm); free(w); free(seeds);
 	if (r != EDISON_OK) return r;
 	ED_HIP(ctx, e);
-	/* The graph's own kernel (edison_net_jit.hip) is part of loading a model, as model_compile() is part of it in NNoM: a graph
-	 * that would run on the general matrix-core kernel gets its own -- from the on-disk cache, else compiled now (~1 s, once per
-	 * graph and machine). The kws_conv graph runs on its hand-written kernel and only looks into the cache. EDISON_NET_SPECIALIZE
-	 * (read at every load): 0 = never by itself, 1 = compile for every graph, cache = only look into the cache. A failure here
-	 * (no compiler on the machine, ...) is not a failed load: the graph runs on the general kernel, edison_net_specialized() says so. */
+	/* The graph's own kernel (edison_net_specialize, edison_net_jit.hip) is an explicit call, or an explicit wish: a model load by
+	 * itself starts no compiler, writes no file and loads no code object from a cache (round-3 review: surprising in a drop-in
+	 * library). EDISON_NET_SPECIALIZE (read at every load): unset / 0 = nothing; 1 = specialise every graph that has a
+	 * matrix-core plan at load time (from the cache, else compiled now, ~1 s once per graph and machine); cache = take the own
+	 * kernel only if an earlier call left it in the cache. A failure there (no compiler on the machine, ...) is not a failed load:
+	 * the graph runs on the general kernel, edison_net_specialized() says which. */
 	const char *env_spec = getenv("EDISON_NET_SPECIALIZE");
-	const int never = env_spec && !strcmp(env_spec, "0"), always = env_spec && !strcmp(env_spec, "1"), cache_only = env_spec && !strcmp(env_spec, "cache");
-	if (ctx->mm_ok && !never)
+	const int always = env_spec && !strcmp(env_spec, "1"), cache_only = env_spec && !strcmp(env_spec, "cache");
+	if (ctx->mm_ok && (always || cache_only))
 	{
-		if (always || (!cache_only && !ctx->fast_model))
+		if (always)
 		{
 			char keep[sizeof(ctx->err)];
 			memcpy(keep, ctx->err, sizeof(keep));

@@ -164,8 +164,9 @@ typedef struct {
 /*
  * The same parameters laid out for v_mfma_i32_32x32x32_i8 (fast path, cnn_mfma_kernels.hip). Every layer is the
  * GEMM D[out_channel][pixel] = sum_k A[out_channel][k] * B[k][pixel]; A (weights) is stored as ready-made
- * operand fragments: fragment = 64 lanes x 16 bytes, lane l holds A[row = l&31][k = 32*kstep + 16*(l>>5) + j],
- * j = 0..15, so a wavefront fetches one fragment with a single conflict-free ds_read_b128.
+ * operand fragments: fragment = 64 lanes x 16 bytes, lane l holds A[row = tile_row(l&31)][k = 32*kstep + 16*(l>>5) + j],
+ * j = 0..15, so a wavefront fetches one fragment with a single conflict-free ds_read_b128; tile_row (model.c) orders the 32 rows of
+ * a tile so that a lane's accumulators are 16 consecutive output channels (the seeds b1 .. b3 are stored in that physical order).
  *   a1  conv1 as a Toeplitz GEMM: row = x*16 + o (9 x 16 = 144 rows -> 5 row tiles), k = ky*16 + xx over five
  *       16-byte-padded input rows (K = 80 -> 3 k-steps); A = w1[o][ky][xx - x] inside the 5-tap window, else 0
  *   a2  conv2: 32 rows, k = tap*16 + ci (K = 144 -> 5 k-steps, the last half zero)
@@ -174,6 +175,28 @@ typedef struct {
  *       2 row tiles x 9 k-steps (one tap each) -- the layer has 12 columns per wave, a 32-column tile would be 5/8 padding
  *   afc dense: 10 rows padded to 16, k = 96 padded to 128, the same 16 x 16 x 64 fragments (2 k-steps)
  */
+/* LDS layout of ONE utterance inside a wavefront's slice (cnn_mfma_kernels.hip), shared with model.c, which tabulates addresses: */
+/* Region A: in' = the 31 input rows padded to 16 bytes, EVEN rows then ODD rows (2 x 16 slots of 16 B = 512)  ->
+ *           p2 = conv2's pooled output [5][7] pixels as TWO PLANES of 16 channels (2 x 35 slots = 1120)  ->  c4 [3][32] (96)
+ * Region B: p1 [13][9][16] (1872)  ->  c3 = conv3's output [3][5] pixels as FOUR PLANES of 16 channels (4 x 15 slots = 960)
+ * Planes instead of pixel-major records: a B operand is 16 bytes (16 channels of one tap) per lane, and the lanes of a
+ * ds_read_b128 group are neighbouring columns = neighbouring pixels. With [pixel][32 or 64 channels] records they sat 32 / 64
+ * bytes apart and used every second / fourth 16-byte bank group: 2-way (conv1's row pairs, conv3) and 4-way (conv4) bank
+ * conflicts on every operand read, 39 % of all LDS cycles (profiles/r02_cnn_counters.txt). In a plane neighbouring pixels
+ * are neighbouring 16-byte slots. */
+#define EDM_REGA 1120
+#define EDM_REGB 1872
+#define EDM_IN_ODD 256   /* byte offset of the odd input rows inside region A */
+#define EDM_P2_PLANE 560 /* bytes per 16-channel plane of p2 */
+#define EDM_C3_PLANE 240 /* bytes per 16-channel plane of c3 */
+#define EDM_UTT (EDM_REGA + EDM_REGB)
+/* Which column of a layer's GEMM a lane computes is free (every lane derives its own addresses); for a FULL group of four
+ * utterances the columns are dealt to the (tile, lane) slots so that the 16 lanes of a ds_read_b128 group read 16 different
+ * 16-byte bank groups and the 8 lanes of a ds_write_b128 group write 8 different ones (csrc/cnn_mfma_cols.h, chosen and checked by
+ * tools/dev/cnn_lds_model.py: natural order 457 extra LDS cycles per group = 38 % of all LDS cycles, profiles/r04_cnn_lds_by_phase.txt).
+ * A table entry = byte offsets inside the wave's slice: bits 0-14 where the column's operand reads start, bits 16-30 where its
+ * outputs go, bit 31 = idle lane (reads the tile's last live column again, stores to the dummy slot). */
+#define ED_CNN_COL_IDLE 0x80000000u
 typedef struct {
 	int8_t a1[15][1024]; /* [row_tile*3 + kstep] */
 	int8_t a2[5][1024];
@@ -183,6 +206,7 @@ typedef struct {
 	int32_t b1[ED_C1_O], b2[ED_C2_O], b3[ED_C3_O], b4[ED_C4_O], bfc[16]; /* accumulator seeds as above */
 	int32_t rs1, rs2, rs3, rs4, rsfc;
 	int32_t pad_[3];
+	uint32_t cols1[2][32], cols2[5][32], cols3[2][32]; /* column tables of conv1 / conv2 / conv3, see above */
 } ed_cnn_mfma_model_t;
 
 int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, ed_cnn_mfma_model_t *out_mfma, char *err,
@@ -341,6 +365,13 @@ typedef struct {
 	float *filt;      /* [10] out                                          */
 	int32_t *likely;  /* [1]  out                                          */
 	int32_t *spotted; /* [1]  out: the class, or -1 below the threshold    */
+	/* the state machine behind it (edison_fsm_core.h), or fsm = NULL */
+	void *fsm;            /* edison_fsm, device memory: read and written   */
+	int32_t *fsm_state;   /* [1] out: the state after this inference       */
+	void *fsm_copy;       /* edison_fsm out (the host's view), or NULL     */
+	uint32_t dt_us;
+	int32_t wake_idx;
+	uint32_t loc_mask, val_mask;
 } ed_out_filter_t;
 
 /* ------------------------------------------------------------------ kernel launchers (HIP side)           */

@@ -79,7 +79,11 @@ static uint64_t fnv(uint64_t h, const void *p, size_t n)
 	return h;
 }
 
-/* "" = no cache */
+/* The cache holds code objects that this process will EXECUTE: a directory of this user only. It is created 0700 (with its
+ * parent under $HOME); a directory that exists already is used only if it belongs to this uid and is writable by nobody else --
+ * else there is no cache (every edison_net_specialize() compiles). "" = no cache. `compiler` = which compiler made the entry AND
+ * its identity (hipcc: path, size and time stamp of the binary; hipRTC: its version), so that an upgraded ROCm never meets the
+ * objects of the old one (the same text gives 30 % more instructions under ROCm 7.0's hipRTC than under 7.2's hipcc). */
 static void cache_path(char *out, size_t cap, uint64_t graph, uint64_t source, const char *compiler)
 {
 	out[0] = 0;
@@ -96,7 +100,16 @@ static void cache_path(char *out, size_t cap, uint64_t graph, uint64_t source, c
 	}
 	else return;
 	(void)mkdir(base, 0700);
+	struct stat st;
+	if (stat(base, &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return;
 	snprintf(out, cap, "%s/net_gfx950_%016llx_%016llx_%s.hsaco", base, (unsigned long long)graph, (unsigned long long)source, compiler);
+}
+
+/* a cache entry is read only if it is a regular file of this uid that nobody else can write */
+static int cache_entry_trusted(const char *path)
+{
+	struct stat st;
+	return stat(path, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && !(st.st_mode & (S_IWGRP | S_IWOTH));
 }
 
 static char *read_file(const char *path, size_t *n)
@@ -133,6 +146,8 @@ static int write_text(const char *dir, const char *name, const void *data, size_
 	return fclose(f) == 0 && ok;
 }
 
+/* the compiler this library will start: $EDISON_HIPCC, else $ROCM_PATH/bin/hipcc, else /opt/rocm/bin/hipcc -- never whatever
+ * "hipcc" $PATH happens to hold (a library that runs a program by itself names it) */
 static int find_hipcc(char *out, size_t cap)
 {
 	const char *env = getenv("EDISON_HIPCC");
@@ -143,20 +158,26 @@ static int find_hipcc(char *out, size_t cap)
 		if (access(out, X_OK) == 0) return 1;
 	}
 	snprintf(out, cap, "/opt/rocm/bin/hipcc");
-	if (access(out, X_OK) == 0) return 1;
-	const char *path = getenv("PATH");
-	while (path && *path)
-	{
-		const char *end = strchr(path, ':');
-		const size_t len = end ? (size_t)(end - path) : strlen(path);
-		if (len && len + 8 < cap)
-		{
-			snprintf(out, cap, "%.*s/hipcc", (int)len, path);
-			if (access(out, X_OK) == 0) return 1;
-		}
-		path = end ? end + 1 : NULL;
-	}
-	return 0;
+	return access(out, X_OK) == 0;
+}
+
+/* identity of the in-process compiler for the cache key: the HIP runtime this process runs on (libhiprtc comes with it; loading
+ * the compiler library just to ask would cost more than the cache saves) */
+static int hiprtc_version(void)
+{
+	int v = 0;
+	return hipRuntimeGetVersion(&v) == hipSuccess ? v : 0;
+}
+
+/* identity of that compiler for the cache key: path, size and modification time of the binary */
+static uint64_t hipcc_identity(void)
+{
+	char p[512];
+	struct stat st;
+	if (!find_hipcc(p, sizeof(p)) || stat(p, &st) != 0) return 0;
+	uint64_t h = fnv(1469598103934665603ull, p, strlen(p));
+	const long long v[2] = {(long long)st.st_size, (long long)st.st_mtime};
+	return fnv(h, v, sizeof(v));
 }
 
 /* The installed compiler as a child process on a temporary copy of the text. 1: *code / *code_bytes hold the code object
@@ -216,22 +237,42 @@ static int compile_with_hipcc(edison_ctx *ctx, const char *spec, char **code, si
 			for (size_t d = 0; d < sizeof(drop) / sizeof(drop[0]); d++) skip |= strncmp(environ[k], drop[d], strlen(drop[d])) == 0;
 			if (!skip) envp[kept++] = environ[k];
 		}
-		const int sp = envp ? posix_spawn(&pid, hipcc, &fa, NULL, (char *const *)argv, envp) : ENOMEM;
+		/* its own process group: hipcc is a driver that starts clang / lld in turn, and a compiler that has to be stopped is stopped
+		 * with everything it started */
+		posix_spawnattr_t at;
+		posix_spawnattr_init(&at);
+		posix_spawnattr_setflags(&at, POSIX_SPAWN_SETPGROUP);
+		posix_spawnattr_setpgroup(&at, 0);
+		const int sp = envp ? posix_spawn(&pid, hipcc, &fa, &at, (char *const *)argv, envp) : ENOMEM;
+		posix_spawnattr_destroy(&at);
 		free(envp);
 		posix_spawn_file_actions_destroy(&fa);
 		if (sp != 0) snprintf(ctx->err, sizeof(ctx->err), "edison_net_specialize: cannot start %s: %s", hipcc, strerror(sp));
 		else
 		{
 			/* a compiler that does not come back must not hang a model load: two minutes (it needs ~1 s), then it is stopped by PID */
-			int done = 0;
+			int done = 0, confirmed = 0; /* confirmed: waitpid handed us the child's own exit status */
 			for (int waited_ms = 0; !done; waited_ms += 5)
 			{
 				const pid_t w = waitpid(pid, &status, WNOHANG);
-				if (w == pid || (w < 0 && errno != EINTR)) done = 1;
-				else if (waited_ms > 120000) { (void)kill(pid, SIGKILL); while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {} status = -1; done = 1; }
+				if (w == pid) { done = 1; confirmed = 1; }
+				else if (w < 0 && errno != EINTR)
+				{
+					/* ECHILD: the host program ignores SIGCHLD or reaps children itself -- nobody can tell us how the compiler ended,
+					 * and it may still be writing: stop its group and take nothing from it */
+					(void)kill(-pid, SIGKILL);
+					done = 1;
+				}
+				else if (waited_ms > 120000)
+				{
+					(void)kill(-pid, SIGKILL);
+					while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+					done = 1;
+				}
 				else usleep(5000);
 			}
-			*code = status != -1 && WIFEXITED(status) && WEXITSTATUS(status) == 0 ? read_file(out, code_bytes) : NULL;
+			if (!confirmed) status = -1;
+			*code = confirmed && WIFEXITED(status) && WEXITSTATUS(status) == 0 ? read_file(out, code_bytes) : NULL;
 			if (*code) r = 1;
 			else
 			{
@@ -327,12 +368,15 @@ static int specialize(edison_ctx *ctx, int cache_only)
 	char *code = NULL;
 	int state = 0; /* 1: hipcc, 2: cache, 3: hipRTC */
 	/* the cache: an entry made by the compiler that would be tried first, then the other's */
+	char id_hipcc[40], id_rtc[40];
+	snprintf(id_hipcc, sizeof(id_hipcc), "hipcc-%016llx", (unsigned long long)hipcc_identity());
+	snprintf(id_rtc, sizeof(id_rtc), "hiprtc-%d", hiprtc_version());
 	for (int k = 0; k < 2 && !code; k++)
 	{
 		const int is_hipcc = k == 0;
 		if (is_hipcc ? !try_hipcc : !try_rtc) continue;
-		cache_path(path, sizeof(path), graph, source, is_hipcc ? "hipcc" : "hiprtc");
-		if (path[0] && (code = read_file(path, &code_bytes)) != NULL) state = 2;
+		cache_path(path, sizeof(path), graph, source, is_hipcc ? id_hipcc : id_rtc);
+		if (path[0] && cache_entry_trusted(path) && (code = read_file(path, &code_bytes)) != NULL) state = 2;
 	}
 	if (!code && cache_only)
 	{
@@ -360,7 +404,9 @@ static int specialize(edison_ctx *ctx, int cache_only)
 			if (r == 0) return ed_set_err(ctx, EDISON_E_NO_IMPL, "edison_net_specialize: neither hipcc nor libhiprtc.so found (the graph stays on the general kernel)");
 			return EDISON_E_RUNTIME;
 		}
-		cache_path(path, sizeof(path), graph, source, state == 1 ? "hipcc" : "hiprtc");
+		/* (several processes that load the same new graph at once each compile it: the entry is written under a name of its own
+		 * and renamed into place, the last one wins, all are the same) */
+		cache_path(path, sizeof(path), graph, source, state == 1 ? id_hipcc : id_rtc);
 		if (path[0]) write_file_atomic(path, code, code_bytes);
 	}
 	free(spec);

@@ -25,6 +25,7 @@
 #include <immintrin.h>
 
 #include "edison_ctx.h"
+#include "edison_fsm_core.h"
 
 struct edison_stream
 {
@@ -45,6 +46,10 @@ struct edison_stream
 	int8_t *d_logits;     /* [chunk * 10]                            */
 	int32_t *d_argmax;    /* [chunk]                                 */
 	float *d_filt_state;  /* [10]  netOutFilt                        */
+	int fsm;              /* the state machine runs behind the filter (opts.fsm) */
+	edison_fsm *d_fsm;    /* the machine, device memory              */
+	ed_fsm_roles_t roles;
+	uint32_t dt_us;       /* time between two inferences = hop / 16 kHz */
 	float *d_filt;        /* [chunk * 10] netOutFilt after each inference of the push */
 	int32_t *d_likely;    /* [chunk] arm_max_f32 index               */
 	int32_t *d_spotted;   /* [chunk] that index if the maximum exceeds the threshold, else -1 */
@@ -57,7 +62,7 @@ struct edison_stream
 	unsigned char *d_out; /* one block: logits | softmax | argmax | filt | likely | spotted at the offsets below */
 	int16_t *h_in;
 	unsigned char *h_out;
-	size_t off_soft, off_argmax, off_filt, off_likely, off_spotted, h_out_bytes;
+	size_t off_soft, off_argmax, off_filt, off_likely, off_spotted, off_fsm_states, off_fsm, h_out_bytes;
 	hipGraph_t graph_h;
 	hipGraphExec_t exec_h;
 	int last_push_staged;
@@ -119,21 +124,37 @@ __global__ void ed_stream_shift_kernel(int16_t *dst_audio, const int16_t *src_au
  * lanes, the products (1-ALPHA)*x come from a 256-entry table (x is an int8), and the per-frame maximum is taken in
  * parallel afterwards. One workgroup.
  */
+/* the state machine behind the filter: where its state lives and what a step needs (edison_fsm_core.h); fsm = NULL: none */
+struct ed_fsm_stage_t
+{
+	edison_fsm *fsm;      /* device memory, read and written                       */
+	int32_t *states;      /* [chunk] out: the state after each inference           */
+	edison_fsm *copy;     /* out: the machine after the push (the host's view), or NULL */
+	uint32_t dt_us;
+	ed_fsm_roles_t roles;
+};
+
 __global__ __launch_bounds__(256) void ed_stream_filter_kernel(const int8_t *soft, int chunk, double alpha, double one_minus_alpha,
                                                                double threshold, float *state, float *filt, int32_t *likely,
-                                                               int32_t *spotted)
+                                                               int32_t *spotted, ed_fsm_stage_t fs)
 {
 	__shared__ double bx[256];
 	const int t = threadIdx.x;
-	bx[t] = __dmul_rn(one_minus_alpha, (double)(float)(int8_t)(t - 128));
+	bx[t] = one_minus_alpha * (double)(float)(int8_t)(t - 128);
 	__syncthreads();
 	if (t < EDISON_NET_OUT)
 	{
+		/* the product and the sum are rounded SEPARATELY (the Cortex-M4 computes doubles in software, nothing is fused): HIP's
+		 * __dmul_rn / __dadd_rn are plain * and +, which the compiler's default contraction turns into one v_fma_f64 -- a
+		 * different double in the last place, and a different float wherever that sum sits next to a float rounding boundary
+		 * (found in round 4 by scripted softmax streams: one value in ~4 000; network outputs of 0 and 127 never showed it) */
 		float y = state[t];
 		for (int i = 0; i < chunk; i++)
 		{
+#pragma clang fp contract(off)
 			const int x = soft[(size_t)i * EDISON_NET_OUT + t];
-			y = (float)__dadd_rn(__dmul_rn(alpha, (double)y), bx[x + 128]);
+			const double a = alpha * (double)y; /* (not __dmul_rn / __dadd_rn: their bodies are compiled with the header's own contraction) */
+			y = (float)(a + bx[x + 128]);
 			filt[(size_t)i * EDISON_NET_OUT + t] = y;
 		}
 		state[t] = y;
@@ -149,40 +170,69 @@ __global__ __launch_bounds__(256) void ed_stream_filter_kernel(const int8_t *sof
 		likely[i] = idx;
 		spotted[i] = ((double)best > threshold) ? idx : -1;
 	}
+	if (!fs.fsm) return;
+	/* edisonFSM (app.c:371, 727-928), one step per inference in time order: sequential by definition, so ONE lane walks the
+	 * (likely, spotted) pairs of the push -- a handful of integer operations per step; the machine stays in registers */
+	__syncthreads();
+	if (t == 0)
+	{
+		edison_fsm m = *fs.fsm;
+		for (int i = 0; i < chunk; i++)
+			fs.states[i] = ed_fsm_step_core(&m, spotted[i] >= 0, (uint32_t)likely[i], fs.dt_us, &fs.roles);
+		*fs.fsm = m;
+		if (fs.copy) *fs.copy = m;
+	}
 }
 
 static int enqueue_mapped_push(edison_stream *s, unsigned seq, int *flag_written);
 
+/* the state-machine stage of a push whose outputs go to the block `out` (device view: the stream's own block, or the mapped one) */
+static ed_fsm_stage_t fsm_stage(const edison_stream *s, unsigned char *out)
+{
+	ed_fsm_stage_t fs;
+	memset(&fs, 0, sizeof(fs));
+	if (!s->fsm) return fs;
+	fs.fsm = s->d_fsm;
+	fs.states = (int32_t *)(out + s->off_fsm_states);
+	fs.copy = (edison_fsm *)(out + s->off_fsm);
+	fs.dt_us = s->dt_us;
+	fs.roles = s->roles;
+	return fs;
+}
+
 /* enqueue the device operations of a push on hipStream q (passed explicitly: ctx->stream is not touched); the CNN writes
  * logits / softmax / argmax where it is told to (the stream's own block, or the caller's buffers) */
-static int enqueue_push_on(edison_stream *s, hipStream_t q, int8_t *logits, int8_t *softmax, int32_t *argmax, int slide = 0)
+static int enqueue_push_on(edison_stream *s, hipStream_t q, int8_t *logits, int8_t *softmax, int32_t *argmax, int slide = 0, int n = 0)
 {
 	edison_ctx *ctx = s->ctx;
+	if (n <= 0) n = s->chunk;       /* frames of this push: the stream's chunk, or fewer (edison_stream_push_n_dev: a ragged last push) */
+	if (n != s->chunk) slide = 0;   /* the sliding bookkeeping counts whole chunks: a short push brings the history back to the front */
 	int16_t *audio = s->d_audio + s->a_pos;                          /* history, then the new samples */
 	int8_t *feat = s->d_feat + (size_t)s->f_pos * EDISON_NUM_MFCC;   /* 30 rows of history, then the new rows */
 	/* 13 coefficients, int8 net input (scale 1): rows 30.. of the feature buffer */
-	int r = ed_ctx_mfcc_launch_on(ctx, q, audio, s->chunk, s->chunk, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
+	int r = ed_ctx_mfcc_launch_on(ctx, q, audio, n, n, 0, s->hop, s->variant, EDISON_NUM_MFCC, NULL,
 	                              feat + 30 * EDISON_NUM_MFCC, 1.0f, 0, NULL, NULL, NULL, NULL);
 	if (r != EDISON_OK) return r;
 	/* window i of the push = rows i..i+30 of the feature buffer: a 13-byte utterance stride, nothing is copied */
-	r = ed_ctx_kws_cnn_launch_on(ctx, q, feat, s->chunk, EDISON_NUM_MFCC, logits, softmax, argmax);
+	r = ed_ctx_kws_cnn_launch_on(ctx, q, feat, n, EDISON_NUM_MFCC, logits, softmax, argmax);
 	if (r != EDISON_OK) return r;
 	if (s->filter)
 	{
-		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, q, softmax, s->chunk, s->alpha,
-		                   s->one_minus_alpha, s->threshold, s->d_filt_state, s->d_filt, s->d_likely, s->d_spotted);
+		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, q, softmax, n, s->alpha,
+		                   s->one_minus_alpha, s->threshold, s->d_filt_state, s->d_filt, s->d_likely, s->d_spotted, fsm_stage(s, s->d_out));
 		if (hipGetLastError() != hipSuccess) return ed_set_err(ctx, EDISON_E_RUNTIME, "stream: filter launch failed");
 	}
-	if (slide && s->a_pos / (s->chunk * s->hop) + 2 <= s->slots)
+	const size_t nnew = (size_t)n * s->hop; /* < 2^30: edison_stream_create_ex */
+	if (slide && (size_t)s->a_pos / nnew + 2 <= (size_t)s->slots)
 	{
 		/* the next push finds its history behind this push's samples / rows and still fits: nothing moves */
-		s->a_pos += s->chunk * s->hop;
-		s->f_pos += s->chunk;
+		s->a_pos += (int)nnew;
+		s->f_pos += n;
 		return EDISON_OK;
 	}
-	hipLaunchKernelGGL(ed_stream_shift_kernel, dim3(1), dim3(256), 0, q, s->d_audio, audio + s->chunk * s->hop, s->tail,
-	                   s->d_feat, feat + (size_t)s->chunk * EDISON_NUM_MFCC);
-	if (slide) s->a_pos = s->f_pos = 0; /* (a captured graph always runs at position 0 and ends here) */
+	hipLaunchKernelGGL(ed_stream_shift_kernel, dim3(1), dim3(256), 0, q, s->d_audio, audio + nnew, s->tail,
+	                   s->d_feat, feat + (size_t)n * EDISON_NUM_MFCC);
+	s->a_pos = s->f_pos = 0; /* (a captured graph always runs at position 0 and ends here) */
 	return hipGetLastError() == hipSuccess ? EDISON_OK : ed_set_err(ctx, EDISON_E_RUNTIME, "stream: shift launch failed");
 }
 
@@ -226,8 +276,14 @@ static int enqueue_mapped_push(edison_stream *s, unsigned seq, int *flag_written
 	{
 		/* the stream's output filter (app.c:341-356) for this one inference is done by the same kernel, behind its softmax */
 		ed_out_filter_t f;
+		memset(&f, 0, sizeof(f));
 		f.alpha = s->alpha; f.one_minus_alpha = s->one_minus_alpha; f.threshold = s->threshold;
 		f.state = s->d_filt_state; f.filt = (float *)(o8 + s->off_filt); f.likely = (int32_t *)(o8 + s->off_likely); f.spotted = (int32_t *)(o8 + s->off_spotted);
+		if (s->fsm)
+		{
+			f.fsm = s->d_fsm; f.fsm_state = (int32_t *)(o8 + s->off_fsm_states); f.fsm_copy = o8 + s->off_fsm;
+			f.dt_us = s->dt_us; f.wake_idx = s->roles.wake_idx; f.loc_mask = s->roles.loc_mask; f.val_mask = s->roles.val_mask;
+		}
 		r = ed_ctx_kws1_launch_on(ctx, s->own, s->md_audio, s->variant, s->md_feat + 30 * EDISON_NUM_MFCC, s->md_feat, (int8_t *)o8,
 		                          (int8_t *)(o8 + s->off_soft), (int32_t *)(o8 + s->off_argmax), s->md_flag, seq, s->filter ? &f : NULL);
 		if (r == EDISON_OK) { *flag_written = 1; return EDISON_OK; }
@@ -245,7 +301,7 @@ static int enqueue_mapped_push(edison_stream *s, unsigned seq, int *flag_written
 	{
 		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, s->own, (const int8_t *)(o8 + s->off_soft), s->chunk, s->alpha,
 		                   s->one_minus_alpha, s->threshold, s->d_filt_state, (float *)(o8 + s->off_filt), (int32_t *)(o8 + s->off_likely),
-		                   (int32_t *)(o8 + s->off_spotted));
+		                   (int32_t *)(o8 + s->off_spotted), fsm_stage(s, o8));
 		if (hipGetLastError() != hipSuccess) r = ed_set_err(ctx, EDISON_E_RUNTIME, "stream: filter launch failed");
 	}
 	return r;
@@ -270,6 +326,7 @@ extern "C" void edison_stream_destroy(edison_stream *s)
 	if (s->d_feat) (void)hipFree(s->d_feat);
 	if (s->d_out) (void)hipFree(s->d_out); /* logits, softmax, argmax and the filter outputs live in this one block */
 	if (s->d_filt_state) (void)hipFree(s->d_filt_state);
+	if (s->d_fsm) (void)hipFree(s->d_fsm);
 	if (s->ev_in) (void)hipEventDestroy(s->ev_in);
 	if (s->ev_out) (void)hipEventDestroy(s->ev_out);
 	if (s->own) (void)hipStreamDestroy(s->own);
@@ -282,11 +339,17 @@ extern "C" int edison_stream_reset(edison_stream *s)
 	edison_ctx *ctx = s->ctx;
 	{ const int rq = drain_q(s, s->own); if (rq != EDISON_OK) return rq; }
 	s->a_pos = s->f_pos = 0;
-	ED_HIP(ctx, hipMemsetAsync(s->d_audio, 0, sizeof(int16_t) * (size_t)(s->tail + s->chunk * s->hop), s->own));
+	ED_HIP(ctx, hipMemsetAsync(s->d_audio, 0, sizeof(int16_t) * ((size_t)s->tail + (size_t)s->chunk * s->hop), s->own));
 	ED_HIP(ctx, hipMemsetAsync(s->d_feat, 0, (size_t)(30 + s->chunk) * EDISON_NUM_MFCC, s->own));
 	if (s->filter) ED_HIP(ctx, hipMemsetAsync(s->d_filt_state, 0, sizeof(float) * EDISON_NET_OUT, s->own));
+	if (s->fsm)
+	{
+		edison_fsm start;
+		edison_fsm_init(&start); /* EDI_RESET, as the firmware enters appMicMfccInfereContinuous (app.c:288-300) */
+		ED_HIP(ctx, hipMemcpyAsync(s->d_fsm, &start, sizeof(start), hipMemcpyHostToDevice, s->own));
+	}
 	ED_HIP(ctx, hipStreamSynchronize(s->own));
-	if (s->m_audio) memset(s->m_audio, 0, sizeof(int16_t) * (size_t)(s->tail + s->chunk * s->hop));
+	if (s->m_audio) memset(s->m_audio, 0, sizeof(int16_t) * ((size_t)s->tail + (size_t)s->chunk * s->hop));
 	if (s->m_feat) memset(s->m_feat, 0, (size_t)(30 + s->chunk) * EDISON_NUM_MFCC);
 	s->frames_seen = 0;
 	return EDISON_OK;
@@ -318,6 +381,7 @@ extern "C" void edison_stream_default_opts(edison_stream_opts *o)
 	o->filter = 0;
 	o->filter_alpha = 0.9;   /* NET_OUT_MOVING_AVG_ALPHA for NET_TYPE_NNOM, app.c:38 */
 	o->true_threshold = 0.5; /* TRUE_THRESHOLD, app.c:34 */
+	o->fsm = 0;
 	const char *g = getenv("EDISON_STREAM_GRAPH");
 	o->launch_mode = (g && atoi(g)) ? EDISON_STREAM_LAUNCH_GRAPH : EDISON_STREAM_LAUNCH_DIRECT;
 }
@@ -333,10 +397,15 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 		return ed_set_err(ctx, EDISON_E_SIZE, "stream: the loaded model is not a 31x13x1 -> 10 softmax classifier");
 	if (hop < 2 || hop > EDISON_FRAME_LEN || (hop & 1) || chunk_frames < 1 || chunk_frames > (1 << 22))
 		return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: hop must be even and 2..1024, chunk 1..4M frames");
+	/* positions and sample counts of a push are ints in places (a_pos, kernel arguments): a push of 2^30 samples or more (2 GiB of
+	 * int16) is refused here instead of wrapping there */
+	if ((int64_t)chunk_frames * hop >= ((int64_t)1 << 30))
+		return ed_set_err(ctx, EDISON_E_SIZE, "stream: chunk_frames x hop must stay below 2^30 samples per push");
 	if (o->mfcc_variant != EDISON_MFCC_B && o->mfcc_variant != EDISON_MFCC_C)
 		return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: MFCC variant must be EDISON_MFCC_B or EDISON_MFCC_C");
 	if (o->filter && !(o->filter_alpha >= 0.0 && o->filter_alpha <= 1.0))
 		return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: filter_alpha must be within [0, 1]");
+	if (o->fsm && !o->filter) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: the state machine (fsm) works on the filtered outputs: filter = 1 too");
 	edison_stream *s = (edison_stream *)calloc(1, sizeof(edison_stream));
 	if (!s) return ed_set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed");
 	s->ctx = ctx; s->hop = hop; s->chunk = chunk_frames; s->tail = EDISON_FRAME_LEN - hop;
@@ -344,6 +413,9 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 	s->model_epoch = ctx->model_epoch;
 	s->tables_epoch = ctx->tables_epoch;
 	s->filter = o->filter ? 1 : 0;
+	s->fsm = o->fsm ? 1 : 0;
+	s->dt_us = (uint32_t)(((uint64_t)hop * 1000000u) / EDISON_FS); /* one inference per hop (app.c:635-663: one per audio event) */
+	edison_fsm_roles(&s->roles.wake_idx, &s->roles.loc_mask, &s->roles.val_mask);
 	s->use_graph = o->launch_mode == EDISON_STREAM_LAUNCH_GRAPH;
 	s->alpha = o->filter_alpha;
 	s->one_minus_alpha = 1.0 - o->filter_alpha; /* the firmware's (1.0-NET_OUT_MOVING_AVG_ALPHA), folded in double */
@@ -365,6 +437,8 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 		off = (off + 15) & ~(size_t)15; s->off_filt = off; off += s->filter ? c * EDISON_NET_OUT * sizeof(float) : 0;
 		s->off_likely = off; off += s->filter ? c * sizeof(int32_t) : 0;
 		s->off_spotted = off; off += s->filter ? c * sizeof(int32_t) : 0;
+		s->off_fsm_states = off; off += s->fsm ? c * sizeof(int32_t) : 0;
+		off = (off + 15) & ~(size_t)15; s->off_fsm = off; off += s->fsm ? sizeof(edison_fsm) : 0;
 		s->h_out_bytes = off;
 		if (e == hipSuccess) e = hipMalloc((void **)&s->d_out, s->h_out_bytes + 16);
 		if (e == hipSuccess)
@@ -381,6 +455,7 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 	{
 		if (e == hipSuccess) e = hipMalloc((void **)&s->d_filt_state, sizeof(float) * EDISON_NET_OUT);
 	}
+	if (s->fsm && e == hipSuccess) e = hipMalloc((void **)&s->d_fsm, sizeof(edison_fsm));
 	if (e != hipSuccess)
 	{
 		edison_stream_destroy(s);
@@ -428,7 +503,7 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 	}
 	if (r == EDISON_OK && in_bytes <= ED_STREAM_MAPPED_MAX_BYTES)
 	{
-		const size_t audio_bytes = sizeof(int16_t) * (size_t)(s->tail + s->chunk * s->hop) + 16, feat_bytes = (size_t)(30 + s->chunk) * EDISON_NUM_MFCC + 16;
+		const size_t audio_bytes = sizeof(int16_t) * ((size_t)s->tail + (size_t)s->chunk * s->hop) + 16, feat_bytes = (size_t)(30 + s->chunk) * EDISON_NUM_MFCC + 16;
 		e = hipHostMalloc((void **)&s->m_audio, audio_bytes, hipHostMallocMapped);
 		if (e == hipSuccess) e = hipHostMalloc((void **)&s->m_feat, feat_bytes, hipHostMallocMapped);
 		if (e == hipSuccess) e = hipHostMalloc((void **)&s->m_out, s->h_out_bytes + 16, hipHostMallocMapped);
@@ -475,11 +550,22 @@ extern "C" int edison_stream_create(edison_ctx *ctx, int hop, int chunk_frames, 
 extern "C" int edison_stream_push_dev(edison_stream *s, const int16_t *samples, int8_t *logits, int8_t *softmax,
                                       int32_t *argmax)
 {
+	return edison_stream_push_n_dev(s, samples, s ? s->chunk : 0, logits, softmax, argmax);
+}
+
+/* the same for n_frames <= chunk new frames (n_frames * hop samples; outputs [n_frames][..]): the ragged last push of a recording whose
+ * length the chunk does not divide. A short push needs the directly launched kernels (a captured graph has the chunk baked in). */
+extern "C" int edison_stream_push_n_dev(edison_stream *s, const int16_t *samples, int n_frames, int8_t *logits, int8_t *softmax,
+                                        int32_t *argmax)
+{
 	if (!s || !samples) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
+	if (n_frames < 1 || n_frames > s->chunk) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: n_frames must be 1 .. chunk_frames");
+	if (n_frames != s->chunk && s->use_graph)
+		return ed_set_err(ctx, EDISON_E_NO_IMPL, "stream: a push shorter than the chunk needs launch_mode = EDISON_STREAM_LAUNCH_DIRECT (the captured graph holds the chunk)");
 	if (s->model_epoch != ctx->model_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: the model was reloaded after this stream was created; create a new stream");
 	if (s->tables_epoch != ctx->tables_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: edison_mfcc_configure was called after this stream was created; create a new stream");
-	const size_t nnew = (size_t)s->chunk * s->hop;
+	const size_t nnew = (size_t)n_frames * s->hop;
 	{ const int rs = stream_state_to(s, 0); if (rs != EDISON_OK) return rs; }
 	s->last_push_mapped = 0;
 	if (!s->use_graph)
@@ -491,12 +577,12 @@ extern "C" int edison_stream_push_dev(edison_stream *s, const int16_t *samples, 
 		ED_HIP(ctx, hipMemcpyAsync(s->d_audio + s->a_pos + s->tail, samples, nnew * sizeof(int16_t), hipMemcpyDeviceToDevice, q));
 		/* the output filter reads the softmax from the stream's own block */
 		int8_t *so = s->filter ? s->d_soft : softmax;
-		{ const int rd = enqueue_push_on(s, q, logits, so, argmax, 1); if (rd != EDISON_OK) return rd; }
-		if (s->filter && softmax) ED_HIP(ctx, hipMemcpyAsync(softmax, s->d_soft, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToDevice, q));
+		{ const int rd = enqueue_push_on(s, q, logits, so, argmax, 1, n_frames); if (rd != EDISON_OK) return rd; }
+		if (s->filter && softmax) ED_HIP(ctx, hipMemcpyAsync(softmax, s->d_soft, (size_t)n_frames * EDISON_NET_OUT, hipMemcpyDeviceToDevice, q));
 		s->q_last = q;
 		s->q_pending = 1;
 		s->last_push_staged = 0;
-		s->frames_seen += s->chunk;
+		s->frames_seen += n_frames;
 		return EDISON_OK;
 	}
 	/* graph replay: on the private stream (a graph is captured on one stream), ordered against the caller's with events.
@@ -647,6 +733,95 @@ static int stream_filter_out(edison_stream *s, float *filt, int32_t *likely, int
 		ED_HIP(ctx, hipEventRecord(s->ev_out, s->own));
 		ED_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_out, 0));
 	}
+	return EDISON_OK;
+}
+
+/* the state machine after the LAST push and the state after each of its inferences */
+static int stream_fsm_out(edison_stream *s, edison_fsm *fsm, int32_t *states, int host)
+{
+	if (!s) return EDISON_E_ARGUMENT;
+	edison_ctx *ctx = s->ctx;
+	if (!s->fsm) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: created without the state machine (opts.fsm)");
+	const size_t c = (size_t)s->chunk;
+	if (s->last_push_mapped)
+	{
+		if (host)
+		{
+			if (fsm) memcpy(fsm, s->m_out + s->off_fsm, sizeof(*fsm));
+			if (states) memcpy(states, s->m_out + s->off_fsm_states, c * sizeof(int32_t));
+			return EDISON_OK;
+		}
+		if (states) ED_HIP(ctx, hipMemcpyAsync(states, s->m_out + s->off_fsm_states, c * sizeof(int32_t), hipMemcpyHostToDevice, s->own));
+		ED_HIP(ctx, hipEventRecord(s->ev_out, s->own));
+		ED_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_out, 0));
+		return EDISON_OK;
+	}
+	{ const int rq = drain_q(s, s->own); if (rq != EDISON_OK) return rq; }
+	if (host && s->last_push_staged)
+	{
+		if (fsm) memcpy(fsm, s->h_out + s->off_fsm, sizeof(*fsm));
+		if (states) memcpy(states, s->h_out + s->off_fsm_states, c * sizeof(int32_t));
+		return EDISON_OK;
+	}
+	const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+	if (states) ED_HIP(ctx, hipMemcpyAsync(states, s->d_out + s->off_fsm_states, c * sizeof(int32_t), kind, s->own));
+	if (host && fsm) ED_HIP(ctx, hipMemcpyAsync(fsm, s->d_fsm, sizeof(*fsm), hipMemcpyDeviceToHost, s->own));
+	if (host) ED_HIP(ctx, hipStreamSynchronize(s->own));
+	else
+	{
+		ED_HIP(ctx, hipEventRecord(s->ev_out, s->own));
+		ED_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_out, 0));
+	}
+	return EDISON_OK;
+}
+
+extern "C" int edison_stream_fsm(edison_stream *s, edison_fsm *fsm, int32_t *states) { return stream_fsm_out(s, fsm, states, 1); }
+extern "C" int edison_stream_fsm_dev(edison_stream *s, int32_t *states) { return stream_fsm_out(s, NULL, states, 0); }
+
+/* The firmware's post-processing chain (app.c:332-371) on n network outputs in time order, without a stream: the filter kernel
+ * with the state machine behind it, one launch. Host pointers; synchronous. */
+extern "C" int edison_postproc(edison_ctx *ctx, const int8_t *softmax, int64_t n, double alpha, double true_threshold, uint32_t dt_us,
+                               float *filt_state, edison_fsm *fsm, float *filt, int32_t *likely, int32_t *spotted, int32_t *states)
+{
+	if (!ctx || !softmax || !filt_state || n < 0 || n >= ((int64_t)1 << 31) || !(alpha >= 0.0 && alpha <= 1.0)) return EDISON_E_ARGUMENT;
+	if (n == 0) return EDISON_OK;
+	const size_t c = (size_t)n;
+	size_t off = c * EDISON_NET_OUT;                                   /* softmax at 0 */
+	off = (off + 15) & ~(size_t)15; const size_t o_state = off; off += EDISON_NET_OUT * sizeof(float);
+	off = (off + 15) & ~(size_t)15; const size_t o_filt = off; off += c * EDISON_NET_OUT * sizeof(float);
+	const size_t o_likely = off; off += c * sizeof(int32_t);
+	const size_t o_spotted = off; off += c * sizeof(int32_t);
+	const size_t o_states = off; off += c * sizeof(int32_t);
+	off = (off + 15) & ~(size_t)15; const size_t o_fsm = off; off += sizeof(edison_fsm);
+	unsigned char *d = NULL;
+	ED_HIP(ctx, hipSetDevice(ctx->device));
+	ED_HIP(ctx, hipMalloc((void **)&d, off));
+	hipStream_t q = ctx->stream;
+	hipError_t e = hipMemcpyAsync(d, softmax, c * EDISON_NET_OUT, hipMemcpyHostToDevice, q);
+	if (e == hipSuccess) e = hipMemcpyAsync(d + o_state, filt_state, EDISON_NET_OUT * sizeof(float), hipMemcpyHostToDevice, q);
+	if (e == hipSuccess && fsm) e = hipMemcpyAsync(d + o_fsm, fsm, sizeof(*fsm), hipMemcpyHostToDevice, q);
+	if (e == hipSuccess)
+	{
+		ed_fsm_stage_t fs;
+		memset(&fs, 0, sizeof(fs));
+		if (fsm)
+		{
+			fs.fsm = (edison_fsm *)(d + o_fsm); fs.states = (int32_t *)(d + o_states); fs.dt_us = dt_us;
+			edison_fsm_roles(&fs.roles.wake_idx, &fs.roles.loc_mask, &fs.roles.val_mask);
+		}
+		hipLaunchKernelGGL(ed_stream_filter_kernel, dim3(1), dim3(256), 0, q, (const int8_t *)d, (int)n, alpha, 1.0 - alpha, true_threshold,
+		                   (float *)(d + o_state), (float *)(d + o_filt), (int32_t *)(d + o_likely), (int32_t *)(d + o_spotted), fs);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(filt_state, d + o_state, EDISON_NET_OUT * sizeof(float), hipMemcpyDeviceToHost, q);
+	if (e == hipSuccess && fsm) e = hipMemcpyAsync(fsm, d + o_fsm, sizeof(*fsm), hipMemcpyDeviceToHost, q);
+	if (e == hipSuccess && filt) e = hipMemcpyAsync(filt, d + o_filt, c * EDISON_NET_OUT * sizeof(float), hipMemcpyDeviceToHost, q);
+	if (e == hipSuccess && likely) e = hipMemcpyAsync(likely, d + o_likely, c * sizeof(int32_t), hipMemcpyDeviceToHost, q);
+	if (e == hipSuccess && spotted) e = hipMemcpyAsync(spotted, d + o_spotted, c * sizeof(int32_t), hipMemcpyDeviceToHost, q);
+	if (e == hipSuccess && states && fsm) e = hipMemcpyAsync(states, d + o_states, c * sizeof(int32_t), hipMemcpyDeviceToHost, q);
+	if (e == hipSuccess) e = hipStreamSynchronize(q);
+	(void)hipFree(d);
+	ED_HIP(ctx, e);
 	return EDISON_OK;
 }
 

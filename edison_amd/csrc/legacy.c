@@ -20,6 +20,7 @@
 #include <time.h>
 
 #include "../../include/edison_hip.h"
+#include "edison_fsm_core.h"
 
 /* firmware/src/ai/nnom/keywords.txt */
 static const char *const g_keywords[EDISON_NET_OUT] = {"edison", "cinema", "bedroom", "office", "livingroom",
@@ -245,40 +246,27 @@ void edison_fsm_init(edison_fsm *f)
 	f->wake_idx = f->loc_idx = f->val_idx = f->last_loc = f->last_val = -1;
 }
 
+/* the roles of the ten classes for ed_fsm_step_core (edison_fsm_core.h) */
+void edison_fsm_roles(int32_t *wake_idx, uint32_t *loc_mask, uint32_t *val_mask)
+{
+	int32_t w = -1;
+	uint32_t lm = 0, vm = 0;
+	for (uint32_t i = 0; i < EDISON_NET_OUT; i++)
+	{
+		if (strcmp(g_keywords[i], g_fsm_wakeword) == 0) w = (int32_t)i;
+		if (fsm_role(g_fsm_locations, i)) lm |= 1u << i;
+		if (fsm_role(g_fsm_values, i)) vm |= 1u << i;
+	}
+	if (wake_idx) *wake_idx = w;
+	if (loc_mask) *loc_mask = lm;
+	if (val_mask) *val_mask = vm;
+}
+
 int edison_fsm_step(edison_fsm *f, float pred_max, uint32_t pred_idx, uint32_t dt_us, double true_threshold)
 {
 	if (!f) return EDISON_E_ARGUMENT;
-	int next = f->state;
-	const int hit = (double)pred_max > true_threshold;
-	switch (f->state)
-	{
-	case EDISON_FSM_RESET: /* app.c:766-791 */
-		for (int i = 0; i < EDISON_NET_OUT; i++)
-			if (strcmp(g_keywords[i], g_fsm_wakeword) == 0) f->wake_idx = i;
-		next = EDISON_FSM_IDLE;
-		break;
-	case EDISON_FSM_IDLE: /* app.c:793-800 */
-		if (hit && (int)pred_idx == f->wake_idx) { f->hot_timeout_ms = 0; next = EDISON_FSM_HOT; }
-		break;
-	case EDISON_FSM_HOT: /* app.c:801-824 */
-		f->hot_timeout_ms += dt_us / 1000u;
-		if (hit && fsm_role(g_fsm_locations, pred_idx)) { f->loc_idx = (int)pred_idx; f->hot_timeout_ms = 0; next = EDISON_FSM_LOC; }
-		if (f->hot_timeout_ms > EDI_LOC_TIMEOUT_MS) next = EDISON_FSM_IDLE;
-		break;
-	case EDISON_FSM_LOC: /* app.c:826-848: a value found at the very call that times out is dropped */
-		f->hot_timeout_ms += dt_us / 1000u;
-		if (hit && fsm_role(g_fsm_values, pred_idx)) { f->val_idx = (int)pred_idx; next = EDISON_FSM_SET; }
-		if (f->hot_timeout_ms > EDI_LOC_TIMEOUT_MS) next = EDISON_FSM_IDLE;
-		break;
-	case EDISON_FSM_SET: /* app.c:850-872: "set location to required value", then idle */
-		f->last_loc = f->loc_idx;
-		f->last_val = f->val_idx;
-		f->commands++;
-		next = EDISON_FSM_IDLE;
-		break;
-	default:
-		return EDISON_E_ARGUMENT;
-	}
-	f->state = next;
-	return next;
+	ed_fsm_roles_t roles;
+	edison_fsm_roles(&roles.wake_idx, &roles.loc_mask, &roles.val_mask);
+	const int r = ed_fsm_step_core(f, (double)pred_max > true_threshold, pred_idx, dt_us, &roles);
+	return r < 0 ? EDISON_E_ARGUMENT : r;
 }

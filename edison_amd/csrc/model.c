@@ -16,6 +16,7 @@
 
 #include "../../include/edison_hip.h"
 #include "edison_internal.h"
+#include "cnn_mfma_cols.h"
 
 enum { T_CONV = 1, T_POOL = 2, T_DENSE = 3, T_SOFTMAX = 4 };
 
@@ -41,14 +42,21 @@ static void pack(const int8_t *w, int O, int K, int K4, int OS, int32_t *out)
 		}
 }
 
-/* Fill one MFMA A-operand fragment: lane l, byte j  <-  a(row0 + (l & 31), 32*kstep + 16*(l >> 5) + j). */
+/* Which logical row of a 32-row tile sits in physical row p of the MFMA's A operand. The D operand of v_mfma_i32_32x32x32_i8 gives
+ * lane half h the physical rows 8 g + 4 h + j (register group g = 0..3, j = 0..3): with logical row 16 h + 4 g + j there, the
+ * four packed dwords of a lane are 16 CONSECUTIVE rows (output channels) of its column -- one ds_write_b128 as it stands. (With
+ * rows in natural order a lane held 4-byte pieces 8 bytes apart and needed two v_permlane32_swap per 16 bytes to trade them with
+ * the other lane half: 38 swaps of 8 cycles per group of four utterances, in a kernel bound by vector issue.) */
+static int tile_row(int p) { return 16 * ((p >> 2) & 1) + 4 * (p >> 3) + (p & 3); }
+
+/* Fill one MFMA A-operand fragment: lane l, byte j  <-  a(row0 + tile_row(l & 31), 32*kstep + 16*(l >> 5) + j). */
 typedef int8_t (*a_elem_fn)(const int8_t *w, int row, int k);
 
 static void fill_frag(int8_t *frag, const int8_t *w, a_elem_fn a, int row0, int kstep)
 {
 	for (int l = 0; l < 64; l++)
 		for (int j = 0; j < 16; j++)
-			frag[l * 16 + j] = a(w, row0 + (l & 31), 32 * kstep + 16 * (l >> 5) + j);
+			frag[l * 16 + j] = a(w, row0 + tile_row(l & 31), 32 * kstep + 16 * (l >> 5) + j);
 }
 
 /* conv1 as Toeplitz: row = x*16 + o, k = ky*16 + xx; w1 is OHWI [16][5][5][1] */
@@ -142,10 +150,64 @@ int ed_parse_model(const void *blob, size_t blob_bytes, ed_cnn_model_t *out, ed_
 		for (int rt = 0; rt < 2; rt++)
 			for (int s = 0; s < 9; s++) fill_frag16(m->a4[rt * 9 + s], payload + r[5].v[9], a4_elem, 16 * rt, s);
 		for (int s = 0; s < 2; s++) fill_frag16(m->afc[s], payload + r[6].v[9], afc_elem, 0, s);
-		memcpy(m->b1, out->b1, sizeof(m->b1)); memcpy(m->b2, out->b2, sizeof(m->b2));
-		memcpy(m->b3, out->b3, sizeof(m->b3)); memcpy(m->b4, out->b4, sizeof(m->b4));
+		/* the accumulator seeds of the 32-row tiles in PHYSICAL row order (conv1: a lane half owns all 16 channels of one x
+		 * position, so its seeds are the 16 channels in order whatever the tile) */
+		memcpy(m->b1, out->b1, sizeof(m->b1));
+		for (int p_ = 0; p_ < 32; p_++) m->b2[p_] = out->b2[tile_row(p_)];
+		for (int p_ = 0; p_ < 64; p_++) m->b3[p_] = out->b3[32 * (p_ >> 5) + tile_row(p_ & 31)];
+		memcpy(m->b4, out->b4, sizeof(m->b4));
 		memcpy(m->bfc, out->bfc, sizeof(m->bfc));
 		m->rs1 = out->rs1; m->rs2 = out->rs2; m->rs3 = out->rs3; m->rs4 = out->rs4; m->rsfc = out->rsfc;
+		/* the column tables of a full group (edison_internal.h): byte offsets of the column's operand reads and of its outputs;
+		 * an idle lane re-reads the last live column of its tile */
+		for (int t = 0; t < 2; t++)
+		{
+			uint32_t last = 0;
+			for (int pass = 0; pass < 2; pass++) /* pass 0 finds the tile's last live column, pass 1 fills */
+				for (int c = 0; c < 32; c++)
+				{
+					const int q = ED_CNN_COLS_CONV1[t][c];
+					if (q >= 0)
+					{
+						const int u = q / 13, py = q % 13;
+						last = (uint32_t)(u * EDM_UTT + py * 16) | ((uint32_t)(u * EDM_UTT + EDM_REGA + py * 9 * 16) << 16);
+						if (pass) m->cols1[t][c] = last;
+					}
+					else if (pass) m->cols1[t][c] = (last & 0x7fffu) | ED_CNN_COL_IDLE;
+				}
+		}
+		for (int t = 0; t < 5; t++)
+		{
+			uint32_t last = 0;
+			for (int pass = 0; pass < 2; pass++)
+				for (int c = 0; c < 32; c++)
+				{
+					const int q = ED_CNN_COLS_CONV2[t][c];
+					if (q >= 0)
+					{
+						const int u = q / 35, r_ = q % 35, py = r_ / 7, x = r_ % 7;
+						last = (uint32_t)(u * EDM_UTT + EDM_REGA + ((2 * py) * 9 + x) * 16) | ((uint32_t)(u * EDM_UTT + (py * 7 + x) * 16) << 16);
+						if (pass) m->cols2[t][c] = last;
+					}
+					else if (pass) m->cols2[t][c] = (last & 0x7fffu) | ED_CNN_COL_IDLE;
+				}
+		}
+		for (int t = 0; t < 2; t++)
+		{
+			uint32_t last = 0;
+			for (int pass = 0; pass < 2; pass++)
+				for (int c = 0; c < 32; c++)
+				{
+					const int q = ED_CNN_COLS_CONV3[t][c];
+					if (q >= 0)
+					{
+						const int u = q / 15, r_ = q % 15, y = r_ / 5, x = r_ % 5;
+						last = (uint32_t)(u * EDM_UTT + (y * 7 + x) * 16) | ((uint32_t)(u * EDM_UTT + EDM_REGA + (y * 5 + x) * 16) << 16);
+						if (pass) m->cols3[t][c] = last;
+					}
+					else if (pass) m->cols3[t][c] = (last & 0x7fffu) | ED_CNN_COL_IDLE;
+				}
+		}
 	}
 	return EDISON_OK;
 }

@@ -22,21 +22,24 @@ from .context import KEYWORDS, default_context
 
 class Stream:
     def __init__(self, ctx=None, hop=FRAME_LEN, chunk_frames=1, q15=False, output_filter=False, alpha=0.9,
-                 threshold=0.5, graph=None):
+                 threshold=0.5, graph=None, fsm=False):
         self.ctx = ctx or default_context()
         self._L = _lib.lib()
         o = _lib.StreamOpts()
         self._L.edison_stream_default_opts(ctypes.byref(o))
         o.hop, o.chunk_frames = int(hop), int(chunk_frames)
         o.mfcc_variant = _lib.MFCC_C if q15 else _lib.MFCC_B
-        o.filter = 1 if output_filter else 0
+        o.filter = 1 if (output_filter or fsm) else 0
+        o.fsm = 1 if fsm else 0         # the firmware's state machine as the last GPU stage of every push (edison_stream_fsm)
         o.filter_alpha, o.true_threshold = float(alpha), float(threshold)
         if graph is not None:    # None: the library's default (direct launches unless EDISON_STREAM_GRAPH=1)
             o.launch_mode = 1 if graph else 0
         h = ctypes.c_void_p()
         self.ctx._check(self._L.edison_stream_create_ex(self.ctx._h, ctypes.byref(o), ctypes.byref(h)))
         self._h = h
-        self.hop, self.chunk, self.output_filter = int(hop), int(chunk_frames), bool(output_filter)
+        self.hop, self.chunk, self.output_filter, self.fsm = int(hop), int(chunk_frames), bool(output_filter or fsm), bool(fsm)
+        self._fsm_states = np.zeros(self.chunk, np.int32)
+        self._fsm = _lib.Fsm()
         self._bufs = None
 
     def close(self):
@@ -77,7 +80,17 @@ class Stream:
         if self.output_filter:
             self.ctx._check(self._L.edison_stream_filtered(self._h, b[9], b[10], b[11]))
             out.update(filtered=b[6].copy(), likely=b[7].copy(), spotted=b[8].copy())
+        if self.fsm:
+            self.ctx._check(self._L.edison_stream_fsm(self._h, ctypes.byref(self._fsm), self._fsm_states.ctypes.data))
+            out.update(fsm_states=self._fsm_states.copy(), fsm=self.fsm_snapshot())
         return out
+
+    def fsm_snapshot(self):
+        """The state machine as the last edison_stream_fsm call saw it: dict(state, hot_timeout_ms, last_command, commands)."""
+        f = self._fsm
+        cmd = None if f.last_loc < 0 else (KEYWORDS[f.last_loc], KEYWORDS[f.last_val])
+        return dict(state=Fsm.STATES[f.state], hot_timeout_ms=int(f.hot_timeout_ms), last_command=cmd, commands=int(f.commands),
+                    raw=(f.state, f.hot_timeout_ms, f.wake_idx, f.loc_idx, f.val_idx, f.last_loc, f.last_val, f.commands))
 
     def _make_bufs(self):
         c = self.chunk
@@ -86,12 +99,17 @@ class Stream:
         self._push = self._L.edison_stream_push
         return (lo, so, am, lo.ctypes.data, so.ctypes.data, am.ctypes.data, fl, li, sp, fl.ctypes.data, li.ctypes.data, sp.ctypes.data)
 
-    def push_t(self, samples, logits=None, softmax=None, argmax=None, filtered=None, likely=None, spotted=None):
-        """Device tensors (torch, int16 / int8 / int32 / fp32 on the context's GPU); asynchronous on the context's stream."""
-        if samples.numel() != self.chunk * self.hop:
-            raise ValueError("push needs exactly chunk_frames*hop = %d samples" % (self.chunk * self.hop))
+    def push_t(self, samples, logits=None, softmax=None, argmax=None, filtered=None, likely=None, spotted=None, n_frames=None):
+        """Device tensors (torch, int16 / int8 / int32 / fp32 on the context's GPU); asynchronous on the context's stream.
+        n_frames < chunk_frames: a ragged last push (edison_stream_push_n_dev: n_frames * hop samples, outputs [n_frames][..])."""
+        n = self.chunk if n_frames is None else int(n_frames)
+        if samples.numel() != n * self.hop:
+            raise ValueError("push needs exactly n_frames*hop = %d samples" % (n * self.hop))
         q = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-        self.ctx._check(self._L.edison_stream_push_dev(self._h, q(samples), q(logits), q(softmax), q(argmax)))
+        if n_frames is None:
+            self.ctx._check(self._L.edison_stream_push_dev(self._h, q(samples), q(logits), q(softmax), q(argmax)))
+        else:
+            self.ctx._check(self._L.edison_stream_push_n_dev(self._h, q(samples), n, q(logits), q(softmax), q(argmax)))
         if filtered is not None or likely is not None or spotted is not None:
             self.ctx._check(self._L.edison_stream_filtered_dev(self._h, q(filtered), q(likely), q(spotted)))
 

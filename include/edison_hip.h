@@ -130,15 +130,17 @@ int edison_net_batch(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *logit
 int edison_net_layers(edison_ctx *ctx, const int8_t *in, int64_t n, int8_t *acts);
 /* The loaded graph's OWN kernel. NNoM fixes shapes, buffers and per-layer kernels once, in model_compile()
  * (nnom.c:758-900); edison_net_specialize() goes one step further and compiles the general matrix-core kernel's source with
- * this graph's plan as constants (~2 s; code objects are cached on disk: $EDISON_JIT_CACHE, else
- * $XDG_CACHE_HOME/edison_amd, else $HOME/.cache/edison_amd; "off" disables the cache). From then on every entry point that
- * runs the general kernel for this load (edison_net_batch*, and edison_cnn_* / edison_kws_* / edison_stream_* for graphs
- * other than kws_conv) runs the graph's own: same arithmetic, bit-identical outputs, kws_conv graph 198 -> 236 M inputs/s.
+ * this graph's plan as constants (0.8-1.8 s with the installed hipcc as a child process -- $EDISON_HIPCC, else $ROCM_PATH/bin/hipcc,
+ * else /opt/rocm/bin/hipcc, never $PATH -- or hipRTC in this process). Code objects are cached on disk: $EDISON_JIT_CACHE, else
+ * $XDG_CACHE_HOME/edison_amd, else $HOME/.cache/edison_amd ("off" disables the cache); the directory is created 0700 and used only
+ * if it belongs to this user and nobody else can write it; an entry is keyed by graph, kernel text, compiler options and the
+ * compiler's identity. From then on every entry point that runs the general kernel for this load (edison_net_batch*, and
+ * edison_cnn_* / edison_kws_* / edison_stream_* for graphs other than kws_conv) runs the graph's own: same arithmetic,
+ * bit-identical outputs, 1.7-3 x the general kernel on the fixture graphs (profiles/r03_net_own_kernel_all_graphs.txt).
  * EDISON_E_NO_IMPL: the graph has no matrix-core plan, or neither hipcc nor libhiprtc.so is installed -- the graph stays on the general
- * kernel. edison_model_load* does this by itself for every graph that would otherwise run on the general kernel (the
- * kws_conv graph has its hand-written kernel and only looks into the cache): ~1 s at the first load of a graph on a machine,
- * a file read afterwards. EDISON_NET_SPECIALIZE in the environment, read at every load: 0 = loads never do it, cache = loads
- * only look into the cache, 1 = every load compiles, kws_conv included; a failure there never fails the load.
+ * kernel. A model load by itself does NONE of this (no compiler, no file, no cached code object): it is this call, or the
+ * caller's wish in the environment, read at every load -- EDISON_NET_SPECIALIZE=1: every load ends with this call (a failure
+ * there never fails the load), =cache: a load takes the own kernel if an earlier call left it in the cache.
  * edison_net_specialized: 0 general kernel; own kernel: 1 compiled just now by a hipcc child process (the installed ROCm's
  * compiler, tried first), 2 taken from the cache, 3 compiled just now by hipRTC in this process (EDISON_JIT_COMPILER=hipcc|hiprtc
  * picks one).
@@ -293,6 +295,11 @@ void edison_stream_destroy(edison_stream *s);
 int edison_stream_reset(edison_stream *s);
 int edison_stream_push_dev(edison_stream *s, const int16_t *samples /* device, chunk*hop */, int8_t *logits,
                            int8_t *softmax, int32_t *argmax /* device, may be NULL */);
+/* n_frames <= chunk_frames new frames (n_frames * hop samples, outputs [n_frames][..]): the ragged last push of a recording that the
+ * chunk does not divide (the firmware has no counterpart: its microphone never ends, app.c:288-371). Direct launch mode only for
+ * n_frames < chunk_frames (EDISON_E_NO_IMPL otherwise). The filtered outputs of such a push: its first n_frames entries. */
+int edison_stream_push_n_dev(edison_stream *s, const int16_t *samples /* device, n_frames*hop */, int n_frames, int8_t *logits,
+                             int8_t *softmax, int32_t *argmax /* device, may be NULL */);
 int edison_stream_push(edison_stream *s, const int16_t *samples /* host */, int8_t *logits, int8_t *softmax,
                        int32_t *argmax);
 int64_t edison_stream_frames_seen(const edison_stream *s);
@@ -314,7 +321,10 @@ typedef struct edison_stream_opts
 	                   * EDISON_STREAM_LAUNCH_GRAPH: every push replays the hipGraph captured at creation (device pushes: the
 	                   * MFCC / CNN / filter / shift nodes; host pushes: upload + those + download). Same results; on this
 	                   * platform the replay measures slower. Default from EDISON_STREAM_GRAPH=1. */
-	int reserved_;
+	int fsm;          /* 1 (needs filter = 1): the firmware's state machine (edisonFSM, app.c:727-928; edison_fsm below) as the last
+	                   * stage of every push, on the GPU: the inferences of the push walk through it in order, the time between
+	                   * two of them being the hop (dt = hop / 16 kHz, the cadence of appAudioEvent); state per inference and
+	                   * the machine itself: edison_stream_fsm*. The machine starts in RESET and survives pushes. */
 } edison_stream_opts;
 #define EDISON_STREAM_LAUNCH_DIRECT 0
 #define EDISON_STREAM_LAUNCH_GRAPH 1
@@ -324,6 +334,11 @@ int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts *o, edison
  * (predMaxIdx), spotted [chunk] int32 (predMaxIdx where predMax > threshold, else -1). Each may be NULL. */
 int edison_stream_filtered(edison_stream *s, float *filt /* host */, int32_t *likely, int32_t *spotted);
 int edison_stream_filtered_dev(edison_stream *s, float *filt /* device */, int32_t *likely, int32_t *spotted);
+/* The state machine of a stream created with fsm = 1, after the LAST push: *fsm = the machine (may be NULL), states [chunk] int32 =
+ * the state it was in after each inference of that push (may be NULL). */
+struct edison_fsm;
+int edison_stream_fsm(edison_stream *s, struct edison_fsm *fsm /* host */, int32_t *states /* host */);
+int edison_stream_fsm_dev(edison_stream *s, int32_t *states /* device */);
 
 /* ---- the firmware's home-automation state machine (edisonFSM, app.c:727-928), host side, without the LEDs -------
  * RESET -> IDLE -(wake word "edison" spotted)-> HOT -(a location spotted)-> LOC -(a value spotted)-> SET -> IDLE;
@@ -346,6 +361,14 @@ typedef struct edison_fsm
 void edison_fsm_init(edison_fsm *f);
 /* pred_max / pred_idx: arm_max_f32 of the filtered outputs; returns the new state. */
 int edison_fsm_step(edison_fsm *f, float pred_max, uint32_t pred_idx, uint32_t dt_us, double true_threshold);
+/* The whole post-processing chain of the firmware (app.c:332-371) on n network outputs in time order, as one GPU stage and without a
+ * stream: moving average -> first maximum -> threshold -> state machine. softmax [n][10] int8 (host); filt_state [10] fp32 in/out
+ * (netOutFilt, zeros at the start), fsm in/out (edison_fsm_init at the start; NULL: no state machine), dt_us = time between two
+ * inferences; outputs (host, each may be NULL): filt [n][10], likely [n], spotted [n], states [n]. */
+int edison_postproc(edison_ctx *ctx, const int8_t *softmax, int64_t n, double alpha, double true_threshold, uint32_t dt_us,
+                    float *filt_state, edison_fsm *fsm, float *filt, int32_t *likely, int32_t *spotted, int32_t *states);
+/* roles of the ten classes in the state machine: the wake word's class index (-1: none), bit masks of the locations and values */
+void edison_fsm_roles(int32_t *wake_idx, uint32_t *loc_mask, uint32_t *val_mask);
 
 /* ---- legacy call surface of the reference firmware (batch = 1, process-global context) --------------- */
 /* firmware/src/ai/ai.h:74-80. aiInitialize() creates the global context on device $EDISON_DEVICE (default 0)

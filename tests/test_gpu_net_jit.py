@@ -146,7 +146,7 @@ def test_both_compilers_give_the_same_answers(built_lib, jit_cache, monkeypatch,
     c.load_weights_h(_header("kws_small"))
     assert c.net_specialize() == state
     (entry,) = list(jit_cache.glob("*.hsaco"))
-    assert entry.name.endswith("_%s.hsaco" % compiler)
+    assert ("_%s-" % compiler) in entry.name and entry.name.endswith(".hsaco")     # ..._<compiler>-<its identity>.hsaco
     info = c.net_info()
     x = np.random.default_rng(3).integers(-128, 128, (2000, info["in_h"] * info["in_w"] * info["in_c"])).astype(np.int8)
     ref = net_ref.run(_blob("kws_small"), x)
@@ -170,15 +170,20 @@ def test_a_failing_hipcc_falls_through_to_hiprtc(built_lib, jit_cache, monkeypat
     c.close()
 
 
-def test_a_model_load_compiles_the_own_kernel_by_itself(built_lib, tmp_path, monkeypatch, oracle_mod, oracle_model):
-    """The library's default (EDISON_NET_SPECIALIZE unset): loading any graph but kws_conv ends with its own kernel (compiled at the
-    first load on a machine, from the cache afterwards); kws_conv keeps its hand-written kernel and compiles nothing; =0: never."""
+def test_a_model_load_compiles_only_when_asked(built_lib, tmp_path, monkeypatch, oracle_mod, oracle_model):
+    """The library's default (EDISON_NET_SPECIALIZE unset): a model load starts no compiler, writes no file and takes nothing from a
+    cache -- not even an entry an explicit call left there. =1: every load ends with edison_net_specialize (compiled at the first
+    load on a machine, from the cache afterwards); =cache: a load only looks into the cache; =0: as unset."""
     from edison_amd.context import Context
     from oracle import net_ref
     monkeypatch.setenv("EDISON_JIT_CACHE", str(tmp_path / "jit3"))
     monkeypatch.delenv("EDISON_NET_SPECIALIZE", raising=False)
-    c = Context(0)                                                   # the shipped kws_conv graph
+    c = Context(0, model_path=None)
+    c.load_weights_h(_header("kws_small"))
     assert c.net_specialized() == 0 and not list((tmp_path / "jit3").glob("*.hsaco"))
+    c.close()
+    monkeypatch.setenv("EDISON_NET_SPECIALIZE", "1")
+    c = Context(0, model_path=None)
     c.load_weights_h(_header("kws_small"))
     assert c.net_specialized() in (1, 3) and len(list((tmp_path / "jit3").glob("*.hsaco"))) == 1
     info = c.net_info()
@@ -191,11 +196,33 @@ def test_a_model_load_compiles_the_own_kernel_by_itself(built_lib, tmp_path, mon
     c.load_weights_h(_header("kws_small"))
     assert c.net_specialized() == 2                                  # the second load on this "machine": a file read
     c.close()
-    monkeypatch.setenv("EDISON_NET_SPECIALIZE", "0")
+    for v, want in (("cache", 2), ("0", 0), (None, 0)):
+        if v is None:
+            monkeypatch.delenv("EDISON_NET_SPECIALIZE")
+        else:
+            monkeypatch.setenv("EDISON_NET_SPECIALIZE", v)
+        c = Context(0, model_path=None)
+        c.load_weights_h(_header("kws_small"))
+        assert c.net_specialized() == want, (v, c.net_specialized())
+        c.close()
+    # the cache belongs to this user alone: a directory others can write is not used (every call compiles), and neither is an entry
+    # others can write
+    import os, stat
+    monkeypatch.setenv("EDISON_NET_SPECIALIZE", "cache")
+    entry = next((tmp_path / "jit3").glob("*.hsaco"))
+    os.chmod(entry, 0o666)
     c = Context(0, model_path=None)
     c.load_weights_h(_header("kws_small"))
     assert c.net_specialized() == 0
     c.close()
+    os.chmod(entry, 0o600)
+    os.chmod(tmp_path / "jit3", 0o777)
+    c = Context(0, model_path=None)
+    c.load_weights_h(_header("kws_small"))
+    assert c.net_specialized() == 0
+    c.close()
+    os.chmod(tmp_path / "jit3", 0o700)
+    assert stat.S_IMODE(os.stat(tmp_path / "jit3").st_mode) == 0o700
 
 
 def test_kws_and_stream_entry_points_on_another_graphs_own_kernel(built_lib, jit_cache):

@@ -299,3 +299,163 @@ def test_device_pushes_slide_through_the_history_buffer_and_wrap(ctx, hop, chunk
             continue
         assert np.array_equal(so[i * chunk:(i + 1) * chunk], want[i]["softmax"]), i
         assert np.array_equal(am[i * chunk:(i + 1) * chunk], np.asarray(want[i]["argmax"]).reshape(-1)), i
+
+
+@pytest.mark.parametrize("hop,chunk,tail", [(512, 64, 17), (1024, 9, 1), (512, 4096, 1907)])
+def test_ragged_last_push(ctx, hop, chunk, tail):
+    """A recording the chunk does not divide: whole chunks through edison_stream_push_dev (sliding history), the remaining `tail`
+    frames through edison_stream_push_n_dev, more whole chunks after it -- every window equal to the batch path on the same
+    samples (BASELINE configs[4]'s hour is 27 x 4096 + 1907 frames). A short push under the captured graph is refused."""
+    import torch
+    from edison_amd import _lib
+    from edison_amd.stream import Stream
+    rng = np.random.default_rng(hop + chunk + tail)
+    plan = [chunk, chunk, tail, chunk, tail, chunk]
+    n_frames = sum(plan)
+    audio = np.clip(rng.normal(0, 2500, n_frames * hop), -32768, 32767).astype(np.int16)
+    dev = torch.device("cuda", 0)
+    a = torch.from_numpy(audio).to(dev)
+    st = Stream(ctx, hop=hop, chunk_frames=chunk)
+    soft, am = [], []
+    at = 0
+    for n in plan:
+        so = torch.zeros((n, 10), dtype=torch.int8, device=dev)
+        ar = torch.zeros((n,), dtype=torch.int32, device=dev)
+        st.push_t(a[at * hop:(at + n) * hop], softmax=so, argmax=ar, n_frames=None if n == chunk else n)
+        soft.append(so); am.append(ar); at += n
+    torch.cuda.synchronize()
+    assert st.frames_seen == n_frames
+    soft = torch.cat(soft).cpu().numpy(); am = torch.cat(am).cpu().numpy()
+    full = np.concatenate([np.zeros(1024 - hop, np.int16), audio])
+    _, feat = ctx.mfcc(full, n_frames=n_frames, frame_step=hop, variant=_lib.MFCC_B, n_coef=13, want_feat=True)
+    ref = ctx.cnn(_windows_from_features(feat))
+    assert np.array_equal(soft, ref["softmax"]) and np.array_equal(am, ref["argmax"])
+    with pytest.raises(ValueError):
+        st.push_t(a[:chunk * hop], n_frames=max(1, chunk - 1))          # sample count must match n_frames
+    st.close()
+    if chunk > 1:
+        g = Stream(ctx, hop=hop, chunk_frames=chunk, graph=True)
+        with pytest.raises(_lib.EdisonError) as ei:
+            g.push_t(a[:(chunk - 1) * hop], n_frames=chunk - 1)
+        assert ei.value.code == _lib.E_NO_IMPL
+        g.close()
+
+
+def _host_chain(oracle_mod, soft, alpha, threshold, dt_us, state=None, fsm=None):
+    """The chain on the host, independently of the GPU stage: the oracle's output filter (oracle/postproc_ref.c), then the library's
+    HOST state machine (edison_fsm_step, legacy.c) one inference at a time."""
+    import ctypes
+    from edison_amd import _lib
+    L = _lib.lib()
+    filt, likely, spotted, st = oracle_mod.output_filter(soft, state=state, alpha=alpha, threshold=threshold)
+    if fsm is None:
+        fsm = _lib.Fsm()
+        L.edison_fsm_init(ctypes.byref(fsm))
+    states = np.zeros(len(likely), np.int32)
+    for i in range(len(likely)):
+        states[i] = L.edison_fsm_step(ctypes.byref(fsm), float(filt[i, likely[i]]), int(likely[i]), int(dt_us), float(threshold))
+    return filt, likely, spotted, st, states, fsm
+
+
+def _fsm_tuple(f):
+    return (f.state, f.hot_timeout_ms, f.wake_idx, f.loc_idx, f.val_idx, f.last_loc, f.last_val, f.commands)
+
+
+def _scenario(rng, n_segments, dt_us):
+    """int8 softmax rows in time order: random segments in which one class is confident (or nobody is), and between them scripted
+    episodes -- a whole command (wake word, location, value), a wake word followed by silence (the 5 s time-out in HOT), a wake
+    word and a location followed by silence (the time-out in LOC) -- long enough for the moving average to cross any threshold
+    used here, so that the machine is walked through every state and both time-outs."""
+    per_5s = 5_000_000 // dt_us
+    rows = []
+
+    def hold(cls, length, conf=127):
+        for _ in range(length):
+            r = rng.integers(0, 8, 10)
+            r[cls] = conf
+            rows.append(r)
+    for k in range(n_segments):
+        if k % 20 == 5:
+            hold(0, 30); hold(int(rng.choice([1, 2, 3, 4, 5])), 30); hold(int(rng.choice([6, 7])), 30); hold(9, 10)   # a command
+        elif k % 20 == 11:
+            hold(0, 30); hold(9, per_5s + 40, conf=int(rng.choice([127, 40])))                                         # time-out in HOT
+        elif k % 20 == 17:
+            hold(0, 30); hold(int(rng.choice([1, 2, 3, 4, 5])), 30); hold(8, per_5s + 40)                               # time-out in LOC
+        else:
+            cls = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7])) if rng.random() < 0.45 else int(rng.choice([8, 9]))
+            hold(cls, int(rng.choice([1, 2, 5, 20, per_5s // 2, per_5s + 5])), conf=int(rng.choice([127, 100, 60, 20])))
+    return np.array(rows, dtype=np.int8)
+
+
+@pytest.mark.parametrize("seed,threshold,dt_us", [(1, 0.5, 64000), (2, 30.0, 64000), (3, 50.0, 32000), (4, 80.0, 1_000_000), (5, 30.0, 999)])
+def test_postproc_chain_with_the_state_machine_on_the_gpu(ctx, oracle_mod, seed, threshold, dt_us):
+    """moving average -> first maximum -> threshold -> edisonFSM as ONE GPU stage (edison_postproc = the stream's filter
+    kernel with the machine behind it), against the host chain over scripted scenario streams: filtered floats bit for bit, the
+    state after EVERY inference, the machine itself at the end (time-out counter, pending location / value, executed commands) --
+    incl. both 5 s time-outs, the value that arrives at the very step that times out (dropped), dt below one millisecond (the
+    firmware's `hotTimeout += dt/1000` truncates to 0: the machine never times out), and the state carried across calls. The
+    reference holds no vectors for this chain: parity unpinned, the checker is the independent host restatement."""
+    from edison_amd.context import postproc
+    rng = np.random.default_rng(seed)
+    soft = _scenario(rng, 80, dt_us if dt_us >= 1000 else 64000)
+    alpha = 0.9
+    filt, likely, spotted, st, states, fsm = _host_chain(oracle_mod, soft, alpha, threshold, dt_us)
+    got = postproc(ctx, soft, alpha=alpha, threshold=threshold, dt_us=dt_us)
+    assert np.array_equal(got["filtered"].view(np.uint32), filt.view(np.uint32))
+    assert np.array_equal(got["likely"], likely) and np.array_equal(got["spotted"], spotted)
+    assert np.array_equal(got["fsm_states"], states), np.flatnonzero(got["fsm_states"] != states)[:5]
+    assert _fsm_tuple(got["fsm"]) == _fsm_tuple(fsm)
+    if 1000 <= dt_us <= 64000:   # the scenario really gets everywhere: commands executed, both time-outs taken
+        timeouts = int(((states[1:] == 1) & (states[:-1] >= 2) & (states[:-1] <= 3)).sum())
+        assert fsm.commands >= 3 and set(states.tolist()) >= {1, 2, 3, 4} and timeouts >= 4, (fsm.commands, set(states.tolist()), timeouts)
+    # in three pieces, the filter state and the machine carried along: the same answers
+    cuts = [0, len(soft) // 3, len(soft) // 3 + 1, len(soft)]
+    state, m, parts = None, None, []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        g = postproc(ctx, soft[a:b], alpha=alpha, threshold=threshold, dt_us=dt_us, state=state, fsm=m)
+        state, m = g["state"], g["fsm"]
+        parts.append(g["fsm_states"])
+    assert np.array_equal(np.concatenate(parts), states) and _fsm_tuple(m) == _fsm_tuple(fsm)
+
+
+@pytest.mark.parametrize("hop,chunk", [(512, 1), (512, 6), (1024, 64)])
+def test_stream_with_the_state_machine_as_its_last_stage(ctx, oracle_mod, hop, chunk):
+    """A stream created with fsm = 1: host pushes (chunk 1: the one-launch kernel steps the machine itself; larger chunks: the filter
+    kernel's last lane walks the push) and device pushes give, inference by inference, the states of the host chain run on the
+    stream's own softmax outputs; the machine survives pushes and edison_stream_reset puts it back into RESET."""
+    import torch
+    from edison_amd.stream import Stream
+    rng = np.random.default_rng(17 * hop + chunk)
+    n_push = 40 if chunk == 1 else 6
+    audio = np.clip(rng.normal(0, 2500, n_push * chunk * hop), -32768, 32767).astype(np.int16)
+    dt_us = hop * 1_000_000 // 16000
+    thr = 0.5
+    st = Stream(ctx, hop=hop, chunk_frames=chunk, fsm=True, threshold=thr)
+    outs = [st.push(audio[i * chunk * hop:(i + 1) * chunk * hop]) for i in range(n_push)]
+    soft = np.concatenate([o["softmax"] for o in outs])
+    got = np.concatenate([o["fsm_states"] for o in outs])
+    filt, likely, spotted, _, states, fsm = _host_chain(oracle_mod, soft, 0.9, thr, dt_us)
+    assert np.array_equal(np.concatenate([o["filtered"] for o in outs]).view(np.uint32), filt.view(np.uint32))
+    assert np.array_equal(got, states)
+    assert outs[-1]["fsm"]["raw"] == _fsm_tuple(fsm)
+    assert got[0] == 1                                   # RESET -> IDLE at the first inference (app.c:766-791)
+    # device pushes on the same stream object continue the same machine
+    dev = torch.device("cuda", 0)
+    more = np.clip(rng.normal(0, 2500, 2 * chunk * hop), -32768, 32767).astype(np.int16)
+    a = torch.from_numpy(more).to(dev)
+    so = torch.zeros((chunk, 10), dtype=torch.int8, device=dev)
+    sd = torch.zeros((chunk,), dtype=torch.int32, device=dev)
+    dstates, dsoft = [], []
+    for i in range(2):
+        st.push_t(a[i * chunk * hop:(i + 1) * chunk * hop], softmax=so)
+        ctx._check(st._L.edison_stream_fsm_dev(st._h, sd.data_ptr()))
+        torch.cuda.synchronize()
+        dstates.append(sd.cpu().numpy().copy()); dsoft.append(so.cpu().numpy().copy())
+    _, _, _, _, states2, _ = _host_chain(oracle_mod, np.concatenate([soft] + dsoft), 0.9, thr, dt_us)
+    assert np.array_equal(np.concatenate(dstates), states2[len(soft):])
+    st.reset()
+    again = st.push(audio[:chunk * hop])
+    assert np.array_equal(again["fsm_states"], outs[0]["fsm_states"])
+    st.close()
+    with pytest.raises(Exception):
+        Stream(ctx, hop=hop, chunk_frames=chunk, fsm=True, output_filter=False, alpha=2.0)

@@ -186,6 +186,17 @@ def test_fsm_scenarios(built_lib):
     assert [f.step(*e) for e in late_value][-1] == "IDLE" and f.commands == 0   # the value came with the timeout: dropped
 
 
+def test_fsm_roles_of_the_ten_classes(built_lib):
+    """What the GPU stage of the state machine gets instead of strings: the wake word's class and the location / value masks, resolved
+    from the firmware's tables (EDI_WAKEWORD app.c:50, ediLocations / ediValues app.c:135-147) against keywords.txt."""
+    from edison_amd.context import KEYWORDS
+    w, lm, vm = ctypes.c_int32(), ctypes.c_uint32(), ctypes.c_uint32()
+    built_lib.edison_fsm_roles(ctypes.byref(w), ctypes.byref(lm), ctypes.byref(vm))
+    assert KEYWORDS[w.value] == "edison"
+    assert {KEYWORDS[i] for i in range(10) if lm.value >> i & 1} == {"cinema", "bedroom", "office", "livingroom", "kitchen"}
+    assert {KEYWORDS[i] for i in range(10) if vm.value >> i & 1} == {"on", "off"}
+
+
 def test_mel_constants_generator_reproduces_the_firmware_header(built_lib, q15_golden):
     """calcCConstants (mirror of mfcc_on_mcu.py:68-145) must emit firmware/src/audio/mel_constants.h byte for byte:
     same length and SHA-256 as the reference's committed file (fingerprint taken by gen_fixtures_q15.py)."""
