@@ -32,7 +32,7 @@
  * 52 / 140 / 60 / 12 / 4 columns in 2 / 5 / 2 / 1 / 1 tiles of 32 (167 MFMAs per 4 utterances against 133 before: the
  * price of the independence). Logits are parked in LDS and the serial softmax / argmax runs once per 8 groups on 32
  * lanes. Groups are handed out through a counter in LDS (ds_add_rtn_u32) as in the MFCC kernel.
- * LDS: 61 KB of weight fragments + 8 waves x (4 x 2992 B activations + 512 B parked logits) = 157 KB.
+ * LDS: 60 KB of weight fragments, seeds and column tables + 8 waves x (4 x 2992 B activations + 512 B parked logits + 160 B) = 158.5 KB.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,7 +44,7 @@
 
 /* ---- lab knobs: only a lab build (ED_LAB, tools/lab/mkvariant.py) may set them; the product build has none, and
  * tests/test_host_cpu.py checks the values below against what edison_amd/build.py compiles */
-#if !defined(ED_LAB) && (defined(EDM_PRIO) || defined(EDM_SKIP))
+#if !defined(ED_LAB) && (defined(EDM_PRIO) || defined(EDM_SKIP) || defined(EDM_W1V) || defined(EDM_W2V) || defined(EDM_W3V))
 #error "EDM_* lab knob defined without ED_LAB (tools/lab/mkvariant.py builds lab variants)"
 #endif
 #if defined(ED_LAB)
@@ -56,13 +56,24 @@ extern "C" { extern const int ed_lab_build_cnn_mfma; const int ed_lab_build_cnn_
 #ifndef EDM_SKIP
 #define EDM_SKIP 0
 #endif
+/* vector instructions the scheduler is asked to put behind each MFMA of the next tile while a tile is requantised (EDM_WEAVE), for
+ * the shift-8 epilogues of conv1 / conv2 and for conv3 */
+#ifndef EDM_W1V
+#define EDM_W1V 5
+#endif
+#ifndef EDM_W2V
+#define EDM_W2V 4
+#endif
+#ifndef EDM_W3V
+#define EDM_W3V 6
+#endif
 #define EDM_G 4       /* utterances per wavefront group */
 #define EDM_WAVES 8
 #define EDM_THREADS (64 * EDM_WAVES)
 /* (the LDS layout of an utterance -- EDM_REGA, EDM_REGB, EDM_IN_ODD, EDM_P2_PLANE, EDM_C3_PLANE, EDM_UTT -- is in edison_internal.h:
  * model.c builds the column tables from it) */
 #define EDM_PARK 8    /* groups whose logits are parked before one softmax pass (8 x 4 = 32 lanes) */
-#define EDM_WAVE_LDS (EDM_G * EDM_UTT + EDM_PARK * EDM_G * 16 + 64)
+#define EDM_WAVE_LDS (EDM_G * EDM_UTT + EDM_PARK * EDM_G * 16 + 32 + 128) /* + park_group[8] + the idle lanes' 8 dummy slots */
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -225,7 +236,9 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 	unsigned char *acts = smem + sizeof(ed_cnn_mfma_model_t) + wave * EDM_WAVE_LDS; /* wave-private */
 	unsigned char *park = acts + EDM_G * EDM_UTT;                                     /* [EDM_PARK][EDM_G][16] logits */
 	int *park_group = reinterpret_cast<int *>(park + EDM_PARK * EDM_G * 16);          /* [EDM_PARK] group index      */
-	unsigned char *dummy = park + EDM_PARK * EDM_G * 16 + 32 + 16 * (lane >> 5);      /* where idle columns store: no branch */
+	/* where idle columns store (no branch): a ds_write_b128 is served in groups of 8 consecutive lanes, and idle lanes that all wrote ONE
+	 * slot were served one after the other -- every lane of a group has a slot of its own */
+	unsigned char *dummy = park + EDM_PARK * EDM_G * 16 + 32 + 16 * (lane & 7);
 	unsigned *queue = reinterpret_cast<unsigned *>(smem + sizeof(ed_cnn_mfma_model_t) + EDM_WAVES * EDM_WAVE_LDS);
 
 	/* this workgroup's contiguous slice of the utterance groups; its waves draw from it */
@@ -364,7 +377,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 					/* the whole 16-byte record of x = 2 rt + h, as it stands (row order of the A fragments: model.c tile_row) */
 					const uint4 rec = make_uint4(d[0], d[1], d[2], d[3]);
 					*reinterpret_cast<uint4 *>((2 * rt + h < 9 && live) ? p1 + (2 * rt + h) * 16 : dummy) = rec;
-					if (rt + 1 < 5) { if (F8) { EDM_WEAVE(6, 7) } else { EDM_WEAVE(6, 13) } }
+					if (rt + 1 < 5) { if (F8) { EDM_WEAVE(6, EDM_W1V) } else { EDM_WEAVE(6, 13) } }
 					__builtin_amdgcn_sched_barrier(0);
 				}
 			}
@@ -449,7 +462,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 					EDM_FENCE();
 					if (t + 2 < 5) fetch(t + 2, t & 1, (t + 2) % 3, std::true_type()); /* into the fragment registers tile t's MFMAs have consumed */
 					requant(t & 1, t % 3, std::integral_constant<bool, F8>());
-					if (t + 1 < 5) { if (F8) { EDM_WEAVE(10, 4) } else { EDM_WEAVE(10, 7) } }
+					if (t + 1 < 5) { if (F8) { EDM_WEAVE(10, EDM_W2V) } else { EDM_WEAVE(10, 7) } }
 					__builtin_amdgcn_sched_barrier(0);
 				}
 			}
@@ -525,7 +538,7 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 				issue(1, 1);
 				EDM_FENCE();
 				requant3(0);
-				EDM_WEAVE(18, 6)
+				EDM_WEAVE(18, EDM_W3V)
 				__builtin_amdgcn_sched_barrier(0);
 				requant3(1);
 			}

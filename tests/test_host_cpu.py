@@ -630,3 +630,48 @@ def test_product_library_is_not_a_lab_build_and_build_py_refuses_lab_flags(monke
     i = jit.index('getenv("EDISON_JIT_DEFINE")')
     assert "#ifdef ED_LAB" in jit[i - 200:i], "EDISON_JIT_DEFINE must only exist in a lab build of edison_net_jit.hip"
     assert B.JIT_TEXTS[0][1].endswith("cnn_net_mfma_kernels.hip")
+
+
+def test_cnn_column_tables_cover_every_column_and_meet_no_bank_conflict(built_lib):
+    """csrc/cnn_mfma_cols.h (the order in which the lanes of a FULL group take the columns of conv1 / conv2 / conv3) and what model.c
+    makes of it: every live column exactly once, the packed offsets are the columns' LDS addresses, idle lanes re-read a live
+    column of their tile -- and, under the LDS model that the counters confirmed for the natural order (tools/dev/cnn_lds_model.py),
+    the operand reads and epilogue stores of a group lose at most 40 cycles to bank conflicts (natural order: 457)."""
+    import importlib.util
+    from edison_amd import _lib
+    spec = importlib.util.spec_from_file_location("cnn_lds_model", os.path.join(ROOT, "tools", "dev", "cnn_lds_model.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    tabs = M.read_header()
+    total_nat = total = 0
+    for L in (M.Conv1, M.Conv2, M.Conv3):
+        cols = tabs[L.name]
+        assert len(cols) == L.tiles and sorted(q for r in cols for q in r if q is not None) == list(range(L.n))
+        total_nat += M.layer_cost(L, M.natural(L))
+        total += M.layer_cost(L, cols)
+    assert total_nat == 457 and total <= 40, (total_nat, total)
+    # the tables as the kernel gets them (ed_parse_model -> ed_cnn_mfma_model_t.cols1 / cols2 / cols3)
+    blob = open(_lib.DEFAULT_MODEL, "rb").read()
+    plain, mfma = (ctypes.c_char * (1 << 17))(), (ctypes.c_char * (1 << 17))()
+    err = ctypes.create_string_buffer(256)
+    built_lib.ed_parse_model.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    assert built_lib.ed_parse_model(blob, len(blob), plain, mfma, err, 256) == _lib.OK, err.value
+    off = (15 + 5 + 18 + 18 + 2) * 1024 + (16 + 32 + 64 + 32 + 16) * 4 + 8 * 4
+    u32 = np.frombuffer(mfma, dtype=np.uint32, count=(2 + 5 + 2) * 32, offset=off)
+    UTT, REGA = 2992, 1120
+    want = {
+        "conv1": lambda q: ((q // 13) * UTT + (q % 13) * 16, (q // 13) * UTT + REGA + (q % 13) * 9 * 16),
+        "conv2": lambda q: ((q // 35) * UTT + REGA + ((2 * ((q % 35) // 7)) * 9 + (q % 35) % 7) * 16, (q // 35) * UTT + ((q % 35) // 7 * 7 + (q % 35) % 7) * 16),
+        "conv3": lambda q: ((q // 15) * UTT + (((q % 15) // 5) * 7 + (q % 15) % 5) * 16, (q // 15) * UTT + REGA + (((q % 15) // 5) * 5 + (q % 15) % 5) * 16),
+    }
+    at = 0
+    for name, tiles in (("conv1", 2), ("conv2", 5), ("conv3", 2)):
+        for t in range(tiles):
+            live_reads = {want[name](q)[0] for q in tabs[name][t] if q is not None}
+            for c in range(32):
+                e, q = int(u32[at]), tabs[name][t][c]
+                at += 1
+                if q is None:
+                    assert e >> 31 and (e & 0x7fff) in live_reads, (name, t, c, hex(e))
+                else:
+                    assert (e & 0x7fff, (e >> 16) & 0x7fff, e >> 31) == want[name](q) + (0,), (name, t, c, q, hex(e))
