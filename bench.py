@@ -619,6 +619,29 @@ def main():
                        what="the same workload after settle_ms of untimed repetition of the step in front of the W warm-up steps (clocks and "
                             "power settled); a side figure, the headline is the W + K run above")
     checksum = float(out.double().sum().item())
+    # ---- the same batches, several per launch (edison_mfcc_rows_dev: batches that sit at a constant stride are the rows of ONE launch).
+    # The 65 536-frame launch above pays per launch what a longer one amortises -- 2.4 us until the median wave computes, then
+    # waves leaving over 4-5 us at the end: 15 % of the launch window idle, of which the power manager gives ~6 % back as clock
+    # (profiles/r04_mfcc_launch_structure_notes.txt) -- so a caller that streams config-2-sized batches gets the loop's own rate
+    # by handing over a few at a time. A side figure: the headline stays one batch per launch.
+    rows_launch = None
+    try:
+        n_b = 8
+        big = torch.empty((n_b, nf, 1024), dtype=torch.int16, device=dev)
+        for b in range(n_b):
+            big[b] = bufs[b % len(bufs)]
+        out_b = torch.empty((n_b * nf, 13), dtype=torch.float32, device=dev)
+
+        def rows_step(i):
+            ctx.mfcc_rows_t(big, n_b, nf * 1024, nf, 1024, _lib.MFCC_B, 13, out=out_b)
+        r_ms, rev_ms = timed_region(rows_step, max(20, args.steps // n_b), max(3, min(args.warmup, 2000) // n_b), world, args.settle_ms)
+        rows_launch = dict(batches_per_launch=n_b, value=round(world * n_b * nf / (r_ms * 1e-3), 1), unit="frames/s", ms_per_launch=round(r_ms, 4),
+                           us_per_65536_frames=round(rev_ms * 1e3 / n_b * 65536 / nf, 2),
+                           roofline_frac=round(MFCC_BYTES_PER_FRAME * n_b * nf / (rev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           what="%d batches of %d frames, %d samples apart, as the rows of one edison_mfcc_rows_dev launch (settled); the kernel is the grouped instantiation %s" % (n_b, nf, nf * 1024, MFCC_KERNEL_KWS))
+        del big, out_b
+    except Exception as e:  # a side figure must never cost the headline numbers
+        rows_launch = dict(error=repr(e))
 
     # ------------------------------------------------------------------ variant A (log-mel, mfcc_utils.mfcc), same batch
     def mfcc_a_step(i):
@@ -802,6 +825,8 @@ def main():
                     roofline=roofline, device=info["name"], checksum=checksum)
         if settled is not None:
             line["settled"] = settled
+        if rows_launch is not None:
+            line["rows_launch"] = rows_launch
         line["mfcc_variant_a"] = variant_a
         if variant_d is not None:
             line["mfcc_variant_d"] = variant_d

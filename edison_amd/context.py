@@ -256,6 +256,13 @@ class Context:
         self._check(self._L.edison_mfcc_batch_dev(self._h, _t_ptr(audio), int(n_frames), int(frame_step), v, int(n_coef),
                                                   _t_ptr(out), _t_ptr(feat), float(feat_scale)))
 
+    def mfcc_rows_t(self, audio, n_rows, row_stride, frames_per_row, frame_step=FRAME_LEN, variant=MFCC_B, n_coef=NUM_MFCC, out=None,
+                    feat=None, feat_scale=1.0):
+        """edison_mfcc_rows_dev: `n_rows` rows (utterances of batch_mfcc, or whole BATCHES that sit row_stride samples apart) of
+        frames_per_row frames each, in ONE launch; out: fp32 [n_rows * frames_per_row, n_coef]."""
+        self._check(self._L.edison_mfcc_rows_dev(self._h, _t_ptr(audio), int(n_rows), int(row_stride), int(frames_per_row), int(frame_step),
+                                                 variant, int(n_coef), _t_ptr(out), _t_ptr(feat), float(feat_scale)))
+
     def cnn_t(self, feat, n_utt, logits=None, softmax=None, argmax=None):
         self._check(self._L.edison_cnn_batch_dev(self._h, _t_ptr(feat), int(n_utt), _t_ptr(logits), _t_ptr(softmax),
                                                  _t_ptr(argmax)))

@@ -315,70 +315,100 @@ __device__ __forceinline__ void edm_main(const int8_t *__restrict__ feat, int64_
 			v4i A1[15];
 #pragma unroll
 			for (int i = 0; i < 15; i++) A1[i] = edm_ld16(afrag + a1_off + i * 1024);
-#pragma unroll 1
-			for (int t = 0; t < 2; t++)
-			{
-				if (t * 32 >= nb_cur * 13) break; /* no live column in this tile */
-				/* which column (utt, py) this lane computes: for a full group the order that keeps the LDS accesses of a lane group
-				 * on different banks (M.cols1, edison_internal.h), for a partial one the natural order (only the tiles that hold a
-				 * live utterance run) */
+			/* One column tile: where its lanes read and store, its six B fragments. For a full group the column a lane computes comes
+			 * from the order that keeps the LDS accesses of a lane group on different banks (M.cols1, edison_internal.h), for a partial
+			 * one it is the natural order (only the tiles that hold a live utterance run). */
+			struct tile1_t { v4i be[3], bo[3]; unsigned char *p1; bool live; };
+			auto load_tile = [&](int t, tile1_t &c) {
 				int rd_off, st_off;
-				bool live;
 				if (full)
 				{
 					const uint32_t e = M.cols1[t][col];
-					rd_off = (int)(e & 0x7fffu); st_off = (int)((e >> 16) & 0x7fffu); live = !(e & ED_CNN_COL_IDLE);
+					rd_off = (int)(e & 0x7fffu); st_off = (int)((e >> 16) & 0x7fffu); c.live = !(e & ED_CNN_COL_IDLE);
 				}
 				else
 				{
 					const int q = t * 32 + col;
-					live = q < EDM_G * 13;
-					const int qq = live ? q : EDM_G * 13 - 1; /* idle columns recompute the last one and store nothing */
+					c.live = q < EDM_G * 13;
+					const int qq = c.live ? q : EDM_G * 13 - 1; /* idle columns recompute the last one and store nothing */
 					const int u = qq / 13, py = qq - u * 13;
 					rd_off = u * EDM_UTT + py * 16; st_off = u * EDM_UTT + EDM_REGA + (py * 9) * 16;
 				}
 				const unsigned char *inb = acts + rd_off; /* row 2 py of the even plane; row 2 py + 1 of the odd plane is EDM_IN_ODD further */
-				v4i be[3], bo[3];
 #pragma unroll
 				for (int s = 0; s < 3; s++)
 				{
-					const int c = (2 * s + h) < 4 ? (2 * s + h) : 4; /* k-chunk = input row 2 py + c; chunk 5 meets zero weights */
+					const int k = (2 * s + h) < 4 ? (2 * s + h) : 4; /* k-chunk = input row 2 py + k; chunk 5 meets zero weights */
 					/* row r lies in plane r & 1 at slot r >> 1 */
-					be[s] = edm_ld16(inb + (c & 1) * EDM_IN_ODD + (c >> 1) * 16);
-					bo[s] = edm_ld16(inb + ((c + 1) & 1) * EDM_IN_ODD + ((c + 1) >> 1) * 16);
+					c.be[s] = edm_ld16(inb + (k & 1) * EDM_IN_ODD + (k >> 1) * 16);
+					c.bo[s] = edm_ld16(inb + ((k + 1) & 1) * EDM_IN_ODD + ((k + 1) >> 1) * 16);
 				}
-				unsigned char *p1 = acts + st_off;
-				/* software pipeline: the MFMAs of row tile rt + 1 are issued BEFORE the requantisation of row tile rt, so
-				 * that VALU work runs while the matrix pipe is busy (an MFMA blocks vector issue for 8 of its 32 cycles) */
-				v16i ae[2], ao[2];
-				auto issue = [&](int rt, int slot) {
-					ae[slot] = seed1; ao[slot] = seed1;
+				c.p1 = acts + st_off;
+			};
+			/* software pipeline: the MFMAs of the next row tile are issued BEFORE the requantisation of this one, so that VALU work
+			 * runs while the matrix pipe is busy (an MFMA blocks vector issue for 8 of its 32 cycles) */
+			v16i ae[2], ao[2];
+			auto issue = [&](const tile1_t &c, int rt, int slot) {
+				ae[slot] = seed1; ao[slot] = seed1;
 #pragma unroll
-					for (int s = 0; s < 3; s++)
-					{
-						ae[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1[rt * 3 + s], be[s], ae[slot], 0, 0, 0);
-						ao[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1[rt * 3 + s], bo[s], ao[slot], 0, 0, 0);
-					}
-				};
-				issue(0, 0);
-#pragma unroll
-				for (int rt = 0; rt < 5; rt++)
+				for (int s = 0; s < 3; s++)
 				{
-					if (rt + 1 < 5) issue(rt + 1, (rt + 1) & 1);
-					EDM_FENCE();
-					const v16i &e = ae[rt & 1], &o = ao[rt & 1];
-					uint32_t d[4];
+					ae[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1[rt * 3 + s], c.be[s], ae[slot], 0, 0, 0);
+					ao[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1[rt * 3 + s], c.bo[s], ao[slot], 0, 0, 0);
+				}
+			};
+			auto requant1 = [&](const tile1_t &c, int rt, int slot) {
+				const v16i &e = ae[slot], &o = ao[slot];
+				uint32_t d[4];
 #pragma unroll
-					for (int g = 0; g < 4; g++)
-						d[g] = F8 ? edm_pack_relu8(edm_max3z(e[4 * g], o[4 * g]), edm_max3z(e[4 * g + 1], o[4 * g + 1]),
-						                           edm_max3z(e[4 * g + 2], o[4 * g + 2]), edm_max3z(e[4 * g + 3], o[4 * g + 3]))
-						          : edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
-						                          edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs1);
-					/* the whole 16-byte record of x = 2 rt + h, as it stands (row order of the A fragments: model.c tile_row) */
-					const uint4 rec = make_uint4(d[0], d[1], d[2], d[3]);
-					*reinterpret_cast<uint4 *>((2 * rt + h < 9 && live) ? p1 + (2 * rt + h) * 16 : dummy) = rec;
-					if (rt + 1 < 5) { if (F8) { EDM_WEAVE(6, EDM_W1V) } else { EDM_WEAVE(6, 13) } }
+				for (int g = 0; g < 4; g++)
+					d[g] = F8 ? edm_pack_relu8(edm_max3z(e[4 * g], o[4 * g]), edm_max3z(e[4 * g + 1], o[4 * g + 1]),
+					                           edm_max3z(e[4 * g + 2], o[4 * g + 2]), edm_max3z(e[4 * g + 3], o[4 * g + 3]))
+					          : edm_pack_relu(edm_max(e[4 * g], o[4 * g]), edm_max(e[4 * g + 1], o[4 * g + 1]),
+					                          edm_max(e[4 * g + 2], o[4 * g + 2]), edm_max(e[4 * g + 3], o[4 * g + 3]), rs1);
+				/* the whole 16-byte record of x = 2 rt + h, as it stands (row order of the A fragments: model.c tile_row) */
+				const uint4 rec = make_uint4(d[0], d[1], d[2], d[3]);
+				*reinterpret_cast<uint4 *>((2 * rt + h < 9 && c.live) ? c.p1 + (2 * rt + h) * 16 : dummy) = rec;
+			};
+			if (full)
+			{
+				/* both column tiles as ONE pipeline of ten (column tile, row tile) steps: the second tile's B fragments are requested
+				 * a step ahead, and its first MFMAs go out before the first tile's last requantisation -- between
+				 * the tiles the matrix pipe used to drain (a requantisation with nothing behind it) and refill (six MFMAs with
+				 * nothing to do beside them, behind six LDS reads) */
+				tile1_t c0, c1;
+				load_tile(0, c0);
+				issue(c0, 0, 0);
+#pragma unroll
+				for (int k = 0; k < 10; k++)
+				{
+					const int rt = k % 5;
+					if (k + 1 < 10) { if (k + 1 < 5) issue(c0, (k + 1) % 5, (k + 1) & 1); else issue(c1, (k + 1) % 5, (k + 1) & 1); }
+					if (k == 3) load_tile(1, c1); /* behind the first tile's last MFMAs (its fragments are free), a whole step ahead of its own first */
+					EDM_FENCE();
+					if (k < 5) requant1(c0, rt, k & 1); else requant1(c1, rt, k & 1);
+					if (k + 1 < 10) { if (F8) { EDM_WEAVE(6, EDM_W1V) } else { EDM_WEAVE(6, 13) } }
 					__builtin_amdgcn_sched_barrier(0);
+				}
+			}
+			else
+			{
+#pragma unroll 1
+				for (int t = 0; t < 2; t++)
+				{
+					if (t * 32 >= nb_cur * 13) break; /* no live column in this tile */
+					tile1_t c;
+					load_tile(t, c);
+					issue(c, 0, 0);
+#pragma unroll
+					for (int rt = 0; rt < 5; rt++)
+					{
+						if (rt + 1 < 5) issue(c, rt + 1, (rt + 1) & 1);
+						EDM_FENCE();
+						requant1(c, rt, rt & 1);
+						if (rt + 1 < 5) { EDM_WEAVE(6, 13) }
+						__builtin_amdgcn_sched_barrier(0);
+					}
 				}
 			}
 		}

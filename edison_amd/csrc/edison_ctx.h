@@ -68,7 +68,7 @@ struct edison_ctx
 	ed_mm_plan_t *h_mm_plan; /* host copy of the matrix-core plan: what the specialisation is generated from */
 	void *spec_mod, *spec_fn; /* hipModule_t / hipFunction_t */
 	int spec_epoch;           /* the model load (model_epoch) it was compiled for */
-	int spec_state;           /* 1: compiled by this process, 2: loaded from the on-disk cache */
+	int spec_state;           /* 1: compiled just now by the hipcc child process, 2: loaded from the on-disk cache, 3: compiled just now by hipRTC in this process */
 	/* growable device scratch for the host-pointer entry points and the fused KWS path */
 	void *scratch;
 	size_t scratch_bytes;
