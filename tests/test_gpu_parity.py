@@ -402,3 +402,37 @@ def test_batch_mfcc_rows_in_one_launch(ctx, oracle_mod):
     out = mfu.batch_mfcc(data[:3, :2048], 16000, 2048, 1024, 1024, 0, 1024, 32, 80, 7600)
     assert out.shape == (3, 2, 32) and out.dtype == np.float64
     assert np.array_equal(out[1].astype(np.float32), ctx.mfcc(data[1, :2048], n_frames=2, variant=_lib.MFCC_A, n_coef=32))
+
+
+@pytest.mark.parametrize("shifts", [(8, 8, 7, 9), (7, 9, 8, 8), (9, 8, 6, 10), (8, 7, 7, 9), (10, 10, 9, 7)])
+def test_retrained_kws_conv_with_other_output_shifts_on_the_matrix_core_kernel(shifts):
+    """The hand-written CNN kernel serves any retrained model of the kws_conv shape. Round 4 gave conv1 / conv2 a shorter
+    requantisation for an output shift of exactly 8 (the shipped model) and kept the general form for every other shift: both
+    instantiations, every layer's shift changed in turn, ragged batches (partial groups of 1-3 utterances take the natural column
+    order, full groups the conflict-free one) -- logits, softmax and argmax bit for bit against the numpy oracle of the same blob
+    (oracle/net_ref.py, itself pinned on the reference NNoM for every fixture graph). Same weights, other shifts: what a retraining
+    that re-quantises the activations differently would ship."""
+    import struct
+    from edison_amd import _lib
+    from edison_amd.context import Context
+    from oracle import net_ref
+    blob = bytearray(open(_lib.DEFAULT_MODEL, "rb").read())
+    (h, w, c), recs, _ = net_ref.parse_blob(bytes(blob))
+    conv = [i for i, r in enumerate(recs) if r[0] == net_ref.T_CONV]
+    assert len(conv) == 4
+    for i, rs in zip(conv, shifts):
+        struct.pack_into("<i", blob, 40 + 48 * i + 4 * 7, rs)            # out_rshift of the layer
+    blob = bytes(blob)
+    c2 = Context(0, model_path=None)
+    c2.load_model_bytes(blob)
+    assert c2.net_info()["accelerated"] == 1                           # the hand-written kernel, not the general one
+    rng = np.random.default_rng(sum(shifts))
+    for n in (1, 2, 3, 4, 5, 7, 33, 4099):
+        x = rng.integers(-128, 128, (n, 403)).astype(np.int8)
+        x[0] = 127
+        x[-1] = -128
+        got = c2.cnn(x)
+        ref = net_ref.run(blob, x)
+        assert np.array_equal(got["logits"], ref["logits"]), (shifts, n)
+        assert np.array_equal(got["softmax"], ref["softmax"]) and np.array_equal(got["argmax"], ref["argmax"]), (shifts, n)
+    c2.close()
