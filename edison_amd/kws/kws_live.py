@@ -34,27 +34,32 @@ def run(path, q15=False, ctx=None, out=None, alpha=0.9, threshold=0.5):
     hop = cfg.frame_length
     n = -(-data.shape[0] // hop)
     data = np.pad(data, (0, n * hop - data.shape[0]))
-    st = Stream(ctx, hop=hop, chunk_frames=n, q15=q15, output_filter=True, alpha=alpha, threshold=threshold)
+    # the firmware's loop body behind the network (app.c:341-371) is part of the push: moving average, maximum, threshold and
+    # edisonFSM run as the last GPU stages (Stream(fsm=True)); what comes back is the state after every inference
+    st = Stream(ctx, hop=hop, chunk_frames=n, q15=q15, output_filter=True, alpha=alpha, threshold=threshold, fsm=True)
     res = st.push(data)
     st.close()
-    fsm = Fsm(threshold)
-    dt_us = int(round(hop * 1e6 / cfg.fs))                      # one frame of audio between two FSM calls
     events = []
+    before, loc, val = "RESET", -1, -1
     for i in range(n):
-        filt = res["filtered"][i]
         likely, spotted = int(res["likely"][i]), int(res["spotted"][i])
         line = "pred: [ " + " ".join("%2.2f" % float(v) for v in res["softmax"][i]) + " ] likely: %s" % KEYWORDS[likely]
         if spotted >= 0:
             line += " spotted %s" % KEYWORDS[spotted]
-        before, cmds = fsm.state, fsm.commands
-        after = fsm.step(float(filt[likely]), likely, dt_us)
+        after = Fsm.STATES[int(res["fsm_states"][i])]
         if after != before:
             line += "   [FSM %s -> %s]" % (before, after)
-        if fsm.commands != cmds:
-            line += "   [%s %s]" % fsm.last_command
-            events.append(fsm.last_command)
+        if before == "HOT" and after == "LOC":
+            loc = likely                                          # the location that was spotted (app.c:812-816)
+        if before == "LOC" and after == "SET":
+            val = likely                                          # ... and the value (app.c:836-840)
+        if before == "SET":                                       # the step that executes the command (app.c:850-872)
+            line += "   [%s %s]" % (KEYWORDS[loc], KEYWORDS[val])
+            events.append((KEYWORDS[loc], KEYWORDS[val]))
+        before = after
         print(line, file=out)
-    return dict(result=res, commands=events, state=fsm.state)
+    assert len(events) == res["fsm"]["commands"]
+    return dict(result=res, commands=events, state=before)
 
 
 def main(argv):
