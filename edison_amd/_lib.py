@@ -13,7 +13,7 @@ DEFAULT_MODEL = os.path.join(_HERE, "data", "kws_nnom.ednn")
 OK = 0
 E_ARGUMENT, E_LENGTH, E_SIZE, E_NO_MEMORY, E_MORE_TODO = -1, -2, -3, -7, -8
 E_RUNTIME, E_NO_IMPL, E_NO_DEVICE, E_NO_MODEL = -16, -17, -18, -19
-MFCC_A, MFCC_B, MFCC_C, MFCC_USE_LOG = 0, 1, 2, 0x100
+MFCC_A, MFCC_B, MFCC_C, MFCC_TF, MFCC_USE_LOG = 0, 1, 2, 3, 0x100
 
 FS, FRAME_LEN, NUM_MEL, NUM_MFCC, UTT_FRAMES, NET_IN, NET_OUT = 16000, 1024, 32, 13, 31, 403, 10
 DIST_ID_BYTES = 128

@@ -43,8 +43,8 @@ struct edison_ctx
 	char name[128];
 	hipStream_t own_stream;
 	hipStream_t stream;
-	ed_mfcc_tables_t *d_tab[2]; /* variant A, B */
-	int mel_NLO[2], mel_NHI[2];
+	ed_mfcc_tables_t *d_tab[3]; /* variant A, B, TF (ed_tab_index) */
+	int mel_NLO[3], mel_NHI[3];
 	ed_q15_tables_t *d_q15; /* variant C (firmware Q15); NULL when the configured filterbank does not fit it */
 	int q15_nlo, q15_nhi;   /* host copy of the table shape: selects the kernel instance */
 	char q15_err[160];      /* why variant C is unavailable, when it is */

@@ -17,6 +17,8 @@ static char g_init_err[512] = "";
 
 static int set_err(edison_ctx *ctx, int code, const char *msg) { return ed_set_err(ctx, code, msg); }
 
+static inline int tab_index(int variant) { return variant == EDISON_MFCC_TF ? 2 : variant; }
+
 static int upload_tables(edison_ctx *ctx, double fs, double lo, double hi, double scale)
 {
 	/* Tables are treated like the model: graphs captured by edison_stream objects hold the kernel instance picked for the
@@ -25,11 +27,12 @@ static int upload_tables(edison_ctx *ctx, double fs, double lo, double hi, doubl
 	 * edison_stream_push* checks -- a stream created before this call refuses further pushes. */
 	ED_HIP(ctx, hipDeviceSynchronize());
 	ctx->tables_epoch++;
-	for (int v = 0; v < 2; v++)
+	static const int variants[3] = {EDISON_MFCC_A, EDISON_MFCC_B, EDISON_MFCC_TF}; /* slot = tab_index(variant) */
+	for (int v = 0; v < 3; v++)
 	{
 		ed_mfcc_tables_t *h = (ed_mfcc_tables_t *)malloc(sizeof(ed_mfcc_tables_t));
 		if (!h) return set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed");
-		int r = ed_build_mfcc_tables(v, fs, lo, hi, scale, h, ctx->err, sizeof(ctx->err));
+		int r = ed_build_mfcc_tables(variants[v], fs, lo, hi, scale, h, ctx->err, sizeof(ctx->err));
 		if (r != EDISON_OK) { free(h); return r; }
 		if (!ctx->d_tab[v]) ED_HIP(ctx, hipMalloc((void **)&ctx->d_tab[v], sizeof(ed_mfcc_tables_t)));
 		/* synchronous w.r.t. the stream: a kernel in flight may still be reading the old tables */
@@ -124,7 +127,7 @@ extern "C" void edison_shutdown(edison_ctx *ctx)
 	(void)hipSetDevice(ctx->device);
 	(void)hipDeviceSynchronize();
 	(void)edison_dist_shutdown(ctx);
-	for (int v = 0; v < 2; v++) if (ctx->d_tab[v]) (void)hipFree(ctx->d_tab[v]);
+	for (int v = 0; v < 3; v++) if (ctx->d_tab[v]) (void)hipFree(ctx->d_tab[v]);
 	if (ctx->d_q15) (void)hipFree(ctx->d_q15);
 	if (ctx->d_model) (void)hipFree(ctx->d_model);
 	if (ctx->d_model_mfma) (void)hipFree(ctx->d_model_mfma);
@@ -434,7 +437,9 @@ static int mfcc_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *au
 		return ed_ctx_mfcc_q15_launch_on(ctx, stream, audio, n_frames, fpg, group_stride, frame_step, n_coef, NULL, mfcc, feat, 0,
 		                                 NULL, NULL, NULL);
 	}
-	if (v != EDISON_MFCC_A && v != EDISON_MFCC_B) return set_err(ctx, EDISON_E_ARGUMENT, "unknown MFCC variant");
+	if (v != EDISON_MFCC_A && v != EDISON_MFCC_B && v != EDISON_MFCC_TF) return set_err(ctx, EDISON_E_ARGUMENT, "unknown MFCC variant");
+	if (v == EDISON_MFCC_TF && (variant & EDISON_MFCC_USE_LOG)) return set_err(ctx, EDISON_E_ARGUMENT, "variant TF always takes the logarithm");
+	const int ti = tab_index(v);
 	if (n_coef < 1 || n_coef > EDISON_NUM_MEL) return set_err(ctx, EDISON_E_ARGUMENT, "n_coef must be 1..32");
 	if (n_frames < 0 || n_frames >= ((int64_t)1 << 31) || frame_step < 0 || fpg < 1)
 		return set_err(ctx, EDISON_E_ARGUMENT, "bad frame count / step");
@@ -443,11 +448,12 @@ static int mfcc_launch_on(edison_ctx *ctx, hipStream_t stream, const int16_t *au
 	memset(&a, 0, sizeof(a));
 	a.audio = audio; a.n_frames = n_frames; a.frames_per_group = fpg; a.group_stride = group_stride;
 	a.frame_step = frame_step; a.n_coef = n_coef; a.use_log = (variant & EDISON_MFCC_USE_LOG) ? 1 : 0;
-	a.mel_NLO = ctx->mel_NLO[v];
-	a.mel_NHI = ctx->mel_NHI[v];
+	a.mel_NLO = ctx->mel_NLO[ti];
+	a.mel_NHI = ctx->mel_NHI[ti];
 	a.mfcc = mfcc; a.feat = feat; a.feat_scale = feat_scale;
 	a.fft = fft; a.spec = spec; a.mel = mel; a.logmel = logmel;
-	int e = ed_launch_mfcc(&a, ctx->d_tab[v], stages, ctx->n_cu, stream);
+	a.window = v == EDISON_MFCC_TF;
+	int e = ed_launch_mfcc(&a, ctx->d_tab[ti], stages, ctx->n_cu, stream);
 	if (e != 0)
 	{
 		snprintf(ctx->err, sizeof(ctx->err), "MFCC kernel launch failed: %s", hipGetErrorString((hipError_t)e));

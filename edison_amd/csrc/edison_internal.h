@@ -47,13 +47,16 @@ typedef struct {
 	float spec_scale; /* applied to 2|X[k]|: A 0.5, B 0.5/1024/sqrt(2)                                       */
 	float log_offset; /* 1e-6                                                                                */
 	int32_t always_log; /* variant A                                                                         */
-	int32_t pad_;
+	int32_t has_window; /* variant TF: the frame is multiplied by window2 before the FFT                     */
+	/* (w[2m], w[2m+1]), m = 0..511: the window as the packed frame meets it, one float2 per complex input point.
+	 * Read by the one-frame kernel's WINDOW instances only (all zero for A and B). */
+	float window2[512][2];
 } ed_mfcc_tables_t;
 
 /* mfcc_utils.gen_mel_weight_matrix in float64 (W[nbins][nmel]); returns 0 or a negative EDISON_E_* code.   */
 int ed_gen_mel_weight_matrix(int num_mel_bins, int num_spectrogram_bins, double sample_rate,
                              double lower_edge_hertz, double upper_edge_hertz, double *W);
-/* Build the device tables of one variant (0 = A, 1 = B). */
+/* Build the device tables of one variant (EDISON_MFCC_A, _B or _TF). */
 int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hertz, double upper_edge_hertz,
                          double mel_mtx_scale, ed_mfcc_tables_t *out, char *err, size_t err_cap);
 
@@ -387,6 +390,8 @@ typedef struct {
 	float *mfcc;      /* [n_frames][n_coef] or NULL */
 	int8_t *feat;     /* [n_frames][n_coef] or NULL */
 	float feat_scale;
+	int window;       /* the variant windows its frames (ed_mfcc_tables_t.window2): one-frame kernel's WINDOW instances. (Sits
+	                   * in what was alignment padding: the kernel arguments of every other instance keep their offsets.) */
 	/* stage dumps (diagnostic kernel only) */
 	float *fft, *spec, *mel, *logmel;
 } ed_mfcc_args_t;

@@ -42,12 +42,12 @@
 
 #include "mfcc_one_frame.h"
 
-template <bool STAGES, bool ALIGNED, int NLO, int NHI>
+template <bool STAGES, bool ALIGNED, int NLO, int NHI, bool WINDOW = false>
 __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
 {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	ed_mfcc1_body<STAGES, ALIGNED, NLO, NHI>(args, tab, smem, wave, blockIdx.x * ED_WPB + wave, gridDim.x * ED_WPB, nullptr);
+	ed_mfcc1_body<STAGES, ALIGNED, NLO, NHI, WINDOW>(args, tab, smem, wave, blockIdx.x * ED_WPB + wave, gridDim.x * ED_WPB, nullptr);
 }
 
 /* ================================================================================================================
@@ -515,6 +515,22 @@ static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables
 	const bool aligned = ((reinterpret_cast<uintptr_t>(args->audio) & 3) == 0) && (args->frame_step % 2 == 0) &&
 	                     (args->group_stride % 2 == 0);
 	static const int one_frame = getenv("ED_MFCC_ONE_FRAME") ? atoi(getenv("ED_MFCC_ONE_FRAME")) : 0; /* A/B knob */
+	if (args->window)
+	{
+		/* variant TF (windowed frames): the one-frame kernel's WINDOW instances; the two-frame kernel has none */
+		dim3 grid((unsigned)blocks), block(64 * ED_WPB);
+		if (stages)
+		{
+			if (aligned) hipLaunchKernelGGL((ed_mfcc_kernel<true, true, NLO, NHI, true>), grid, block, lds, stream, *args, dev_tab);
+			else hipLaunchKernelGGL((ed_mfcc_kernel<true, false, NLO, NHI, true>), grid, block, lds, stream, *args, dev_tab);
+		}
+		else
+		{
+			if (aligned) hipLaunchKernelGGL((ed_mfcc_kernel<false, true, NLO, NHI, true>), grid, block, lds, stream, *args, dev_tab);
+			else hipLaunchKernelGGL((ed_mfcc_kernel<false, false, NLO, NHI, true>), grid, block, lds, stream, *args, dev_tab);
+		}
+		return (int)hipGetLastError();
+	}
 	if (!stages && !one_frame)
 	{
 		/* the fast path: two frames per wavefront in packed fp32, one ED2_WPB-wave workgroup per CU */

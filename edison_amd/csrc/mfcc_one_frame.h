@@ -63,7 +63,7 @@ __device__ __forceinline__ void ed_load_frame(const int16_t *fp, int lane, uint3
  * the workgroup must call it (table staging + one workgroup barrier); a wave takes frames f_first, f_first + f_stride, ...
  * below args.n_frames -- none at all if f_first is not below it. feat2: a second place for the int8 feature row (any address
  * space, e.g. LDS), or null. */
-template <bool STAGES, bool ALIGNED, int NLO, int NHI>
+template <bool STAGES, bool ALIGNED, int NLO, int NHI, bool WINDOW = false>
 __device__ __forceinline__ void ed_mfcc1_body(const ed_mfcc_args_t &args, const ed_mfcc_tables_t *__restrict__ tab, float *smem, int wave,
                                               uint32_t f_first, uint32_t f_stride, int8_t *feat2)
 {
@@ -120,6 +120,16 @@ __device__ __forceinline__ void ed_mfcc1_body(const ed_mfcc_args_t &args, const 
 		{
 			re[a] = (float)(int16_t)(raw[a] & 0xffffu);
 			im[a] = (float)(int16_t)(raw[a] >> 16);
+		}
+		if (WINDOW) /* variant TF: tf.signal.stft's Hann window on the float32 samples, as (w[2m], w[2m+1]) per packed point */
+		{
+#pragma unroll
+			for (int a = 0; a < 8; a++)
+			{
+				const float2 w = *reinterpret_cast<const float2 *>(&tab->window2[lane + 64 * a][0]);
+				re[a] *= w.x;
+				im[a] *= w.y;
+			}
 		}
 		if (f + stride < n_frames) ed_load_frame<ALIGNED>(ed_frame_ptr(args, f + stride), lane, raw);
 

@@ -6,6 +6,8 @@
  *   hertz_to_mel            audio/edison/mfcc/mfcc_utils.py:30-34, constants audio/config.py:35-36
  *   variant A scaling       mfcc_utils.py:171-193  (|fft|[:512], 512-bin matrix, ln(x+1e-6), dct2/sqrt(2*32))
  *   variant B scaling       mfcc_utils.py:282-318  (fft/1024, |.|/sqrt2, 513-bin matrix, dct2 * 1/64)
+ *   variant TF              mfcc_utils.py:201-253  (tf.signal.stft: periodic Hann window, rfft; |.|, 513-bin matrix,
+ *                           ln(x+1e-6), tf.signal.mfccs_from_log_mel_spectrograms = dct2 * rsqrt(2*32))
  *
  * The device works on Z = FFT512(x[2n] + i*x[2n+1]) and on 2*X[k] (see mfcc_kernels.hip), so the factor 1/2
  * of the real-FFT split is folded into spec_scale together with the variant's own normalisation.
@@ -145,11 +147,12 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 {
 	const int NMEL = EDISON_NUM_MEL;
 	const int nbins = (variant == EDISON_MFCC_A) ? EDISON_FRAME_LEN / 2 : EDISON_FRAME_LEN / 2 + 1;
-	if (variant != EDISON_MFCC_A && variant != EDISON_MFCC_B) return EDISON_E_ARGUMENT;
+	if (variant != EDISON_MFCC_A && variant != EDISON_MFCC_B && variant != EDISON_MFCC_TF) return EDISON_E_ARGUMENT;
 	memset(out, 0, sizeof(*out));
 	/* scale of the reference's spectrogram relative to the kernel's 2|X[k]|: A |X| (mfcc_utils.py:174),
-	 * B |X/1024|/sqrt2 (mfcc_utils.py:297-300) */
-	const double spec_scale = (variant == EDISON_MFCC_A) ? 0.5 : 0.5 / 1024.0 / sqrt(2.0);
+	 * B |X/1024|/sqrt2 (mfcc_utils.py:297-300),
+	 * TF |X| (tf.abs(stfts), mfcc_utils.py:222) */
+	const double spec_scale = (variant == EDISON_MFCC_B) ? 0.5 / 1024.0 / sqrt(2.0) : 0.5;
 
 	/* --- FFT twiddles, rounded once from float64 */
 	for (int l = 0; l < 64; l++)
@@ -253,7 +256,7 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 	free(W);
 
 	/* --- DCT-II (scipy.fftpack.dct type 2, norm=None: y[c] = 2*sum x[n] cos(pi*c*(2n+1)/(2N))) + scaling */
-	double dscale = (variant == EDISON_MFCC_A) ? 1.0 / sqrt(2.0 * (double)NMEL) : 1.0 / 64.0;
+	double dscale = (variant == EDISON_MFCC_B) ? 1.0 / 64.0 : 1.0 / sqrt(2.0 * (double)NMEL);
 	for (int l = 0; l < 64; l++)
 	{
 		int c = l & 31, h = l >> 5;
@@ -266,6 +269,13 @@ int ed_build_mfcc_tables(int variant, double sample_rate, double lower_edge_hert
 	}
 	out->spec_scale = (float)spec_scale;
 	out->log_offset = 1e-6f;
-	out->always_log = (variant == EDISON_MFCC_A) ? 1 : 0;
+	out->always_log = (variant == EDISON_MFCC_B) ? 0 : 1;
+	if (variant == EDISON_MFCC_TF)
+	{
+		/* tf.signal.hann_window(frame_length, periodic=True): 0.5 - 0.5 cos(2 pi n / N), rounded once from float64 */
+		out->has_window = 1;
+		for (int n = 0; n < EDISON_FRAME_LEN; n++)
+			out->window2[n / 2][n % 2] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)EDISON_FRAME_LEN));
+	}
 	return EDISON_OK;
 }

@@ -11,8 +11,10 @@ kws_keras.py:450, kws_on_mcu.py:293,343,...) can import this module in its place
   mfcc_mcu                mfcc_utils.py:255-323   -> edison_mfcc_stages, variant B
 
   dct2Makhoul             mfcc_utils.py:324-343   (host numpy helper of the board tools: DCT-II through one FFT)
-  mfcc_tf                 mfcc_utils.py:201-253   TensorFlow's own MFCC, a comparison curve of mfcc.py only: raises
-                                                  (TensorFlow is not a dependency of this path)
+  mfcc_tf                 mfcc_utils.py:201-253   -> edison_mfcc_stages, variant TF: tf.signal's pipeline (periodic Hann
+                                                  window, rfft, 513-bin mel matrix, ln, dct2*rsqrt(64)) on the GPU.
+                                                  TensorFlow is not in this image: PARITY UNPINNED, checked against a
+                                                  float64 restatement of tf.signal's published definitions only
 
 The GPU path is specialised for the reference's shipped geometry: 1024-sample frames and 32 mel bins
 (audio/config.py:15,19). Other values raise NotImplementedError rather than silently taking another path.
@@ -171,6 +173,30 @@ def dct2Makhoul(x):
     return (V * twiddle).real, v, V
 
 
-def mfcc_tf(*args, **kwargs):
-    """tf.signal's MFCC (mfcc_utils.py:201-253): only a comparison curve in mfcc.py, needs TensorFlow."""
-    raise NotImplementedError("mfcc_tf needs TensorFlow, which this path does not depend on; use mfcc() / mfcc_mcu()")
+def mfcc_tf(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, mel_nbins, mel_lower_hz, mel_upper_hz,
+            unused=None):
+    """The TensorFlow curve of ``main.py mfcc host`` (mfcc_utils.py:201-253) without TensorFlow: tf.signal.stft with its
+    default periodic Hann window, tf.abs, tf.signal.linear_to_mel_weight_matrix over the fft_len/2+1 unique bins,
+    ln(x + 1e-6) and tf.signal.mfccs_from_log_mel_spectrograms (DCT-II * rsqrt(2 * mel_nbins)), all on the GPU (variant TF of
+    the C-ABI). Same list of per-frame dicts, with the DC bin cut from 'fft', 'spectrogram' and 'mel_weight_matrix' as the
+    reference does (:245-249); float32 arithmetic like TensorFlow's. Parity unpinned (see the module docstring)."""
+    if fft_len != frame_len:
+        raise NotImplementedError("the MI355X path implements fft_len == frame_len (audio/config.py:15-16)")
+    ctx = _prepare(fs, frame_len, mel_nbins, mel_lower_hz, mel_upper_hz)
+    frame_count = _frame_count(frame_count, nSamples, frame_len, frame_step)
+    st = ctx.mfcc_stages(_as_int16(data), n_frames=frame_count, frame_step=frame_step, variant=_lib.MFCC_TF)
+    W = gen_mel_weight_matrix(num_mel_bins=mel_nbins, num_spectrogram_bins=fft_len // 2 + 1, sample_rate=fs,
+                              lower_edge_hertz=mel_lower_hz, upper_edge_hertz=mel_upper_hz)
+    output = []
+    for f in range(frame_count):
+        frame = {}
+        frame['t_start'] = f * frame_step / fs
+        frame['t_end'] = (f * frame_step + frame_len) / fs
+        frame['fft'] = st['fft'][f, 1:].astype(np.complex64)
+        frame['spectrogram'] = st['spectrogram'][f, 1:]
+        frame['mel_weight_matrix'] = W[1:].astype(np.float32)
+        frame['mel_spectrogram'] = st['mel_spectrogram'][f]
+        frame['log_mel_spectrogram'] = st['log_mel_spectrogram'][f]
+        frame['mfcc'] = st['mfcc'][f]
+        output.append(frame)
+    return output

@@ -64,6 +64,11 @@ extern "C" {
                          * Integer-exact. Through the fp32 entry points below the outputs are the int16 values as
                          * floats (Cube branch of mfccToNetInput, app.c:680-683) and feat is the NNoM branch
                          * (app.c:686-694); feat_scale must be 1, no log. Native int16 interface: edison_mfcc_q15_*.  */
+#define EDISON_MFCC_TF 3 /* mfcc_utils.mfcc_tf (mfcc_utils.py:201-253), the TensorFlow curve of `main.py mfcc host`:
+                          * periodic Hann window (tf.signal.stft's default) -> rfft -> |.| -> mel(513x32) -> ln(x+1e-6) ->
+                          * dct2/sqrt(64). Batch and stage entry points only (edison_mfcc_batch / _rows / _stages and
+                          * their _dev forms); TensorFlow is not in this image, so this variant's parity is UNPINNED:
+                          * it is checked against a float64 restatement of tf.signal's published definitions only.     */
 #define EDISON_MFCC_USE_LOG 0x100 /* OR into variant: mfcc_mcu(..., use_log=True)                       */
 
 typedef struct edison_ctx edison_ctx;

@@ -7,6 +7,7 @@
  *   gen_mel_weight_matrix  audio/edison/mfcc/mfcc_utils.py:36-73
  *   mfcc       (variant A) audio/edison/mfcc/mfcc_utils.py:134-199
  *   mfcc_mcu   (variant B) audio/edison/mfcc/mfcc_utils.py:255-323
+ *   mfcc_tf    (variant TF) audio/edison/mfcc/mfcc_utils.py:201-253 -- PARITY UNPINNED, see oracle.h
  *
  * The FFT and the DCT live in third-party dependencies that are not under /root/reference
  * (numpy==1.18.2 np.fft.fft, scipy==1.4.1 scipy.fftpack.dct, audio/requirements.txt:33,58). They are
@@ -112,10 +113,11 @@ int oracle_mfcc(const int16_t *x, int64_t n_frames, int frame_len, int64_t frame
 {
 	const int N = frame_len, nmel = num_mel_bins;
 	if (N < 2 || (N & (N - 1)) != 0 || nmel < 1) return -1;
-	if (variant != ORACLE_MFCC_VARIANT_A && variant != ORACLE_MFCC_VARIANT_B) return -1;
+	if (variant != ORACLE_MFCC_VARIANT_A && variant != ORACLE_MFCC_VARIANT_B && variant != ORACLE_MFCC_VARIANT_TF) return -1;
 	/* A: spectrogram = |fft|[:N/2], mel matrix built for N/2 bins (mfcc_utils.py:171-181)
-	 * B: spectrogram = |fft/N|/sqrt2 over all N bins, mel uses the first N/2+1 (:297-308) */
-	const int nspec_out = (variant == ORACLE_MFCC_VARIANT_A) ? N / 2 : N;
+	 * B: spectrogram = |fft/N|/sqrt2 over all N bins, mel uses the first N/2+1 (:297-308)
+	 * TF: spectrogram = |rfft(hann * frame)| over the N/2+1 unique bins, all of them into the mel product (:218-231) */
+	const int nspec_out = (variant == ORACLE_MFCC_VARIANT_A) ? N / 2 : (variant == ORACLE_MFCC_VARIANT_TF) ? N / 2 + 1 : N;
 	const int nbins = (variant == ORACLE_MFCC_VARIANT_A) ? N / 2 : N / 2 + 1;
 
 	double *W = (double *)malloc(sizeof(double) * (size_t)nbins * nmel);
@@ -136,8 +138,9 @@ int oracle_mfcc(const int16_t *x, int64_t n_frames, int frame_len, int64_t frame
 	for (int k = 0; k < nmel; k++)
 		for (int n = 0; n < nmel; n++)
 			dct[(size_t)k * nmel + n] = 2.0 * cos(M_PI * (double)k * (double)(2 * n + 1) / (double)(2 * nmel));
-	/* A: / sqrt(2*mel_nbins) (:193); B: * 1.0/64 (:318, a literal 64 in the reference) */
-	const double dct_div = (variant == ORACLE_MFCC_VARIANT_A) ? sqrt(2.0 * (double)nmel) : 64.0;
+	/* A: / sqrt(2*mel_nbins) (:193); B: * 1.0/64 (:318, a literal 64 in the reference)
+	 * TF: tf.signal.mfccs_from_log_mel_spectrograms = dct(type 2) * rsqrt(2 * num_mel_bins), the same scale as A */
+	const double dct_div = (variant == ORACLE_MFCC_VARIANT_B) ? 64.0 : sqrt(2.0 * (double)nmel);
 
 	int err = 0;
 #ifdef _OPENMP
@@ -164,10 +167,16 @@ int oracle_mfcc(const int16_t *x, int64_t n_frames, int frame_len, int64_t frame
 			{
 				const int16_t *chunk = x + f * frame_step; /* :168 / :293 */
 				for (int i = 0; i < N; i++) { re[i] = (double)chunk[i]; im[i] = 0.0; }
+				if (variant == ORACLE_MFCC_VARIANT_TF) /* tf.signal.hann_window(N, periodic=True), stft's default window_fn */
+					for (int i = 0; i < N; i++) re[i] *= 0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)N);
 				fft_c2c(re, im, N, twr, twi);
 				if (variant == ORACLE_MFCC_VARIANT_A)
 				{
 					for (int k = 0; k < N / 2; k++) sp[k] = hypot(re[k], im[k]); /* :171-174 */
+				}
+				else if (variant == ORACLE_MFCC_VARIANT_TF)
+				{
+					for (int k = 0; k <= N / 2; k++) sp[k] = hypot(re[k], im[k]); /* :222 tf.abs(stfts) */
 				}
 				else
 				{
@@ -185,7 +194,7 @@ int oracle_mfcc(const int16_t *x, int64_t n_frames, int frame_len, int64_t frame
 					for (int j = 0; j < nmel; j++) me[j] /= mel_mtx_scale; /* :309 */
 				for (int j = 0; j < nmel; j++)
 				{
-					if (variant == ORACLE_MFCC_VARIANT_A) lm[j] = log(me[j] + 1e-6);  /* :189 */
+					if (variant != ORACLE_MFCC_VARIANT_B) lm[j] = log(me[j] + 1e-6);  /* :189 / :233 */
 					else lm[j] = use_log ? log(me[j] + 1e-6) : me[j];                 /* :313-315 */
 				}
 				if (spectrogram) memcpy(spectrogram + (size_t)f * nspec_out, sp, sizeof(double) * (size_t)nspec_out);
@@ -196,7 +205,7 @@ int oracle_mfcc(const int16_t *x, int64_t n_frames, int frame_len, int64_t frame
 					{
 						double acc = 0.0;
 						for (int n = 0; n < nmel; n++) acc += lm[n] * dct[(size_t)k * nmel + n];
-						mfcc[(size_t)f * nmel + k] = (variant == ORACLE_MFCC_VARIANT_A) ? acc / dct_div
+						mfcc[(size_t)f * nmel + k] = (variant != ORACLE_MFCC_VARIANT_B) ? acc / dct_div
 						                                                                : 1.0 / dct_div * acc;
 					}
 			}

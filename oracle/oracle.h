@@ -24,6 +24,12 @@ extern "C" {
 
 #define ORACLE_MFCC_VARIANT_A 0 /* mfcc_utils.mfcc      (audio/edison/mfcc/mfcc_utils.py:134-199) */
 #define ORACLE_MFCC_VARIANT_B 1 /* mfcc_utils.mfcc_mcu  (audio/edison/mfcc/mfcc_utils.py:255-323) */
+/* mfcc_utils.mfcc_tf (audio/edison/mfcc/mfcc_utils.py:201-253). PARITY UNPINNED: the arithmetic lives in TensorFlow
+ * (tensorflow==2.1.0, audio/requirements.txt), which is neither under /root/reference nor installed here, and the reference
+ * holds no output of it. Restated in float64 from tf.signal's published definitions (stft: periodic Hann window, rfft;
+ * linear_to_mel_weight_matrix -- which gen_mel_weight_matrix above is the reference's own numpy port of;
+ * mfccs_from_log_mel_spectrograms: DCT-II * rsqrt(2 * num_mel_bins)). spectrogram is [n_frames][frame_len/2 + 1]. */
+#define ORACLE_MFCC_VARIANT_TF 3
 
 /* gen_mel_weight_matrix (mfcc_utils.py:36-73): W is [num_spectrogram_bins][num_mel_bins] row-major. */
 void oracle_mel_weight_matrix(int num_mel_bins, int num_spectrogram_bins, double sample_rate,

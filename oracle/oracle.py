@@ -27,6 +27,7 @@ F32_REF_SO = os.path.join(_HERE, "_ref", "libmfcc_f32_ref.so")    # the referenc
 DEFAULT_MODEL = os.path.join(os.path.dirname(_HERE), "edison_amd", "data", "kws_nnom.ednn")
 
 VARIANT_A, VARIANT_B = 0, 1
+VARIANT_TF = 3  # mfcc_utils.mfcc_tf restated from tf.signal's definitions: PARITY UNPINNED (oracle.h)
 L_CONV, L_POOL, L_DENSE, L_SOFTMAX = 1, 2, 3, 4
 
 # audio/config.py:11-32
@@ -368,7 +369,7 @@ def mfcc(x, variant, n_frames=None, frame_len=FRAME_LEN, frame_step=FRAME_LEN, u
     if n_frames <= 0:
         return np.zeros((0, num_mel_bins))
     assert (n_frames - 1) * frame_step + frame_len <= x.shape[0]
-    nspec = frame_len // 2 if variant == VARIANT_A else frame_len
+    nspec = frame_len // 2 if variant == VARIANT_A else frame_len // 2 + 1 if variant == VARIANT_TF else frame_len
     out = np.zeros((n_frames, num_mel_bins), np.float64)
     sp = np.zeros((n_frames, nspec), np.float64) if stages else None
     me = np.zeros((n_frames, num_mel_bins), np.float64) if stages else None

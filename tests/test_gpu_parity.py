@@ -85,6 +85,64 @@ def test_mfcc_vs_oracle_seeded(ctx, oracle_mod):
         _close(got, oracle_mod.mfcc(x, ov, n_threads=4), variant)
 
 
+def test_mfcc_tf_variant_against_the_float64_restatement(ctx, built_lib, oracle_mod, mfcc_golden):
+    """Variant TF = mfcc_utils.mfcc_tf (mfcc_utils.py:201-253), the TensorFlow curve of `main.py mfcc host`. PARITY UNPINNED:
+    TensorFlow is not installed and the reference holds no output of it, so the GPU is held to the oracle's float64
+    restatement of tf.signal's definitions (oracle.h), with variant A's bar (same logarithm and DCT scale). What IS pinned:
+    the 513-bin mel matrix both use is the reference's own (golden mel_W513, test_host_cpu.py)."""
+    from edison_amd import _lib
+    from edison_amd.mfcc import mfcc_utils as mfu
+    for name in ("edison", "two_tone", "noise", "extremes", "quiet"):
+        x = mfcc_golden["in_" + name]
+        ref, rst = oracle_mod.mfcc(x, oracle_mod.VARIANT_TF, stages=True)
+        st = ctx.mfcc_stages(x, variant=_lib.MFCC_TF)
+        # a band whose energy lies below the float32 FFT's rounding floor (a windowed constant frame has exact zeros outside
+        # three bins in float64, ~1e-7 of the line in float32 -- TensorFlow's float32 FFT has such a floor of its own) has a
+        # logarithm that is all rounding: those frames are held to the linear stages only
+        ok = rst["mel_spectrogram"].min(axis=1) > 1e-5 * rst["spectrogram"].max(axis=1)
+        assert ok.sum() >= (1 if name == "extremes" else len(ok) - 1), (name, ok)
+        full = st
+        st = {k: v[ok] for k, v in full.items()}
+        rst, ref, lin, rlin = {k: v[ok] for k, v in rst.items()}, ref[ok], full, rst
+        assert np.abs(lin["spectrogram"] - rlin["spectrogram"]).max() <= 2e-6 * np.abs(rlin["spectrogram"]).max() + 1e-30
+        assert np.abs(lin["mel_spectrogram"] - rlin["mel_spectrogram"]).max() <= 2e-6 * np.abs(rlin["mel_spectrogram"]).max() + 1e-30
+        _close(st["mfcc"], ref, "A")
+        assert np.abs(st["spectrogram"] - rst["spectrogram"]).max() <= 2e-6 * np.abs(rst["spectrogram"]).max() + 1e-30
+        assert np.abs(st["mel_spectrogram"] - rst["mel_spectrogram"]).max() <= 2e-6 * np.abs(rst["mel_spectrogram"]).max() + 1e-30
+        # the window takes the leakage away, so quiet bands sit further below the strongest line than in variant A and carry
+        # more of the float32 FFT's rounding floor (~1e-7 of that line) into their logarithm: 1.1e-4 measured on two_tone
+        assert np.abs(st["log_mel_spectrogram"] - rst["log_mel_spectrogram"]).max() <= 5e-4
+        # the batch entry points take the same kernel: bit-identical to the stage dump, any n_coef, any hop / alignment
+        assert np.array_equal(ctx.mfcc(x, variant=_lib.MFCC_TF, n_coef=32), full["mfcc"])
+        assert np.array_equal(ctx.mfcc(x, variant=_lib.MFCC_TF, n_coef=13), full["mfcc"][:, :13])
+    x = mfcc_golden["in_noise"]
+    _close(ctx.mfcc(x, frame_step=333, variant=_lib.MFCC_TF, n_coef=32), oracle_mod.mfcc(x, oracle_mod.VARIANT_TF, frame_step=333), "A")
+    _close(ctx.mfcc(x[1:], variant=_lib.MFCC_TF, n_coef=32), oracle_mod.mfcc(x[1:], oracle_mod.VARIANT_TF), "A")
+    rows = np.stack([x[:4096], x[4096:8192]])
+    got = ctx.mfcc_rows(rows, 4, variant=_lib.MFCC_TF, n_coef=32)
+    assert np.array_equal(got[1], ctx.mfcc(x[4096:8192], variant=_lib.MFCC_TF, n_coef=32))
+    # a window is not a scale: TF differs from A on the same frames, and a constant frame has no energy outside DC's neighbours
+    assert np.abs(ctx.mfcc(x, variant=_lib.MFCC_TF, n_coef=32) - ctx.mfcc(x, variant=_lib.MFCC_A, n_coef=32)).max() > 0.1
+    # the reference's structure (:239-252): DC cut from fft / spectrogram / matrix, float32 like TensorFlow's tensors
+    xe = mfcc_golden["in_edison"]
+    o = mfu.mfcc_tf(xe, 16000, len(xe), 1024, 1024, 0, 1024, 32, 80.0, 7600.0)
+    assert len(o) == 10 and set(o[3]) == {"t_start", "t_end", "fft", "spectrogram", "mel_weight_matrix", "mel_spectrogram",
+                                          "log_mel_spectrogram", "mfcc"}
+    assert o[3]["fft"].shape == (512,) and o[3]["spectrogram"].shape == (512,) and o[3]["mel_weight_matrix"].shape == (512, 32)
+    assert o[3]["mfcc"].shape == (32,) and o[3]["t_start"] == 3 * 1024 / 16000
+    np.testing.assert_allclose(o[3]["mel_weight_matrix"], mfcc_golden["mel_W513"][1:], rtol=0, atol=1e-7)
+    _close(np.array([f["mfcc"] for f in o]), oracle_mod.mfcc(xe, oracle_mod.VARIANT_TF), "A")
+    with pytest.raises(NotImplementedError):
+        mfu.mfcc_tf(xe, 16000, len(xe), 1024, 1024, 0, 2048, 32, 80.0, 7600.0)
+    # always a logarithm (no use_log flag), no stream stage, no one-launch microphone push
+    with pytest.raises(_lib.EdisonError):
+        ctx.mfcc(xe, variant=_lib.MFCC_TF, use_log=True)
+    L, o_, h = _lib.lib(), _lib.StreamOpts(), ctypes.c_void_p()
+    L.edison_stream_default_opts(ctypes.byref(o_))
+    o_.mfcc_variant = _lib.MFCC_TF
+    assert L.edison_stream_create_ex(ctx._h, ctypes.byref(o_), ctypes.byref(h)) == _lib.E_ARGUMENT
+
+
 def test_mfcc_overlap_unaligned_ncoef_log(ctx, oracle_mod, mfcc_golden):
     x = mfcc_golden["in_noise"]
     from edison_amd import _lib
@@ -331,7 +389,7 @@ def test_cli_entry_points(ctx, kws_golden, mfcc_golden, tmp_path, capsys):
     wavfile.write(wav, 16000, mfcc_golden["in_edison"])
     assert cli.main(["main.py", "mfcc", "host", wav]) == 0
     out = capsys.readouterr().out
-    assert "Number of input samples = 11243" in out and "(2, 10, 13)" in out
+    assert "Number of input samples = 11243" in out and "(4, 10, 13)" in out   # own, tf, mcu, mcu log (mfcc.py:209-216)
     assert cli.main(["main.py", "kws", "mcu", "fileinf", wav]) == 0
     out = capsys.readouterr().out
     assert "edison" in out.splitlines()[-2]

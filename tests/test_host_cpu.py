@@ -337,7 +337,7 @@ def test_mfcc_lane_tables_hold_the_whole_filterbank(built_lib, mfcc_golden, vari
     assert not W[nbins:].any()
 
 
-def test_dct2_makhoul_helper_and_tf_stub():
+def test_dct2_makhoul_helper_and_mfcc_tf_signature():
     """mfcc_utils.dct2Makhoul (mfcc_utils.py:324-343) = scipy's DCT-II, with the reordered input and its FFT."""
     from scipy.fftpack import dct
     from edison_amd.mfcc import mfcc_utils as mfu
@@ -347,8 +347,15 @@ def test_dct2_makhoul_helper_and_tf_stub():
         d, v, V = mfu.dct2Makhoul(x)
         np.testing.assert_allclose(d, dct(x, 2), rtol=1e-12, atol=1e-12)
         assert sorted(v.tolist()) == sorted(x.tolist()) and np.allclose(V, np.fft.fft(v))
+    # mfcc_tf takes the reference's positional arguments (mfcc_utils.py:201-204) and, like its siblings, refuses a geometry
+    # the GPU path is not built for before it touches the device
+    import inspect
+    assert list(inspect.signature(mfu.mfcc_tf).parameters) == ["data", "fs", "nSamples", "frame_len", "frame_step", "frame_count",
+                                                              "fft_len", "mel_nbins", "mel_lower_hz", "mel_upper_hz", "unused"]
     with pytest.raises(NotImplementedError):
-        mfu.mfcc_tf(np.zeros(1024), 16000)
+        mfu.mfcc_tf(np.zeros(1024), 16000, 1024, 1024, 1024, 0, 2048, 32, 80.0, 7600.0)
+    with pytest.raises(NotImplementedError):
+        mfu.mfcc_tf(np.zeros(1024), 16000, 1024, 512, 512, 0, 512, 32, 80.0, 7600.0)
 
 
 def test_net_out_filt_mirror():

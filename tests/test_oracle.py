@@ -48,6 +48,29 @@ def test_oracle_mel_matrix(oracle_mod, mfcc_golden):
     assert not mfcc_golden["mel_W513"][0].any()
 
 
+def test_mfcc_tf_restatement_against_numpy_and_scipy(oracle_mod, mfcc_golden):
+    """oracle VARIANT_TF (mfcc_utils.mfcc_tf, mfcc_utils.py:201-253) is PARITY UNPINNED: TensorFlow is not installed here and
+    the reference holds no output of it. This test only shows that the C restatement computes what tf.signal documents --
+    periodic Hann window, rfft, |.|, the 513-bin mel matrix (pinned: the reference's own, golden mel_W513), ln(x + 1e-6),
+    DCT-II * rsqrt(2 * 32) -- by recomputing it with numpy.fft and scipy.fft."""
+    import scipy.fft
+    x = np.concatenate([mfcc_golden["in_edison"], mfcc_golden["in_noise"][:3072], mfcc_golden["in_extremes"][:2048]])
+    n = x.shape[0] // 1024
+    fr = x[:n * 1024].reshape(n, 1024).astype(np.float64)
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(1024) / 1024.0)
+    spec = np.abs(np.fft.rfft(fr * win, axis=1))
+    mel = spec @ mfcc_golden["mel_W513"]
+    lm = np.log(mel + 1e-6)
+    want = scipy.fft.dct(lm, type=2, axis=1) / np.sqrt(2.0 * 32)
+    got, st = oracle_mod.mfcc(x, oracle_mod.VARIANT_TF, stages=True)
+    assert st["spectrogram"].shape == (n, 513)
+    np.testing.assert_allclose(st["spectrogram"], spec, rtol=0, atol=1e-9 * spec.max())
+    np.testing.assert_allclose(st["mel_spectrogram"], mel, rtol=0, atol=1e-9 * mel.max())
+    np.testing.assert_allclose(st["log_mel_spectrogram"], lm, rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(got, want, rtol=1e-7, atol=1e-6)
+    assert np.abs(got - oracle_mod.mfcc(x, oracle_mod.VARIANT_A)).max() > 0.1   # a windowed frame is not variant A's frame
+
+
 def test_reference_known_answers(mfcc_golden, cnn_golden, kws_golden):
     """The vectors SURVEY.md 8(c) recorded from the reference, re-checked on the committed fixtures."""
     np.testing.assert_allclose(mfcc_golden["A_mfcc_edison"][3][:3], [97.5289613, 2.47939590, 0.516462789], rtol=1e-8)
