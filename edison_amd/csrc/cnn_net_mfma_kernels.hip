@@ -275,6 +275,49 @@ __device__ __forceinline__ void emm_chain(const lds8 *(&fl)[R], const int8_t *(&
 			aw[t][4 * g] = s4.x; aw[t][4 * g + 1] = s4.y; aw[t][4 * g + 2] = s4.z; aw[t][4 * g + 3] = s4.w;
 		}
 	const int last = n_ks - 1;
+#if !EMM_SPEC
+	/* The general kernel's n_ks is a run-time number: the loop is two k-steps long and the operands PING-PONG between two
+	 * register sets -- set 0 holds the even steps, set 1 the odd ones -- so that "carry the operands into the next step" is
+	 * no instruction at all (the one-step form below copied (R + C NW) fragments per step with v_mov: ~30 moves beside four
+	 * MFMAs in this kernel). Same program order as below: the chunk offset of step s+2, the operands of step s+1, the
+	 * MFMAs of step s. */
+	int k0 = EMM_LD32(kp), k1 = EMM_LD32(kp + 8 * (last < 1 ? last : 1));
+	v4i a0[R], b0[NB], a1[R], b1[NB];
+#pragma unroll
+	for (int r = 0; r < R; r++) a0[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], 0);
+#pragma unroll
+	for (int c = 0; c < NB; c++) b0[c] = EMM_LD128(bw[c] + k0);
+	int s = 0;
+	for (; s + 1 < ((EMM_SKIP & 2) ? 0 : n_ks); s += 2)
+	{
+		k0 = EMM_LD32(kp + 8 * (s + 2 < n_ks ? s + 2 : last));
+#pragma unroll
+		for (int r = 0; r < R; r++) a1[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], s + 1);
+#pragma unroll
+		for (int c = 0; c < NB; c++) b1[c] = EMM_LD128(bw[c] + k1);
+#pragma unroll
+		for (int t = 0; t < NT; t++) aw[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[t / (C * NW)], b0[t % (C * NW)], aw[t], 0, 0, 0);
+		k1 = EMM_LD32(kp + 8 * (s + 3 < n_ks ? s + 3 : last));
+		if (s + 2 < n_ks) /* uniform: the last step has nothing to fetch (a k-step's operands are R + C * NW KB of LDS traffic) */
+		{
+#pragma unroll
+			for (int r = 0; r < R; r++) a0[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], s + 2);
+#pragma unroll
+			for (int c = 0; c < NB; c++) b0[c] = EMM_LD128(bw[c] + k0);
+		}
+#pragma unroll
+		for (int t = 0; t < NT; t++) aw[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1[t / (C * NW)], b1[t % (C * NW)], aw[t], 0, 0, 0);
+		/* set 0 and the odd offset cross the back edge: see emm_keep */
+		asm volatile("" : "+v"(k1));
+		emm_keep(a0);
+		emm_keep(b0);
+	}
+	if (s < ((EMM_SKIP & 2) ? 0 : n_ks)) /* an odd count: the last step's operands are in set 0 */
+	{
+#pragma unroll
+		for (int t = 0; t < NT; t++) aw[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[t / (C * NW)], b0[t % (C * NW)], aw[t], 0, 0, 0);
+	}
+#else
 	int k_cur = EMM_LD32(kp), k_nxt = EMM_LD32(kp + 8 * (last < 1 ? last : 1));
 	v4i a[R], b[NB];
 #pragma unroll
@@ -308,6 +351,7 @@ __device__ __forceinline__ void emm_chain(const lds8 *(&fl)[R], const int8_t *(&
 		emm_keep(a);
 		emm_keep(b);
 	}
+#endif
 #pragma unroll
 	for (int u = 0; u < R * C; u++)
 	{
@@ -513,6 +557,37 @@ __device__ __forceinline__ void emm_layer_small(const emm_mm_args &A, int lane)
 			fg[u] = A.fragg + (size_t)rts[u] * n_ks * 1024 + lane * 16;
 			a[u] = emm_load_a<FRAG_LDS>(fl[u], fg[u], 0);
 		}
+#if !EMM_SPEC
+		/* two k-steps per iteration, the operands ping-pong between two register sets (see emm_chain) */
+		int k0 = EMM_LD32(kp), k1 = EMM_LD32(kp + 16 * (last < 1 ? last : 1));
+		v4i bq = EMM_LD128(bp + k0), a1[U], b1;
+		int s = 0;
+		for (; s + 1 < ((EMM_SKIP & 2) ? 0 : n_ks); s += 2)
+		{
+			k0 = EMM_LD32(kp + 16 * (s + 2 < n_ks ? s + 2 : last));
+#pragma unroll
+			for (int u = 0; u < U; u++) a1[u] = emm_load_a<FRAG_LDS>(fl[u], fg[u], s + 1);
+			b1 = EMM_LD128(bp + k1);
+#pragma unroll
+			for (int u = 0; u < U; u++) aw[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[u], bq, aw[u], 0, 0, 0);
+			k1 = EMM_LD32(kp + 16 * (s + 3 < n_ks ? s + 3 : last));
+			if (s + 2 < n_ks) /* uniform: the last step has nothing to fetch */
+			{
+#pragma unroll
+				for (int u = 0; u < U; u++) a[u] = emm_load_a<FRAG_LDS>(fl[u], fg[u], s + 2);
+				bq = EMM_LD128(bp + k0);
+			}
+#pragma unroll
+			for (int u = 0; u < U; u++) aw[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[u], b1, aw[u], 0, 0, 0);
+			asm volatile("" : "+v"(k1), "+v"(bq));
+			emm_keep(a);
+		}
+		if (s < ((EMM_SKIP & 2) ? 0 : n_ks))
+		{
+#pragma unroll
+			for (int u = 0; u < U; u++) aw[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[u], bq, aw[u], 0, 0, 0);
+		}
+#else
 		int k_cur = EMM_LD32(kp), k_nxt = EMM_LD32(kp + 16 * (last < 1 ? last : 1));
 		v4i bq = EMM_LD128(bp + k_cur);
 		for (int s = 0; s < ((EMM_SKIP & 2) ? 0 : n_ks); s++)
@@ -536,6 +611,7 @@ __device__ __forceinline__ void emm_layer_small(const emm_mm_args &A, int lane)
 			asm volatile("" : "+v"(k_nxt), "+v"(bq));
 			emm_keep(a);
 		}
+#endif
 		/* lane (column, kq) holds rows 16 rt + 4 kq .. +3 */
 #pragma unroll
 		for (int u = 0; u < U; u++)
