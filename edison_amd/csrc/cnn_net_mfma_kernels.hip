@@ -102,6 +102,8 @@ extern "C" void ed_set_net_debug_buffer(void *p) { (void)hipMemcpyToSymbol(HIP_S
 #endif
 #define EMM_MAX_THREADS 768 /* 12 waves: 168 VGPRs each (four accumulator tiles + the pipeline's operands need ~150) */
 
+template <int V> struct emm_int { static constexpr int value = V; }; /* a compile-time number as a generic lambda's argument */
+
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
@@ -128,6 +130,20 @@ __device__ __forceinline__ uint32_t emm_pack4(int a0, int a1, int a2, int a3, in
 	const int v2 = emm_med3(a2 >> rs, lo_clamp, 127), v3 = emm_med3(a3 >> rs, lo_clamp, 127);
 	const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x0c0c0400u), p23 = __builtin_amdgcn_perm((uint32_t)v3, (uint32_t)v2, 0x0c0c0400u);
 	return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+}
+
+/* The same four bytes where the planner allows it (ED_RUN_RS_HI; a0..a3 already shifted by rs - 8): sat8(v >> 8) is the high
+ * byte of sat16(v) -- two v_cvt_pk_i16_i32, the lower clamp as two v_pk_max_i16 (lo2: 0 | 0 with a ReLU, -32768 | -32768
+ * without), one v_perm_b32 that picks bytes 1 and 3 of both pairs: 5 instructions for four values instead of 15. */
+__device__ __forceinline__ uint32_t emm_pack4_hi(int a0, int a1, int a2, int a3, uint32_t lo2)
+{
+	typedef short s2 __attribute__((ext_vector_type(2)));
+	s2 p01 = __builtin_amdgcn_cvt_pk_i16(a0, a1), p23 = __builtin_amdgcn_cvt_pk_i16(a2, a3), lo;
+	__builtin_memcpy(&lo, &lo2, 4);
+	p01 = __builtin_elementwise_max(p01, lo); p23 = __builtin_elementwise_max(p23, lo);
+	uint32_t u01, u23;
+	__builtin_memcpy(&u01, &p01, 4); __builtin_memcpy(&u23, &p23, 4);
+	return __builtin_amdgcn_perm(u23, u01, 0x07050301u);
 }
 
 /* i / d and i % d for 0 <= i < 2^21, 0 < d: one float multiply and a one-step correction instead of the ~20-instruction
@@ -260,12 +276,86 @@ __device__ __forceinline__ void emm_keep(v4i (&x)[N])
  * already in registers (res[s * C * NW + c]: a layer with one column-tile group and several row-tile groups fetched them once
  * for all of those), 2 = the A fragments are (res[s * R + r]: one row-tile group, several column-tile groups). */
 #define EMM_RES_MAX 8
-template <int NW, int R, int C, bool FRAG_LDS, int MODE>
-__device__ __forceinline__ void emm_chain(const lds8 *(&fl)[R], const int8_t *(&fg)[R], const lds8 *kp /* &koff[h] */, const lds8 *(&bw)[NW * C],
-                                          int n_ks, const lds8 *(&sp)[R], v16i (&acc)[R * C], const v4i (&res)[EMM_RES_MAX])
+/* AC: the caller's acc[] has AC tiles per row tile (a narrow chain for the last group of an odd tile count fills the first R x C
+ * of the group's array) */
+template <int NW, int R, int C, bool FRAG_LDS, int MODE, int AC>
+__device__ __forceinline__ void emm_chain(const lds8 *const *fl, const int8_t *const *fg, const lds8 *kp /* &koff[h] */, const lds8 *const *bw,
+                                          int n_ks, const lds8 *const *sp, v16i *acc, const v4i (&res)[EMM_RES_MAX])
 {
 	constexpr int NT = R * C * NW, NB = C * NW; /* accumulator tile (r, c, w) is aw[(r * C + c) * NW + w] */
 	v16i aw[NT];
+	const int last = n_ks - 1;
+#if !EMM_SPEC
+	/* The general kernel's n_ks is a run-time number. Its loop is two k-steps long and the operands PING-PONG between two
+	 * register sets, so that "carry the operands into the next step" is no instruction at all (the one-step form below copied
+	 * (R + C NW) fragments per step with v_mov: ~30 moves beside four MFMAs in this kernel). Step 0 stands in front of the
+	 * loop: its MFMAs take a row tile's seeds as their C operand and write the tiles' own registers, so the C NW tiles of
+	 * a row tile share ONE copy of the seeds (reading them "straight into the accumulators" cost 16 v_mov per further tile).
+	 * Same program order as below: the chunk offset of step s+2, the operands of step s+1, the MFMAs of step s. */
+	v16i sd[R];
+#pragma unroll
+	for (int r = 0; r < R; r++)
+#pragma unroll
+		for (int g = 0; g < 4; g++)
+		{
+			const v4i s4 = EMM_LD128(sp[r] + 32 * g);
+			sd[r][4 * g] = s4.x; sd[r][4 * g + 1] = s4.y; sd[r][4 * g + 2] = s4.z; sd[r][4 * g + 3] = s4.w;
+		}
+	int ke = EMM_LD32(kp), ko = EMM_LD32(kp + 8 * (last < 1 ? last : 1)); /* offsets of the next even / odd step to fetch */
+	v4i ae[R], be[NB], ao[R], bo[NB];                                       /* operands of an even / odd step              */
+#pragma unroll
+	for (int r = 0; r < R; r++) ae[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], 0);
+#pragma unroll
+	for (int c = 0; c < NB; c++) be[c] = EMM_LD128(bw[c] + ke);
+	if (EMM_SKIP & 2)
+	{
+#pragma unroll
+		for (int t = 0; t < NT; t++) aw[t] = sd[t / (C * NW)];
+	}
+	else
+	{
+		ke = EMM_LD32(kp + 8 * (2 < n_ks ? 2 : last));
+		if (1 < n_ks) /* uniform */
+		{
+#pragma unroll
+			for (int r = 0; r < R; r++) ao[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], 1);
+#pragma unroll
+			for (int c = 0; c < NB; c++) bo[c] = EMM_LD128(bw[c] + ko);
+		}
+#pragma unroll
+		for (int t = 0; t < NT; t++) aw[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ae[t / (C * NW)], be[t % (C * NW)], sd[t / (C * NW)], 0, 0, 0);
+		int s = 1;
+		for (; s + 1 < n_ks; s += 2) /* steps s (odd set) and s + 1 (even set) */
+		{
+			ko = EMM_LD32(kp + 8 * (s + 2 < n_ks ? s + 2 : last));
+#pragma unroll
+			for (int r = 0; r < R; r++) ae[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], s + 1);
+#pragma unroll
+			for (int c = 0; c < NB; c++) be[c] = EMM_LD128(bw[c] + ke);
+#pragma unroll
+			for (int t = 0; t < NT; t++) aw[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ao[t / (C * NW)], bo[t % (C * NW)], aw[t], 0, 0, 0);
+			ke = EMM_LD32(kp + 8 * (s + 3 < n_ks ? s + 3 : last));
+			if (s + 2 < n_ks) /* uniform: the last step has nothing to fetch (a k-step's operands are R + C * NW KB of LDS traffic) */
+			{
+#pragma unroll
+				for (int r = 0; r < R; r++) ao[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], s + 2);
+#pragma unroll
+				for (int c = 0; c < NB; c++) bo[c] = EMM_LD128(bw[c] + ko);
+			}
+#pragma unroll
+			for (int t = 0; t < NT; t++) aw[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ae[t / (C * NW)], be[t % (C * NW)], aw[t], 0, 0, 0);
+			/* the odd set and the even offset cross the back edge: see emm_keep */
+			asm volatile("" : "+v"(ke));
+			emm_keep(ao);
+			emm_keep(bo);
+		}
+		if (s < n_ks) /* an even count: the last step's operands are in the odd set */
+		{
+#pragma unroll
+			for (int t = 0; t < NT; t++) aw[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ao[t / (C * NW)], bo[t % (C * NW)], aw[t], 0, 0, 0);
+		}
+	}
+#else
 #pragma unroll
 	for (int t = 0; t < NT; t++)
 #pragma unroll
@@ -274,50 +364,6 @@ __device__ __forceinline__ void emm_chain(const lds8 *(&fl)[R], const int8_t *(&
 			const v4i s4 = EMM_LD128(sp[t / (C * NW)] + 32 * g);
 			aw[t][4 * g] = s4.x; aw[t][4 * g + 1] = s4.y; aw[t][4 * g + 2] = s4.z; aw[t][4 * g + 3] = s4.w;
 		}
-	const int last = n_ks - 1;
-#if !EMM_SPEC
-	/* The general kernel's n_ks is a run-time number: the loop is two k-steps long and the operands PING-PONG between two
-	 * register sets -- set 0 holds the even steps, set 1 the odd ones -- so that "carry the operands into the next step" is
-	 * no instruction at all (the one-step form below copied (R + C NW) fragments per step with v_mov: ~30 moves beside four
-	 * MFMAs in this kernel). Same program order as below: the chunk offset of step s+2, the operands of step s+1, the
-	 * MFMAs of step s. */
-	int k0 = EMM_LD32(kp), k1 = EMM_LD32(kp + 8 * (last < 1 ? last : 1));
-	v4i a0[R], b0[NB], a1[R], b1[NB];
-#pragma unroll
-	for (int r = 0; r < R; r++) a0[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], 0);
-#pragma unroll
-	for (int c = 0; c < NB; c++) b0[c] = EMM_LD128(bw[c] + k0);
-	int s = 0;
-	for (; s + 1 < ((EMM_SKIP & 2) ? 0 : n_ks); s += 2)
-	{
-		k0 = EMM_LD32(kp + 8 * (s + 2 < n_ks ? s + 2 : last));
-#pragma unroll
-		for (int r = 0; r < R; r++) a1[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], s + 1);
-#pragma unroll
-		for (int c = 0; c < NB; c++) b1[c] = EMM_LD128(bw[c] + k1);
-#pragma unroll
-		for (int t = 0; t < NT; t++) aw[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[t / (C * NW)], b0[t % (C * NW)], aw[t], 0, 0, 0);
-		k1 = EMM_LD32(kp + 8 * (s + 3 < n_ks ? s + 3 : last));
-		if (s + 2 < n_ks) /* uniform: the last step has nothing to fetch (a k-step's operands are R + C * NW KB of LDS traffic) */
-		{
-#pragma unroll
-			for (int r = 0; r < R; r++) a0[r] = emm_load_a<FRAG_LDS>(fl[r], fg[r], s + 2);
-#pragma unroll
-			for (int c = 0; c < NB; c++) b0[c] = EMM_LD128(bw[c] + k0);
-		}
-#pragma unroll
-		for (int t = 0; t < NT; t++) aw[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1[t / (C * NW)], b1[t % (C * NW)], aw[t], 0, 0, 0);
-		/* set 0 and the odd offset cross the back edge: see emm_keep */
-		asm volatile("" : "+v"(k1));
-		emm_keep(a0);
-		emm_keep(b0);
-	}
-	if (s < ((EMM_SKIP & 2) ? 0 : n_ks)) /* an odd count: the last step's operands are in set 0 */
-	{
-#pragma unroll
-		for (int t = 0; t < NT; t++) aw[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[t / (C * NW)], b0[t % (C * NW)], aw[t], 0, 0, 0);
-	}
-#else
 	int k_cur = EMM_LD32(kp), k_nxt = EMM_LD32(kp + 8 * (last < 1 ? last : 1));
 	v4i a[R], b[NB];
 #pragma unroll
@@ -355,11 +401,12 @@ __device__ __forceinline__ void emm_chain(const lds8 *(&fl)[R], const int8_t *(&
 #pragma unroll
 	for (int u = 0; u < R * C; u++)
 	{
-		acc[u] = aw[u * NW];
+		v16i &m = acc[(u / C) * AC + u % C];
+		m = aw[u * NW];
 #pragma unroll
 		for (int w = 1; w < NW; w++)
 #pragma unroll
-			for (int i = 0; i < 16; i++) acc[u][i] = aw[u * NW + w][i] > acc[u][i] ? aw[u * NW + w][i] : acc[u][i];
+			for (int i = 0; i < 16; i++) m[i] = aw[u * NW + w][i] > m[i] ? aw[u * NW + w][i] : m[i];
 	}
 }
 
@@ -376,6 +423,7 @@ struct emm_mm_args
 	int n_ks, n_rt, n_cols, pix_per_img, col_w;
 	int pitch_x, pitch_y, sh, ph, pw;
 	int o_origin, o_row, oc_pitch, out_c, rs, lo_clamp;
+	int hi, qsh;            /* ED_RUN_RS_HI: requantise through the high byte of sat16(v >> qsh), qsh = rs - 8 (< 0: a left shift) */
 	int small;              /* 16 x 16 x 64 tiles (n_ks / n_rt count those) */
 #if EMM_STAMP
 	unsigned long long *st_, *tl_p;
@@ -476,36 +524,53 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 			}
 			v16i acc[R * C];
 			EMM_ST_T(40)
-			if (a_res) emm_chain<NW, R, C, FRAG_LDS, EMM_SPEC ? 2 : 0>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc, res);
-			else if (b_res) emm_chain<NW, R, C, FRAG_LDS, EMM_SPEC ? 1 : 0>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc, res);
-			else emm_chain<NW, R, C, FRAG_LDS, 0>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc, res);
+			if (a_res) emm_chain<NW, R, C, FRAG_LDS, EMM_SPEC ? 2 : 0, C>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc, res);
+			else if (b_res) emm_chain<NW, R, C, FRAG_LDS, EMM_SPEC ? 1 : 0, C>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc, res);
+			else emm_chain<NW, R, C, FRAG_LDS, 0, C>(fl, fg, A.koff + 4 * h, bw, A.n_ks, sp, acc, res);
 			EMM_ST_T(41)
 			/* lane (column, h) holds rows 32 rt + 8 g + 4 h .. +3 in registers 4g..4g+3. Requantise, clamp, pack four rows
 			 * into a dword with three v_perm_b32; whole groups of 8 rows past C_out are skipped under a uniform branch, the
 			 * store alone is predicated. */
+			const uint32_t lo2 = A.lo_clamp == 0 ? 0u : 0x80008000u;
+			const bool full8 = (A.out_c & 7) == 0; /* uniform: a live group of 8 rows is then wholly below C_out */
+			/* QM: 0 (and 4, with byte stores) shift + clamp per value (emm_pack4), 1 / 2 / 3 through the high byte of sat16 (emm_pack4_hi) with no / a right / a
+			 * left shift in front of it -- five copies of the code under one uniform branch per group, so that none of them
+			 * carries the others' selects and register copies */
+			auto epilogue = [&](auto qm_) __attribute__((always_inline))
+			{
+				constexpr int QM = decltype(qm_)::value;
 #pragma unroll
-			for (int r = 0; r < R; r++)
+				for (int r = 0; r < R; r++)
 #pragma unroll
-				for (int c = 0; c < C; c++)
+					for (int c = 0; c < C; c++)
 #pragma unroll
-					for (int g = 0; g < 4; g++)
-					{
-						if ((EMM_SKIP & 1) || rt0 + r >= A.n_rt || 32 * rts[r] + 8 * g >= A.out_c) continue; /* uniform */
-						const v16i &t = acc[r * C + c];
-						const int r0 = 32 * rts[r] + 8 * g + 4 * h;
-						const uint32_t d = emm_pack4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3], A.rs, A.lo_clamp);
-						if ((A.out_c & 3) == 0)
+						for (int g = 0; g < 4; g++)
 						{
-							if (live[c] && r0 < A.out_c) EMM_ST32(op[c] + r0, d);
+							if ((EMM_SKIP & 1) || rt0 + r >= A.n_rt || 32 * rts[r] + 8 * g >= A.out_c) continue; /* uniform */
+							const v16i &t = acc[r * C + c];
+							const int r0 = 32 * rts[r] + 8 * g + 4 * h;
+							int a0 = t[4 * g], a1 = t[4 * g + 1], a2 = t[4 * g + 2], a3 = t[4 * g + 3];
+							if (QM == 2) { a0 >>= A.qsh; a1 >>= A.qsh; a2 >>= A.qsh; a3 >>= A.qsh; }
+							if (QM == 3) { a0 = (int)((uint32_t)a0 << -A.qsh); a1 = (int)((uint32_t)a1 << -A.qsh); a2 = (int)((uint32_t)a2 << -A.qsh); a3 = (int)((uint32_t)a3 << -A.qsh); }
+							const uint32_t d = (QM == 0 || QM == 4) ? emm_pack4(a0, a1, a2, a3, A.rs, A.lo_clamp) : emm_pack4_hi(a0, a1, a2, a3, lo2);
+							if (QM != 4)
+							{
+								if (live[c] && (full8 || r0 < A.out_c)) EMM_ST32(op[c] + r0, d);
+							}
+							else if (live[c]) /* a C_out that is no multiple of 4: byte stores, in a copy of their own (they are the larger half of it) */
+							{
+								if (r0 < A.out_c) op[c][r0] = (int8_t)d;
+								if (r0 + 1 < A.out_c) op[c][r0 + 1] = (int8_t)(d >> 8);
+								if (r0 + 2 < A.out_c) op[c][r0 + 2] = (int8_t)(d >> 16);
+								if (r0 + 3 < A.out_c) op[c][r0 + 3] = (int8_t)(d >> 24);
+							}
 						}
-						else if (live[c])
-						{
-							if (r0 < A.out_c) op[c][r0] = (int8_t)d;
-							if (r0 + 1 < A.out_c) op[c][r0 + 1] = (int8_t)(d >> 8);
-							if (r0 + 2 < A.out_c) op[c][r0 + 2] = (int8_t)(d >> 16);
-							if (r0 + 3 < A.out_c) op[c][r0 + 3] = (int8_t)(d >> 24);
-						}
-					}
+			};
+			if ((A.out_c & 3) != 0) epilogue(emm_int<4>());
+			else if (!A.hi) epilogue(emm_int<0>());
+			else if (A.qsh == 0) epilogue(emm_int<1>());
+			else if (A.qsh > 0) epilogue(emm_int<2>());
+			else epilogue(emm_int<3>());
 			EMM_ST_T(42)
 		}
 	}
@@ -618,7 +683,15 @@ __device__ __forceinline__ void emm_layer_small(const emm_mm_args &A, int lane)
 		{
 			const int r0 = 16 * rts[u] + 4 * kq;
 			if ((EMM_SKIP & 1) || rt0 + u >= A.n_rt) continue; /* uniform */
-			const uint32_t d = emm_pack4(aw[u].x, aw[u].y, aw[u].z, aw[u].w, A.rs, A.lo_clamp);
+			uint32_t d;
+			if (A.hi) /* uniform */
+			{
+				v4i t = aw[u];
+				if (A.qsh > 0) { t.x >>= A.qsh; t.y >>= A.qsh; t.z >>= A.qsh; t.w >>= A.qsh; }
+				else if (A.qsh < 0) { t.x = (int)((uint32_t)t.x << -A.qsh); t.y = (int)((uint32_t)t.y << -A.qsh); t.z = (int)((uint32_t)t.z << -A.qsh); t.w = (int)((uint32_t)t.w << -A.qsh); }
+				d = emm_pack4_hi(t.x, t.y, t.z, t.w, A.lo_clamp == 0 ? 0u : 0x80008000u);
+			}
+			else d = emm_pack4(aw[u].x, aw[u].y, aw[u].z, aw[u].w, A.rs, A.lo_clamp);
 			if ((A.out_c & 3) == 0)
 			{
 				if (live && r0 < A.out_c) EMM_ST32(op + r0, d);
@@ -888,7 +961,8 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 				A.pitch_x = R.pitch_x; A.pitch_y = R.pitch_y; A.sh = R.sh;
 				A.ph = R.ph; A.pw = R.pw;
 				A.small = R.small;
-				A.o_origin = R.o_origin; A.o_row = R.o_row; A.oc_pitch = R.oc_pitch; A.out_c = R.out_c; A.rs = R.rs; A.lo_clamp = R.lo_clamp;
+				A.o_origin = R.o_origin; A.o_row = R.o_row; A.oc_pitch = R.oc_pitch; A.out_c = R.out_c; A.rs = R.rs & ED_RUN_RS_MASK; A.lo_clamp = R.lo_clamp;
+				A.hi = (R.rs & ED_RUN_RS_HI) != 0; A.qsh = (R.rs & ED_RUN_RS_MASK) - 8;
 #if EMM_STAMP
 				A.st_ = stamp_; A.tl_p = &tl_;
 #endif

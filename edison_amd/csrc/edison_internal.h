@@ -299,6 +299,10 @@ typedef struct {
  * reads with two scalar loads (the kernel used to derive it from ed_net_layer_t + ed_mm_layer_t + the consumer's record:
  * a chain of dependent scalar loads and ~100 scalar instructions per layer and input). */
 enum { ED_RUN_SKIP = 0, ED_RUN_MM = 1, ED_RUN_POOL4 = 2, ED_RUN_POOL1 = 3, ED_RUN_SOFTMAX = 4 };
+/* ed_mm_run_t.rs: the planner found that sat8(v >> rs) may be taken as the high byte of sat16(v >> (rs - 8)) -- always for
+ * rs >= 8, for rs < 8 when no accumulator of the layer can leave 32 bits under the left shift (model_net_mm.c) */
+#define ED_RUN_RS_MASK 0xff
+#define ED_RUN_RS_HI 0x100
 typedef struct {
 	int32_t kind;               /* ED_RUN_*                                                                            */
 	int32_t zero_border;        /* 1: the consumer wants a zero border: clear the output images first                  */
@@ -309,7 +313,7 @@ typedef struct {
 	int32_t pitch_x, pitch_y, sh, ph, pw; /* B addressing; rows per output row; fused pooling window (1x1: none)        */
 	int32_t n_ks, n_rt, frag_off, seed_off, koff_off, col_off;
 	int32_t pix_per_img, col_w; /* stored pixels per image, per row                                                    */
-	int32_t out_c, rs, lo_clamp;
+	int32_t out_c, rs, lo_clamp; /* rs: the output shift in the low byte (ED_RUN_RS_MASK) | ED_RUN_RS_HI                  */
 	int32_t in_n;               /* Softmax: classes                                                                    */
 	int32_t small;              /* 1: the 16 x 16 x 64 tiles (n_ks / n_rt then count those)                            */
 	int32_t in_off, o_off;      /* where the layer's input / output images start inside the wave's activation region: the

@@ -311,6 +311,8 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 	int8_t *fb = (int8_t *)calloc(frag_bytes + 16, 1);
 	int32_t *sb = (int32_t *)calloc((size_t)n_seeds + 4, sizeof(int32_t));
 	if (!fb || !sb) { free(fb); free(sb); return EDISON_E_NO_MEMORY; }
+	int64_t acc_bound[ED_NET_MAX_LAYERS]; /* the largest |accumulator| a layer can reach, for the choice of its requantisation (ED_RUN_RS_HI) */
+	memset(acc_bound, 0, sizeof(acc_bound));
 	for (int i = 0; i < n_layers; i++)
 	{
 		const ed_net_layer_t *L = &plan->L[i];
@@ -323,6 +325,14 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		const int8_t *w = payload + r.v[9], *bias = payload + r.v[10]; /* OHWI / [out][in]: row o = kh segments of seg bytes */
 		int8_t *wt = NULL;
 		int seg = kw * in_c, n_rows = L->out_c;
+		for (int o = 0; o < L->out_c; o++) /* |sum x w + seed| <= 128 sum |w| + |seed| */
+		{
+			int64_t sw = 0;
+			for (int q = 0; q < kh * seg; q++) sw += w[(size_t)o * kh * seg + q] < 0 ? -(int64_t)w[(size_t)o * kh * seg + q] : w[(size_t)o * kh * seg + q];
+			const int64_t sd = (int64_t)(int32_t)((uint32_t)(int32_t)bias[o] << r.v[6]) + (int64_t)((1u << r.v[7]) >> 1);
+			const int64_t bd = 128 * sw + (sd < 0 ? -sd : sd);
+			if (bd > acc_bound[i]) acc_bound[i] = bd;
+		}
 		if (M->toep)
 		{
 			/* the Toeplitz matrix, in the layout the packing below expects: [row = x * C_out + oc][ky][q < rowb] */
@@ -457,6 +467,11 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 		R->pix_per_img = dense ? 1 : st_h * (M->toep ? 1 : st_w); R->col_w = dense || M->toep ? 1 : st_w;
 		R->out_c = M->toep ? L->out_w * L->out_c : L->out_c; /* rows of the GEMM */
 		R->rs = L->rs; R->lo_clamp = L->relu ? 0 : -128;
+		/* sat8(v >> rs) is the HIGH byte of sat16(v >> (rs - 8)) (arithmetic shifts compose, and saturating to 16 bits commutes
+		 * with dropping 8 more): two v_cvt_pk_i16_i32 and one v_perm_b32 per four values instead of four shift / clamp pairs.
+		 * For rs < 8 the inner shift goes LEFT, which is exact only while v << (8 - rs) stays inside 32 bits: decided here from
+		 * the layer's own weights and seeds. */
+		if (M->mm && L->rs >= 0 && L->rs <= 31 && (L->rs >= 8 || (acc_bound[i] << (8 - L->rs)) < ((int64_t)1 << 31))) R->rs |= ED_RUN_RS_HI;
 		R->in_n = L->in_n;
 		R->in_off = in_off; R->o_off = o_off;
 		in_off = o_off; /* the consumer reads where this layer stored */

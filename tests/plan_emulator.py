@@ -174,7 +174,7 @@ def run(plan, x):
                         B = S.rd((base + ko)[:, None] + np.arange(16)[None, :]).astype(np.int64).reshape(-1)
                         acc = seeds + A @ B
                         best = acc if best is None else np.maximum(best, acc)
-                    out = np.clip(best >> R.rs, R.lo_clamp, 127)[:R.out_c]
+                    out = np.clip(best >> (R.rs & 0xff), R.lo_clamp, 127)[:R.out_c]
                     S.wr(o + b * R.o_img + ooff + np.arange(R.out_c), out)
             elif R.kind in (RUN_POOL4, RUN_POOL1):
                 L = plan.PL[li]
