@@ -36,7 +36,7 @@
 /* ---- lab knobs: only a lab build (ED_LAB, tools/lab/mkvariant.py) may set them; the product build has none, and
  * tests/test_host_cpu.py checks the values below against what edison_amd/build.py compiles. (The run-time compiler of
  * edison_net_specialize defines EMM_JIT / EMM_SPEC / EMM_SPEC_HEADER -- modes, not knobs -- and never ED_LAB.) */
-#if !defined(ED_LAB) && (defined(EMM_STAMP) || defined(EMM_SKIP) || defined(EMM_PB) || defined(EMM_PRIO))
+#if !defined(ED_LAB) && (defined(EMM_STAMP) || defined(EMM_SKIP) || defined(EMM_PB) || defined(EMM_PRIO) || defined(EMM_NO_HI))
 #error "EMM_* lab knob defined without ED_LAB (tools/lab/mkvariant.py builds lab variants)"
 #endif
 #ifndef EMM_JIT
@@ -74,6 +74,10 @@ extern "C" void ed_set_net_debug_buffer(void *p) { (void)hipMemcpyToSymbol(HIP_S
 #endif
 /* -DEMM_SPEC=1 -DEMM_SPEC_HEADER='"file"': a kernel for ONE graph -- the plans' scalars and layer records come from the
  * generated header (net_spec.c) as C++ constants, the layer loop is unrolled and the per-layer bookkeeping folds away */
+/* lab: 1 = every layer requantises with a shift and two clamps per value (A/B of the high-byte path, ED_RUN_RS_HI) */
+#ifndef EMM_NO_HI
+#define EMM_NO_HI 0
+#endif
 #ifndef EMM_SPEC
 #define EMM_SPEC 0
 #endif
@@ -170,6 +174,21 @@ __device__ __forceinline__ int emm_wave_max(int v)
 	const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16), r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
 	const int m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
 	return m01 > m23 ? m01 : m23;
+}
+/* the same inside every row of 16 lanes (four DPP steps, every lane of a row ends with its row's result): up to four images side by side */
+__device__ __forceinline__ int emm_row_max(int v)
+{
+	int t;
+	t = EMM_DPP(v, 0xB1); v = t > v ? t : v;
+	t = EMM_DPP(v, 0x4E); v = t > v ? t : v;
+	t = EMM_DPP(v, 0x141); v = t > v ? t : v;
+	t = EMM_DPP(v, 0x140); v = t > v ? t : v;
+	return v;
+}
+__device__ __forceinline__ int emm_row_add(int v)
+{
+	v += EMM_DPP(v, 0xB1); v += EMM_DPP(v, 0x4E); v += EMM_DPP(v, 0x141); v += EMM_DPP(v, 0x140);
+	return v;
 }
 __device__ __forceinline__ int emm_wave_add(int v)
 {
@@ -962,7 +981,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 				A.ph = R.ph; A.pw = R.pw;
 				A.small = R.small;
 				A.o_origin = R.o_origin; A.o_row = R.o_row; A.oc_pitch = R.oc_pitch; A.out_c = R.out_c; A.rs = R.rs & ED_RUN_RS_MASK; A.lo_clamp = R.lo_clamp;
-				A.hi = (R.rs & ED_RUN_RS_HI) != 0; A.qsh = (R.rs & ED_RUN_RS_MASK) - 8;
+				A.hi = !EMM_NO_HI && (R.rs & ED_RUN_RS_HI) != 0; A.qsh = (R.rs & ED_RUN_RS_MASK) - 8;
 #if EMM_STAMP
 				A.st_ = stamp_; A.tl_p = &tl_;
 #endif
@@ -1023,7 +1042,21 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 			else /* softmax: arm_softmax_q7.c:215-260 */
 			{
 				const int in_n = (EMM_SKIP & 16) ? 0 : R.in_n;
-				if (in_n <= 64)
+				if (in_n <= 16)
+				{
+					/* at most 16 classes: image b in lane row b (a wave takes at most four images), one lane per class; maximum and
+					 * sum are reductions inside the rows (DPP only), all images of the batch in one pass */
+					const int b = lane >> 4, i = lane & 15;
+					const bool in = i < in_n && b < nb;
+					const int x = in ? (int)a[b * R.in_img + i] : -128;
+					const int base = emm_row_max(x) - 8;
+					int sum = emm_row_add(in ? 1 << emm_med3(x - base, 0, 7) : 0);
+					sum = sum < 1 ? 1 : sum; /* a row without an image */
+					int output_base, rem;
+					emm_divmod(1 << 20, sum, __builtin_amdgcn_rcpf((float)sum), output_base, rem);
+					if (in) o[b * R.o_img + i] = (int8_t)emm_med3(output_base >> emm_med3(13 + base - x, 0, 31), -128, 127);
+				}
+				else if (in_n <= 64)
 				{
 					/* one lane per class, one image after the other: maximum and sum are wave reductions, the division
 					 * happens once, in float with a one-step correction (2^20 < 2^24) */
@@ -1056,31 +1089,52 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 			/* outputs (the layouts of the logits layer's and the last layer's outputs are compact); what this pass stored is
 			 * the output of layer li_out: the fused MaxPool's when there is one */
 			const int li_out = (EMM_SKIP & 16) ? -1 : R.li_out;
-			if (li_out == logits_layer && logits)
-				for (int b = 0; b < nb; b++)
-					for (int i = lane; i < out_n; i += 64) logits[(u0 + b) * out_n + i] = o[b * R.o_img + i];
-			if (li_out == n_layers - 1)
+			if (out_n <= 16)
 			{
-				if (has_softmax && softmax)
-					for (int b = 0; b < nb; b++)
-						for (int i = lane; i < out_n; i += 64) softmax[(u0 + b) * out_n + i] = o[b * R.o_img + i];
-				if (argmax && out_n <= 64)
+				/* at most 16 outputs: image b in lane row b, all images of the batch in one pass (see the Softmax above) */
+				const int b = lane >> 4, i = lane & 15;
+				const bool in = i < out_n && b < nb;
+				if (li_out == logits_layer && logits && in) logits[(u0 + b) * out_n + i] = o[b * R.o_img + i];
+				if (li_out == n_layers - 1)
 				{
-					/* first maximum: the largest (value, 63 - index) pair of the wave */
-					for (int b = 0; b < nb; b++)
+					if (has_softmax && softmax && in) softmax[(u0 + b) * out_n + i] = o[b * R.o_img + i];
+					if (argmax)
 					{
-						const int key = lane < out_n ? (((int)o[b * R.o_img + lane] + 128) << 6) | (63 - lane) : -1;
-						const int best = 63 - (emm_wave_max(key) & 63);
-						if (lane == 0) argmax[u0 + b] = best;
+						/* first maximum: the largest (value, 63 - index) pair of the row */
+						const int key = in ? (((int)o[b * R.o_img + i] + 128) << 6) | (63 - i) : -1;
+						const int best = 63 - (emm_row_max(key) & 63);
+						if (i == 0 && b < nb) argmax[u0 + b] = best;
 					}
 				}
-				else if (argmax && lane < nb)
+			}
+			else
+			{
+				if (li_out == logits_layer && logits)
+					for (int b = 0; b < nb; b++)
+						for (int i = lane; i < out_n; i += 64) logits[(u0 + b) * out_n + i] = o[b * R.o_img + i];
+				if (li_out == n_layers - 1)
 				{
-					const lds8 *v = o + lane * R.o_img;
-					int best = 0, mx = -129;
-					for (int i = 0; i < out_n; i++)
-						if (v[i] > mx) { mx = v[i]; best = i; }
-					argmax[u0 + lane] = best;
+					if (has_softmax && softmax)
+						for (int b = 0; b < nb; b++)
+							for (int i = lane; i < out_n; i += 64) softmax[(u0 + b) * out_n + i] = o[b * R.o_img + i];
+					if (argmax && out_n <= 64)
+					{
+						/* first maximum: the largest (value, 63 - index) pair of the wave */
+						for (int b = 0; b < nb; b++)
+						{
+							const int key = lane < out_n ? (((int)o[b * R.o_img + lane] + 128) << 6) | (63 - lane) : -1;
+							const int best = 63 - (emm_wave_max(key) & 63);
+							if (lane == 0) argmax[u0 + b] = best;
+						}
+					}
+					else if (argmax && lane < nb)
+					{
+						const lds8 *v = o + lane * R.o_img;
+						int best = 0, mx = -129;
+						for (int i = 0; i < out_n; i++)
+							if (v[i] > mx) { mx = v[i]; best = i; }
+						argmax[u0 + lane] = best;
+					}
 				}
 			}
 		}

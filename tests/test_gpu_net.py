@@ -220,3 +220,38 @@ def test_fused_pool_as_the_last_layer_and_multi_unit_groups(built_lib):
         if layers[-1]["type"] == 4:
             assert np.array_equal(out["softmax"], ref["softmax"]), name
     c.close()
+
+
+def test_every_requantisation_mode_of_the_matrix_core_kernel(built_lib):
+    """The matrix-core kernel requantises through the high byte of sat16(v >> (rs - 8)) where the planner proved that exact
+    (model_net_mm.c: ED_RUN_RS_HI) -- with no shift (rs = 8), a right shift (rs > 8) or a left one (rs < 8, small weights) -- and with a
+    shift and two clamps per value otherwise (rs < 8 under large weights; a C_out that is no multiple of 4 stores bytes); with and
+    without a ReLU, on 32 x 32 and on 16 x 16 tiles, with accumulators driven to both rails. All bit-equal to oracle/net_ref.py."""
+    from edison_amd import nnom_import
+    from edison_amd.context import Context
+    from oracle import net_ref
+    rng = np.random.default_rng(12)
+
+    def conv(oc, k, c, rs, wmax, relu, bl=0):
+        return dict(type=1, out_ch=oc, kh=k, kw=k, sh=1, sw=1, w=rng.integers(-wmax, wmax + 1, oc * k * k * c).astype(np.int8),
+                    b=rng.integers(-100, 101, oc).astype(np.int8), out_rshift=rs, bias_lshift=bl, relu=relu, same=0)
+
+    c = Context(0, model_path=None)
+    n_cases = 0
+    for rs in (0, 2, 5, 7, 8, 9, 12, 15):
+        for wmax in (2, 127):
+            for relu in (0, 1):
+                for oc in (8, 6):                      # 6: byte stores
+                    # layer 1 on 32 x 32 tiles (5 x 3 pixels x 2 inputs per wave), layer 2 on 16 x 16 tiles (3 x 1 pixels)
+                    layers = [conv(64, 3, 16, 9, 60, 1, 2), conv(32, 3, 64, rs, wmax, relu, 3), conv(oc, 3, 32, rs, wmax, relu, 1)]
+                    blob = nnom_import.build_blob((9, 7, 16), [dict(L) for L in layers])
+                    c.load_model_bytes(blob)
+                    assert c.net_info()["accelerated"] == 2, (rs, wmax, relu, oc)
+                    x = rng.integers(-128, 128, (45, 9 * 7 * 16)).astype(np.int8)
+                    x[:4] = np.array([127, -128, 127, -128], np.int8)[:, None]     # rails: saturation on both sides
+                    ref, out = net_ref.run(blob, x), c.net(x)
+                    assert np.array_equal(out["logits"], ref["logits"]), (rs, wmax, relu, oc)
+                    assert np.array_equal(out["argmax"], ref["argmax"]), (rs, wmax, relu, oc)
+                    n_cases += 1
+    assert n_cases == 64
+    c.close()

@@ -87,6 +87,35 @@ def test_plan_walk_on_random_graphs(built_lib):
     assert toep >= 5 and small >= 5, (toep, gap, small)      # the sample reaches the planner's special forms
 
 
+def test_high_byte_requantisation_is_offered_only_where_it_is_exact(built_lib):
+    """ed_mm_run_t.rs carries ED_RUN_RS_HI (0x100) when sat8(v >> rs) may be taken as the high byte of sat16(v >> (rs - 8)): always for
+    rs >= 8; for rs < 8 the inner shift goes left, and the planner allows it only when 128 * sum|w| + |seed| of the layer's worst
+    output channel stays inside 32 bits after it. The emulator walks either plan with the plain formula."""
+    import plan_emulator
+    from edison_amd import nnom_import
+    rng = np.random.default_rng(11)
+
+    def conv(oc, k, c, rs, wmax, bl=0):
+        return dict(type=1, out_ch=oc, kh=k, kw=k, sh=1, sw=1, w=rng.choice([-wmax, wmax], oc * k * k * c).astype(np.int8),
+                    b=np.full(oc, 100, np.int8), out_rshift=rs, bias_lshift=bl, relu=1, same=0)
+
+    seen = set()
+    for rs, wmax, bl in ((8, 127, 0), (12, 127, 0), (7, 10, 0), (2, 1, 0), (7, 127, 0), (1, 127, 0), (0, 127, 0), (3, 127, 0), (6, 127, 23), (7, 127, 23), (4, 3, 22),
+                         (8, 127, 23)):
+        # 3 x 3 x 64 taps of +-wmax and a bias of 100 << bl: the bound is 128 * 576 * wmax + (100 << bl) + the rounding constant
+        layers = [conv(64, 3, 16, 9, 50), conv(8, 3, 64, rs, wmax, bl)]
+        blob = nnom_import.build_blob((9, 7, 16), [dict(L) for L in layers])
+        plan = plan_emulator.Plan(blob)
+        bound = 128 * 576 * wmax + (100 << bl) + (1 << rs >> 1)
+        exact = rs >= 8 or (bound << (8 - rs)) < 2 ** 31
+        seen.add((rs >= 8, exact))
+        assert (plan.R[1].rs & 0xff) == rs and bool(plan.R[1].rs & 0x100) == exact, (rs, wmax, bl, hex(plan.R[1].rs))
+        assert plan.R[0].rs == 9 | 0x100
+        x = rng.integers(-128, 128, (2, 9 * 7 * 16)).astype(np.int8)
+        _check(blob, x, (rs, wmax, bl))
+    assert seen == {(True, True), (False, True), (False, False)}
+
+
 def test_planners_under_address_and_ub_sanitizers(built_lib):
     """tools/verify/asan_planner.sh: the library's host C (planners, kws_conv model parser, the table builders of all four MFCC
     variants) rebuilt with gcc -fsanitize=address,undefined and run on the shipped graph, the seven fixture graphs, 80 random
