@@ -766,7 +766,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 	extern __shared__ __attribute__((aligned(16))) int8_t emm_lds_generic[];
 	lds8 *emm_lds = (lds8 *)emm_lds_generic;
 	EMM_CONST int n_layers = EMM_NL_EXPR, batch = EMM_MF(batch), buf_bytes = EMM_MF(buf_bytes);
-	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #if EMM_PRIO == 6 /* lab: a fixed priority per wave of a SIMD */
 	if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1); else if ((wave >> 2) >= 2) __builtin_amdgcn_s_setprio(2);
 #endif
@@ -815,10 +815,17 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 	{
 #pragma unroll
 		for (int b = 0; b < EMM_PB; b++) /* a slot past the end of the input fetches the last image again: it is never written out */
-			if (b < batch) emm_load_image(in + (u_first + b < n ? u_first + b : n - 1) * in_stride, EMM_PF(in_n), lane, pre[b]);
+			if (b < batch) emm_load_image(in + (u_first + b < n ? u_first + b : n - 1) * in_stride, EMM_PF(in_n), lane0, pre[b]);
 	}
 	for (int64_t u0 = u_first; u0 < n; u0 += u_step)
 	{
+		/* The lane number is made opaque once per batch and once per layer: everything a stage derives from it (addresses into
+		 * its tables and images, column numbers, predicates) is then worked out where it is used. Left to itself the optimiser
+		 * hoists those loop-invariant per-lane values of EVERY stage and tile shape in front of the batch loop, keeps them
+		 * alive across it, runs out of registers and spills -- and a scratch reload waits on vmcnt, i.e. for the NEXT batch's
+		 * prefetch that was put in flight just before it: the wave then sits out a memory latency per batch after all. */
+		int lane = lane0;
+		asm volatile("" : "+v"(lane));
 		const int nb = batch == 1 ? 1 : (int)((n - u0) < batch ? (n - u0) : batch);
 		EMM_ST(47)
 		/* ---- the inputs into layer 0's layout */
@@ -918,12 +925,14 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 			 * scalar loads and ~100 scalar instructions per layer and input) */
 			EMM_PR(li, n_layers)
 			const ed_mm_run_t R = EMM_RUN(li);
+			int lane_l = lane0; /* opaque per layer: see the top of the batch loop */
+			asm volatile("" : "+v"(lane_l));
 			if (R.kind == ED_RUN_SKIP) continue; /* a MaxPool taken in the epilogue of the layer in front of it */
 			const lds8 *a = slice + R.in_off;
 			lds8 *o = slice + R.o_off;
 			if (R.zero_border) /* uniform: the consumer wants a zero border */
 			{
-				emm_zero(o, batch * R.o_img, lane);
+				emm_zero(o, batch * R.o_img, lane_l);
 				emm_sync();
 			}
 			if (R.kind == ED_RUN_MM)
@@ -938,7 +947,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 					if (R.xtab_off >= 0)
 					{
 						const lds8 *xt = reinterpret_cast<const lds8 *>(xtab_l + 2 * R.xtab_off);
-						for (int i = lane; i < R.rec_per_img; i += 64)
+						for (int i = lane_l; i < R.rec_per_img; i += 64)
 						{
 							const int w0_ = EMM_LD32(xt + 8 * i), doff = EMM_LD32(xt + 8 * i + 4);
 							const int soff0 = w0_ & 0xffffff, keep = w0_ >> 24;
@@ -954,7 +963,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 						const int dense = L.type == ED_NET_DENSE, out_w = dense ? 1 : L.out_w;
 						const int in_c = dense ? L.in_n : L.in_c, seg = (dense ? 1 : L.kw) * in_c, sw = dense ? 1 : L.sw;
 						const float inv_rec = __builtin_amdgcn_rcpf((float)R.rec_per_img), inv_row = __builtin_amdgcn_rcpf((float)(out_w * ML.cpr)), inv_cpr = __builtin_amdgcn_rcpf((float)ML.cpr);
-						for (int i = lane; i < nb * R.rec_per_img; i += 64)
+						for (int i = lane_l; i < nb * R.rec_per_img; i += 64)
 						{
 							int b, e, r, e2, xo, j;
 							emm_divmod(i, R.rec_per_img, inv_rec, b, e); emm_divmod(e, out_w * ML.cpr, inv_row, r, e2); emm_divmod(e2, ML.cpr, inv_cpr, xo, j);
@@ -985,7 +994,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 #if EMM_STAMP
 				A.st_ = stamp_; A.tl_p = &tl_;
 #endif
-				emm_layer_dispatch<FRAG_LDS>(A, lane); /* windows: 1, 2 or 4 (model_net_mm.c fuses nothing else) */
+				emm_layer_dispatch<FRAG_LDS>(A, lane_l); /* windows: 1, 2 or 4 (model_net_mm.c fuses nothing else) */
 			}
 			else if (R.kind == ED_RUN_POOL4)
 			{
@@ -993,7 +1002,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 				/* four channels per thread: byte-wise signed maximum of dwords */
 				const int c4n = L.in_c >> 2, per_img = L.out_h * L.out_w * c4n;
 				const float inv_img = __builtin_amdgcn_rcpf((float)per_img), inv_c4 = __builtin_amdgcn_rcpf((float)c4n), inv_ow = __builtin_amdgcn_rcpf((float)L.out_w);
-				for (int i = lane; i < nb * per_img; i += 64)
+				for (int i = lane_l; i < nb * per_img; i += 64)
 				{
 					int b, e, pix, c4, y, x;
 					emm_divmod(i, per_img, inv_img, b, e); emm_divmod(e, c4n, inv_c4, pix, c4); emm_divmod(pix, L.out_w, inv_ow, y, x);
@@ -1019,7 +1028,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 			{
 				const ed_net_layer_t L = EMM_NETL(li);
 				const int per_img = L.out_n;
-				for (int i = lane; i < nb * per_img; i += 64)
+				for (int i = lane_l; i < nb * per_img; i += 64)
 				{
 					const int b = i / per_img, e = i - b * per_img;
 					const int pix = e / L.in_c, c = e - pix * L.in_c, y = pix / L.out_w, x = pix - y * L.out_w;
@@ -1044,9 +1053,9 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 				const int in_n = (EMM_SKIP & 16) ? 0 : R.in_n;
 				if (in_n <= 16)
 				{
-					/* at most 16 classes: image b in lane row b (a wave takes at most four images), one lane per class; maximum and
+					/* at most 16 classes: image b in lane_l row b (a wave takes at most four images), one lane_l per class; maximum and
 					 * sum are reductions inside the rows (DPP only), all images of the batch in one pass */
-					const int b = lane >> 4, i = lane & 15;
+					const int b = lane_l >> 4, i = lane_l & 15;
 					const bool in = i < in_n && b < nb;
 					const int x = in ? (int)a[b * R.in_img + i] : -128;
 					const int base = emm_row_max(x) - 8;
@@ -1058,23 +1067,23 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 				}
 				else if (in_n <= 64)
 				{
-					/* one lane per class, one image after the other: maximum and sum are wave reductions, the division
+					/* one lane_l per class, one image after the other: maximum and sum are wave reductions, the division
 					 * happens once, in float with a one-step correction (2^20 < 2^24) */
 					for (int b = 0; b < nb; b++)
 					{
-						const bool in = lane < in_n;
-						const int x = in ? (int)a[b * R.in_img + lane] : -128;
+						const bool in = lane_l < in_n;
+						const int x = in ? (int)a[b * R.in_img + lane_l] : -128;
 						const int base = emm_wave_max(x) - 8;
 						const int sum = emm_wave_add(in ? 1 << emm_med3(x - base, 0, 7) : 0);
 						int output_base, rem;
 						emm_divmod(1 << 20, sum, __builtin_amdgcn_rcpf((float)sum), output_base, rem);
-						if (in) o[b * R.o_img + lane] = (int8_t)emm_med3(output_base >> emm_med3(13 + base - x, 0, 31), -128, 127);
+						if (in) o[b * R.o_img + lane_l] = (int8_t)emm_med3(output_base >> emm_med3(13 + base - x, 0, 31), -128, 127);
 					}
 				}
-				else if (lane < nb)
+				else if (lane_l < nb)
 				{
-					const lds8 *v = a + lane * R.in_img;
-					lds8 *w = o + lane * R.o_img;
+					const lds8 *v = a + lane_l * R.in_img;
+					lds8 *w = o + lane_l * R.o_img;
 					int base = -128;
 					for (int i = 0; i < in_n; i++) base = v[i] > base ? v[i] : base;
 					base -= 8;
@@ -1091,8 +1100,8 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 			const int li_out = (EMM_SKIP & 16) ? -1 : R.li_out;
 			if (out_n <= 16)
 			{
-				/* at most 16 outputs: image b in lane row b, all images of the batch in one pass (see the Softmax above) */
-				const int b = lane >> 4, i = lane & 15;
+				/* at most 16 outputs: image b in lane_l row b, all images of the batch in one pass (see the Softmax above) */
+				const int b = lane_l >> 4, i = lane_l & 15;
 				const bool in = i < out_n && b < nb;
 				if (li_out == logits_layer && logits && in) logits[(u0 + b) * out_n + i] = o[b * R.o_img + i];
 				if (li_out == n_layers - 1)
@@ -1111,29 +1120,29 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 			{
 				if (li_out == logits_layer && logits)
 					for (int b = 0; b < nb; b++)
-						for (int i = lane; i < out_n; i += 64) logits[(u0 + b) * out_n + i] = o[b * R.o_img + i];
+						for (int i = lane_l; i < out_n; i += 64) logits[(u0 + b) * out_n + i] = o[b * R.o_img + i];
 				if (li_out == n_layers - 1)
 				{
 					if (has_softmax && softmax)
 						for (int b = 0; b < nb; b++)
-							for (int i = lane; i < out_n; i += 64) softmax[(u0 + b) * out_n + i] = o[b * R.o_img + i];
+							for (int i = lane_l; i < out_n; i += 64) softmax[(u0 + b) * out_n + i] = o[b * R.o_img + i];
 					if (argmax && out_n <= 64)
 					{
 						/* first maximum: the largest (value, 63 - index) pair of the wave */
 						for (int b = 0; b < nb; b++)
 						{
-							const int key = lane < out_n ? (((int)o[b * R.o_img + lane] + 128) << 6) | (63 - lane) : -1;
+							const int key = lane_l < out_n ? (((int)o[b * R.o_img + lane_l] + 128) << 6) | (63 - lane_l) : -1;
 							const int best = 63 - (emm_wave_max(key) & 63);
-							if (lane == 0) argmax[u0 + b] = best;
+							if (lane_l == 0) argmax[u0 + b] = best;
 						}
 					}
-					else if (argmax && lane < nb)
+					else if (argmax && lane_l < nb)
 					{
-						const lds8 *v = o + lane * R.o_img;
+						const lds8 *v = o + lane_l * R.o_img;
 						int best = 0, mx = -129;
 						for (int i = 0; i < out_n; i++)
 							if (v[i] > mx) { mx = v[i]; best = i; }
-						argmax[u0 + lane] = best;
+						argmax[u0 + lane_l] = best;
 					}
 				}
 			}
@@ -1147,7 +1156,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 	if (done_flag && blockIdx.x == 0 && wave == 0)
 	{
 		__threadfence_system();
-		if (lane == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		if (lane0 == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 #if EMM_STAMP
 	if (g_emm_dbg && threadIdx.x == 0 && blockIdx.x == 0) for (int i = 0; i < 48; i++) g_emm_dbg[i] = stamp_[i];
