@@ -36,7 +36,7 @@
 /* ---- lab knobs: only a lab build (ED_LAB, tools/lab/mkvariant.py) may set them; the product build has none, and
  * tests/test_host_cpu.py checks the values below against what edison_amd/build.py compiles. (The run-time compiler of
  * edison_net_specialize defines EMM_JIT / EMM_SPEC / EMM_SPEC_HEADER -- modes, not knobs -- and never ED_LAB.) */
-#if !defined(ED_LAB) && (defined(EMM_STAMP) || defined(EMM_SKIP) || defined(EMM_PB) || defined(EMM_PRIO) || defined(EMM_NO_HI))
+#if !defined(ED_LAB) && (defined(EMM_STAMP) || defined(EMM_SKIP) || defined(EMM_PB) || defined(EMM_PRIO) || defined(EMM_NO_HI) || defined(EMM_NO_OPAQUE))
 #error "EMM_* lab knob defined without ED_LAB (tools/lab/mkvariant.py builds lab variants)"
 #endif
 #ifndef EMM_JIT
@@ -80,6 +80,12 @@ extern "C" void ed_set_net_debug_buffer(void *p) { (void)hipMemcpyToSymbol(HIP_S
 #endif
 #ifndef EMM_SPEC
 #define EMM_SPEC 0
+#endif
+/* 1 = the lane number is left transparent, 0 = opaque per batch and per layer (emm_net_body): the general kernel needs the
+ * opaque copies (+10.7 %: no register spills), a graph's own kernel is better off without them (+6.1 %: nothing spills there, and
+ * the hoisted per-lane values are constants' worth of work saved per layer) */
+#ifndef EMM_NO_OPAQUE
+#define EMM_NO_OPAQUE EMM_SPEC
 #endif
 #if EMM_SPEC
 #include EMM_SPEC_HEADER
@@ -825,7 +831,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 		 * alive across it, runs out of registers and spills -- and a scratch reload waits on vmcnt, i.e. for the NEXT batch's
 		 * prefetch that was put in flight just before it: the wave then sits out a memory latency per batch after all. */
 		int lane = lane0;
-		asm volatile("" : "+v"(lane));
+		if (!EMM_NO_OPAQUE) asm volatile("" : "+v"(lane));
 		const int nb = batch == 1 ? 1 : (int)((n - u0) < batch ? (n - u0) : batch);
 		EMM_ST(47)
 		/* ---- the inputs into layer 0's layout */
@@ -926,7 +932,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 			EMM_PR(li, n_layers)
 			const ed_mm_run_t R = EMM_RUN(li);
 			int lane_l = lane0; /* opaque per layer: see the top of the batch loop */
-			asm volatile("" : "+v"(lane_l));
+			if (!EMM_NO_OPAQUE) asm volatile("" : "+v"(lane_l));
 			if (R.kind == ED_RUN_SKIP) continue; /* a MaxPool taken in the epilogue of the layer in front of it */
 			const lds8 *a = slice + R.in_off;
 			lds8 *o = slice + R.o_off;
