@@ -68,7 +68,7 @@ extern "C" void ed_set_net_debug_buffer(void *p) { (void)hipMemcpyToSymbol(HIP_S
 #define EMM_ST(i)
 #endif
 /* timing-only ablations for A/B work (tools/lab; results are WRONG when non-zero): 1 no epilogue, 2 no k-loop (the
- * accumulators stay the seeds), 4 no expansion, 8 no input load, 16 no softmax / outputs */
+ * accumulators stay the seeds), 4 no expansion, 8 no input load, 16 no softmax / outputs, 32 zero seeds instead of the seed reads (32 x 32 tiles) */
 #ifndef EMM_SKIP
 #define EMM_SKIP 0
 #endif
@@ -323,7 +323,7 @@ __device__ __forceinline__ void emm_chain(const lds8 *const *fl, const int8_t *c
 #pragma unroll
 		for (int g = 0; g < 4; g++)
 		{
-			const v4i s4 = EMM_LD128(sp[r] + 32 * g);
+			const v4i s4 = (EMM_SKIP & 32) ? (v4i){0, 0, 0, 0} : EMM_LD128(sp[r] + 32 * g);
 			sd[r][4 * g] = s4.x; sd[r][4 * g + 1] = s4.y; sd[r][4 * g + 2] = s4.z; sd[r][4 * g + 3] = s4.w;
 		}
 	int ke = EMM_LD32(kp), ko = EMM_LD32(kp + 8 * (last < 1 ? last : 1)); /* offsets of the next even / odd step to fetch */
