@@ -568,28 +568,39 @@ __device__ __forceinline__ void emm_layer_tiles(const emm_mm_args &A, int lane)
 				for (int r = 0; r < R; r++)
 #pragma unroll
 					for (int c = 0; c < C; c++)
+					{
+						if ((EMM_SKIP & 1) || rt0 + r >= A.n_rt) continue; /* uniform */
+						const v16i &t = acc[r * C + c];
+						uint32_t d[4];
+						/* the arithmetic of the whole tile under uniform branches only, then ONE predicated region for its stores (a
+						 * predicate per store cost five scalar instructions each: exec saved, masked, branched over, restored) */
 #pragma unroll
 						for (int g = 0; g < 4; g++)
 						{
-							if ((EMM_SKIP & 1) || rt0 + r >= A.n_rt || 32 * rts[r] + 8 * g >= A.out_c) continue; /* uniform */
-							const v16i &t = acc[r * C + c];
-							const int r0 = 32 * rts[r] + 8 * g + 4 * h;
 							int a0 = t[4 * g], a1 = t[4 * g + 1], a2 = t[4 * g + 2], a3 = t[4 * g + 3];
 							if (QM == 2) { a0 >>= A.qsh; a1 >>= A.qsh; a2 >>= A.qsh; a3 >>= A.qsh; }
 							if (QM == 3) { a0 = (int)((uint32_t)a0 << -A.qsh); a1 = (int)((uint32_t)a1 << -A.qsh); a2 = (int)((uint32_t)a2 << -A.qsh); a3 = (int)((uint32_t)a3 << -A.qsh); }
-							const uint32_t d = (QM == 0 || QM == 4) ? emm_pack4(a0, a1, a2, a3, A.rs, A.lo_clamp) : emm_pack4_hi(a0, a1, a2, a3, lo2);
+							d[g] = (QM == 0 || QM == 4) ? emm_pack4(a0, a1, a2, a3, A.rs, A.lo_clamp) : emm_pack4_hi(a0, a1, a2, a3, lo2);
+						}
+						if (!live[c]) continue;
+#pragma unroll
+						for (int g = 0; g < 4; g++)
+						{
+							if (32 * rts[r] + 8 * g >= A.out_c) continue; /* uniform */
+							const int r0 = 32 * rts[r] + 8 * g + 4 * h;
 							if (QM != 4)
 							{
-								if (live[c] && (full8 || r0 < A.out_c)) EMM_ST32(op[c] + r0, d);
+								if (full8 || r0 < A.out_c) EMM_ST32(op[c] + r0, d[g]);
 							}
-							else if (live[c]) /* a C_out that is no multiple of 4: byte stores, in a copy of their own (they are the larger half of it) */
+							else /* a C_out that is no multiple of 4: byte stores, in a copy of their own (they are the larger half of it) */
 							{
-								if (r0 < A.out_c) op[c][r0] = (int8_t)d;
-								if (r0 + 1 < A.out_c) op[c][r0 + 1] = (int8_t)(d >> 8);
-								if (r0 + 2 < A.out_c) op[c][r0 + 2] = (int8_t)(d >> 16);
-								if (r0 + 3 < A.out_c) op[c][r0 + 3] = (int8_t)(d >> 24);
+								if (r0 < A.out_c) op[c][r0] = (int8_t)d[g];
+								if (r0 + 1 < A.out_c) op[c][r0 + 1] = (int8_t)(d[g] >> 8);
+								if (r0 + 2 < A.out_c) op[c][r0 + 2] = (int8_t)(d[g] >> 16);
+								if (r0 + 3 < A.out_c) op[c][r0 + 3] = (int8_t)(d[g] >> 24);
 							}
 						}
+					}
 			};
 			if ((A.out_c & 3) != 0) epilogue(emm_int<4>());
 			else if (!A.hi) epilogue(emm_int<0>());
