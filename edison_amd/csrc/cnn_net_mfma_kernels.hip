@@ -826,7 +826,8 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 	/* Images of at most 512 bytes, up to EMM_PB per wave: the next batch's dwords are requested from HBM before this one's
 	 * layers run (two registers per image), so that the wave never waits a memory latency per batch. */
 	const int64_t u_first = ((int64_t)blockIdx.x * n_waves + wave) * batch, u_step = (int64_t)gridDim.x * n_waves * batch;
-	EMM_CONST bool prefetch = n_intab && batch <= EMM_PB && EMM_PF(in_n) <= EMM_PRE * 256 && EMM_PF(in_n) >= 4;
+	static_assert(EMM_PRE * 256 == ED_MM_INTAB_PAD, "the planner pads the input table to what the prefetch covers");
+	EMM_CONST bool prefetch = n_intab >= ED_MM_INTAB_PAD && batch <= EMM_PB && EMM_PF(in_n) <= EMM_PRE * 256 && EMM_PF(in_n) >= 4;
 	uint32_t pre[EMM_PB][EMM_PRE];
 	if (prefetch && u_first < n)
 	{
@@ -871,16 +872,18 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 #pragma unroll
 				for (int k = 0; k < EMM_PRE; k++)
 				{
+					/* the four places of this lane's dword k in one 8-byte read; no test: the table is padded (ED_MM_INTAB_PAD), a byte
+					 * past the image lands in the image's slack */
 					const int e = 4 * lane + 256 * k;
+					const uint64_t at4 = *reinterpret_cast<const EMM_LDS uint64_t *>(intab_l + e);
 #pragma unroll
 					for (int t = 0; t < 4; t++)
-						if (e + t < in_n)
-						{
-							const int at = intab_l[e + t]; /* the same place in every image of the batch */
+					{
+						const int at = (int)((at4 >> (16 * t)) & 0xffffu); /* the same place in every image of the batch */
 #pragma unroll
-							for (int b = 0; b < EMM_PB; b++)
-								if (b < batch) in0[b * l0.img + at] = (int8_t)(v[b][k] >> (8 * t));
-						}
+						for (int b = 0; b < EMM_PB; b++)
+							if (b < batch) in0[b * l0.img + at] = (int8_t)(v[b][k] >> (8 * t));
+					}
 				}
 			}
 			else if (n_intab)

@@ -267,6 +267,10 @@ int ed_plan_net(const void *blob, size_t blob_bytes, ed_net_plan_t *plan, int8_t
 #define ED_MM_MAX_COLS 1024 /* column-table entries of all layers together (8 bytes each in LDS) */
 #define ED_MM_MAX_XTAB 1536 /* expansion-table entries of all layers together (8 bytes each in LDS) */
 #define ED_MM_MAX_INTAB 4096 /* input-table entries (2 bytes each in LDS) */
+/* images of 4 .. ED_MM_INTAB_PAD bytes take the kernel's prefetching input stage (two dwords per lane): their table is padded to
+ * ED_MM_INTAB_PAD entries that all point at the LAST byte of the image's 16 bytes of slack -- the stage then scatters every byte of
+ * both dwords without a test (a byte past the image goes to the slack, which is only ever read against zero weights or masked) */
+#define ED_MM_INTAB_PAD 512
 typedef struct {
 	int32_t mm;                 /* 1: Conv2D / Dense on the matrix cores                                              */
 	int32_t in_hp, in_wp;       /* the input image as this layer wants it in LDS: padded height / width ...          */

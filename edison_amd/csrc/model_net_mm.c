@@ -214,6 +214,11 @@ int ed_plan_net_mm(const void *blob, size_t blob_bytes, const ed_net_plan_t *pla
 			mm->intab[e] = (uint16_t)(((y + M0->in_py) * M0->in_wp + x + M0->in_px) * (plan->L[0].type == ED_NET_CONV ? M0->pp : plan->in_c) + c);
 		}
 		mm->n_intab = plan->in_n;
+		if (plan->in_n >= 4 && plan->in_n < ED_MM_INTAB_PAD) /* see ED_MM_INTAB_PAD */
+		{
+			for (int e = plan->in_n; e < ED_MM_INTAB_PAD; e++) mm->intab[e] = (uint16_t)(M0->in_img - 1);
+			mm->n_intab = ED_MM_INTAB_PAD;
+		}
 	}
 
 	/* LDS budget: a wave's activation region for `batch` inputs -- a layer's input images at one end, its output images at
