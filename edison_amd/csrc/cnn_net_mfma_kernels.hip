@@ -944,10 +944,12 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 			 * ds_read + v_readfirstlane per field; deriving it here from the layer records took a chain of dependent
 			 * scalar loads and ~100 scalar instructions per layer and input) */
 			EMM_PR(li, n_layers)
+			EMM_ST(4 + 5 * li)
 			const ed_mm_run_t R = EMM_RUN(li);
 			int lane_l = lane0; /* opaque per layer: see the top of the batch loop */
 			if (!EMM_NO_OPAQUE) asm volatile("" : "+v"(lane_l));
 			if (R.kind == ED_RUN_SKIP) continue; /* a MaxPool taken in the epilogue of the layer in front of it */
+			EMM_ST(3 + 5 * li)
 			const lds8 *a = slice + R.in_off;
 			lds8 *o = slice + R.o_off;
 			if (R.zero_border) /* uniform: the consumer wants a zero border */

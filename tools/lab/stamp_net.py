@@ -27,7 +27,7 @@ tot = d.sum()
 info = ctx.net_info()
 print("input load %5.1f %%" % (100 * d[0] / tot))
 for li, l in enumerate(info["layers"]):
-    print("layer %d type %d: setup (zero, expand, tables) %5.1f %%   body (tiles / pool / softmax) %5.1f %%" % (li, l["type"], 100 * d[1 + 5 * li] / tot, 100 * d[2 + 5 * li] / tot))
+    print("layer %d type %d: outputs of the layer in front %5.1f %%   run record (scalar loads) %5.1f %%   setup (zero, expand, tables) %5.1f %%   body (tiles / pool / softmax) %5.1f %%" % (li, l["type"], 100 * d[4 + 5 * li] / tot, 100 * d[3 + 5 * li] / tot, 100 * d[1 + 5 * li] / tot, 100 * d[2 + 5 * li] / tot))
 print("inside the tile groups of all layers: group setup %5.1f %%, seeds + k-loop %5.1f %%, epilogue %5.1f %%, before the first group %5.1f %%" % tuple(100 * d[i] / tot for i in (40, 41, 42, 43)))
 print("outputs + loop %5.1f %%" % (100 * (d[46] + d[47]) / tot))
 waves = 256 * info.get("mm_waves", 12)
