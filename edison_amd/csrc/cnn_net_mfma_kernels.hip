@@ -1002,7 +1002,7 @@ __device__ __forceinline__ void emm_net_body(const ed_net_plan_t *__restrict__ P
 				A.fragl = fragl + R.frag_off; A.fragg = frag + R.frag_off;
 				A.koff = reinterpret_cast<const lds8 *>(koff_all + R.koff_off);
 				A.seeds = reinterpret_cast<const lds8 *>(seeds_l + R.seed_off);
-				A.coltab = R.col_off >= 0 ? reinterpret_cast<const lds8 *>(coltab_l + 2 * R.col_off) : nullptr;
+				A.coltab = (R.col_off >= 0 && !(EMM_SKIP & 64)) ? reinterpret_cast<const lds8 *>(coltab_l + 2 * R.col_off) : nullptr; /* lab, 64: no column tables (results stay right) */
 				A.n_ks = R.n_ks; A.n_rt = R.n_rt;
 				A.col_w = R.col_w;
 				A.pix_per_img = R.pix_per_img;

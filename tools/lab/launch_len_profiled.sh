@@ -1,3 +1,4 @@
+# the run that made profiles/r04_launch_len.txt: tools/lab/launch_len.py interleaved, then one rocprofv3 --kernel-trace --stats run per leg (GPU box, via gpurun)
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
