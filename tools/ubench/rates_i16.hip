@@ -25,6 +25,9 @@
 #define I_PKMAX(r) "v_pk_max_i16 " r ", " r ", %8\n"
 #define I_ASHR(r) "v_ashrrev_i32 " r ", 3, " r "\n"
 #define I_MAXI(r) "v_max_i32 " r ", %8, " r "\n"
+#define I_MINI(r) "v_min_i32 " r ", %8, " r "\n"
+#define I_MOV(r) "v_mov_b32 " r ", %8\n"
+#define I_ADDU(r) "v_add_u32 " r ", %8, " r "\n"
 #define I_MED3(r) "v_med3_i32 " r ", " r ", %8, %9\n"
 #define I_MAX3(r) "v_max3_i32 " r ", " r ", %8, %9\n"
 #define I_DSR(r) "ds_read_b32 " r ", %10\n"
@@ -32,8 +35,8 @@
  * a repeating 12-instruction pattern */
 #define I_MIX(r) I_PKADD(r) I_AND(r) I_XOR(r) I_PKASHR(r) I_PKADDU(r) I_DOT2(r) I_DOT2(r) I_PERM(r) I_PKSUB(r) I_BFI(r) I_DOT2(r) I_PERM(r)
 
-enum { PKADD, PKSUB, PKADDU, PKASHR, DOT2, PERM, BFI, AND, XOR, ALIGN, MULHI, MUL24, MIX, CVTPK, PKMAX, ASHR, MAXI, MED3, MAX3, NMODES };
-static const char *names[NMODES] = {"v_pk_add_i16 clamp", "v_pk_sub_i16 clamp", "v_pk_add_u16", "v_pk_ashrrev_i16", "v_dot2_i32_i16 (VOP3P, 0 acc)", "v_perm_b32", "v_bfi_b32", "v_and_b32 (VOP2)", "v_xor_b32 (VOP2)", "v_alignbit_b32", "v_mul_hi_u32", "v_mul_i32_i24", "butterfly mix (12 instr)", "v_cvt_pk_i16_i32", "v_pk_max_i16", "v_ashrrev_i32 (VOP2)", "v_max_i32 (VOP2)", "v_med3_i32", "v_max3_i32"};
+enum { PKADD, PKSUB, PKADDU, PKASHR, DOT2, PERM, BFI, AND, XOR, ALIGN, MULHI, MUL24, MIX, CVTPK, PKMAX, ASHR, MAXI, MED3, MAX3, MINI, MOV, ADDU, NMODES };
+static const char *names[NMODES] = {"v_pk_add_i16 clamp", "v_pk_sub_i16 clamp", "v_pk_add_u16", "v_pk_ashrrev_i16", "v_dot2_i32_i16 (VOP3P, 0 acc)", "v_perm_b32", "v_bfi_b32", "v_and_b32 (VOP2)", "v_xor_b32 (VOP2)", "v_alignbit_b32", "v_mul_hi_u32", "v_mul_i32_i24", "butterfly mix (12 instr)", "v_cvt_pk_i16_i32", "v_pk_max_i16", "v_ashrrev_i32 (VOP2)", "v_max_i32 (VOP2)", "v_med3_i32", "v_max3_i32", "v_min_i32 (VOP2)", "v_mov_b32 (VOP1)", "v_add_u32 (VOP2)"};
 
 template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long *stamps, unsigned *out, int iters, unsigned s, unsigned sel)
 {
@@ -66,6 +69,9 @@ template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long 
 			if (MODE == MAXI) asm volatile(X8(I_MAXI) : OPS : "v"(s), "v"(sel));
 			if (MODE == MED3) asm volatile(X8(I_MED3) : OPS : "v"(s), "v"(sel));
 			if (MODE == MAX3) asm volatile(X8(I_MAX3) : OPS : "v"(s), "v"(sel));
+			if (MODE == MINI) asm volatile(X8(I_MINI) : OPS : "v"(s), "v"(sel));
+			if (MODE == MOV) asm volatile(X8(I_MOV) : OPS : "v"(s), "v"(sel));
+			if (MODE == ADDU) asm volatile(X8(I_ADDU) : OPS : "v"(s), "v"(sel));
 		}
 	}
 	asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
@@ -108,7 +114,7 @@ int main()
 	{
 		run<PKADD>(w, 1); run<PKSUB>(w, 1); run<PKADDU>(w, 1); run<PKASHR>(w, 1); run<DOT2>(w, 1); run<PERM>(w, 1); run<BFI>(w, 1); run<AND>(w, 1); run<XOR>(w, 1);
 		run<ALIGN>(w, 1); run<MULHI>(w, 1); run<MUL24>(w, 1); run<MIX>(w, 12);
-		run<CVTPK>(w, 1); run<PKMAX>(w, 1); run<ASHR>(w, 1); run<MAXI>(w, 1); run<MED3>(w, 1); run<MAX3>(w, 1);
+		run<CVTPK>(w, 1); run<PKMAX>(w, 1); run<ASHR>(w, 1); run<MAXI>(w, 1); run<MED3>(w, 1); run<MAX3>(w, 1); run<MINI>(w, 1); run<MOV>(w, 1); run<ADDU>(w, 1);
 	}
 	return 0;
 }
