@@ -105,11 +105,33 @@ static void cache_path(char *out, size_t cap, uint64_t graph, uint64_t source, c
 	snprintf(out, cap, "%s/net_gfx950_%016llx_%016llx_%s.hsaco", base, (unsigned long long)graph, (unsigned long long)source, compiler);
 }
 
-/* a cache entry is read only if it is a regular file of this uid that nobody else can write */
-static int cache_entry_trusted(const char *path)
+static char *read_fd(int fd, off_t len, size_t *n)
 {
+	char *buf = len > 0 && len < (off_t)(64L << 20) ? (char *)malloc((size_t)len) : NULL;
+	size_t got = 0;
+	while (buf && got < (size_t)len)
+	{
+		const ssize_t k = read(fd, buf + got, (size_t)len - got);
+		if (k < 0 && errno == EINTR) continue;
+		if (k <= 0) { free(buf); buf = NULL; break; }
+		got += (size_t)k;
+	}
+	if (buf) *n = (size_t)len;
+	return buf;
+}
+
+/* A cache entry is read only if it is a regular file of this uid that nobody else can write -- checked on the descriptor the bytes
+ * are then read from (one open with O_NOFOLLOW, fstat, read: no window between the check and the use, no symbolic link followed). */
+static char *read_cache_entry(const char *path, size_t *n)
+{
+	const int fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+	if (fd < 0) return NULL;
 	struct stat st;
-	return stat(path, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && !(st.st_mode & (S_IWGRP | S_IWOTH));
+	char *buf = NULL;
+	if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && !(st.st_mode & (S_IWGRP | S_IWOTH)))
+		buf = read_fd(fd, st.st_size, n);
+	close(fd);
+	return buf;
 }
 
 static char *read_file(const char *path, size_t *n)
@@ -258,9 +280,9 @@ static int compile_with_hipcc(edison_ctx *ctx, const char *spec, char **code, si
 				if (w == pid) { done = 1; confirmed = 1; }
 				else if (w < 0 && errno != EINTR)
 				{
-					/* ECHILD: the host program ignores SIGCHLD or reaps children itself -- nobody can tell us how the compiler ended,
-					 * and it may still be writing: stop its group and take nothing from it */
-					(void)kill(-pid, SIGKILL);
+					/* ECHILD: the host program ignores SIGCHLD or reaps children itself -- the child has ALREADY been reaped (that is
+					 * what the error says), so its pid and process group may belong to somebody else by now: signal nothing. Nobody
+					 * can tell us how the compiler ended, so nothing is taken from it either (confirmed stays 0). */
 					done = 1;
 				}
 				else if (waited_ms > 120000)
@@ -376,7 +398,7 @@ static int specialize(edison_ctx *ctx, int cache_only)
 		const int is_hipcc = k == 0;
 		if (is_hipcc ? !try_hipcc : !try_rtc) continue;
 		cache_path(path, sizeof(path), graph, source, is_hipcc ? id_hipcc : id_rtc);
-		if (path[0] && cache_entry_trusted(path) && (code = read_file(path, &code_bytes)) != NULL) state = 2;
+		if (path[0] && (code = read_cache_entry(path, &code_bytes)) != NULL) state = 2;
 	}
 	if (!code && cache_only)
 	{

@@ -31,6 +31,7 @@ struct edison_stream
 {
 	edison_ctx *ctx;
 	int hop, chunk, tail; /* tail = 1024 - hop samples of history */
+	int last_n;           /* inferences of the LAST push (chunk, or fewer after edison_stream_push_n_dev): what the filtered / state outputs hold */
 	int variant;          /* EDISON_MFCC_B or EDISON_MFCC_C */
 	int filter;
 	int use_graph;        /* edison_stream_opts.launch_mode */
@@ -409,6 +410,7 @@ extern "C" int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts
 	edison_stream *s = (edison_stream *)calloc(1, sizeof(edison_stream));
 	if (!s) return ed_set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed");
 	s->ctx = ctx; s->hop = hop; s->chunk = chunk_frames; s->tail = EDISON_FRAME_LEN - hop;
+	s->last_n = chunk_frames; /* before the first push the (zeroed) blocks read as a whole chunk */
 	s->variant = o->mfcc_variant;
 	s->model_epoch = ctx->model_epoch;
 	s->tables_epoch = ctx->tables_epoch;
@@ -582,6 +584,7 @@ extern "C" int edison_stream_push_n_dev(edison_stream *s, const int16_t *samples
 		s->q_last = q;
 		s->q_pending = 1;
 		s->last_push_staged = 0;
+		s->last_n = n_frames;
 		s->frames_seen += n_frames;
 		return EDISON_OK;
 	}
@@ -603,6 +606,7 @@ extern "C" int edison_stream_push_n_dev(edison_stream *s, const int16_t *samples
 	/* ... and the context's stream continues only after the outputs are written */
 	ED_HIP(ctx, hipEventRecord(s->ev_out, s->own));
 	ED_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_out, 0));
+	s->last_n = s->chunk;
 	s->frames_seen += s->chunk;
 	return EDISON_OK;
 }
@@ -657,7 +661,8 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 		memmove(s->m_feat, s->m_feat + c * EDISON_NUM_MFCC, 30 * EDISON_NUM_MFCC);
 		s->last_push_staged = 0;
 		s->last_push_mapped = 1;
-		s->frames_seen += s->chunk;
+		s->last_n = s->chunk;
+	s->frames_seen += s->chunk;
 		return EDISON_OK;
 	}
 	{ const int rs = stream_state_to(s, 0); if (rs != EDISON_OK) return rs; }
@@ -674,7 +679,8 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 		if (softmax) memcpy(softmax, s->h_out + s->off_soft, c * EDISON_NET_OUT);
 		if (argmax) memcpy(argmax, s->h_out + s->off_argmax, c * sizeof(int32_t));
 		s->last_push_staged = 1;
-		s->frames_seen += s->chunk;
+		s->last_n = s->chunk;
+	s->frames_seen += s->chunk;
 		return EDISON_OK;
 	}
 	s->last_push_staged = 0;
@@ -684,21 +690,25 @@ extern "C" int edison_stream_push(edison_stream *s, const int16_t *samples, int8
 	if (softmax) ED_HIP(ctx, hipMemcpyAsync(softmax, s->d_soft, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToHost, s->own));
 	if (argmax) ED_HIP(ctx, hipMemcpyAsync(argmax, s->d_argmax, (size_t)s->chunk * sizeof(int32_t), hipMemcpyDeviceToHost, s->own));
 	ED_HIP(ctx, hipStreamSynchronize(s->own));
+	s->last_n = s->chunk;
 	s->frames_seen += s->chunk;
 	return EDISON_OK;
 }
 
-/* Filtered outputs of the LAST push (filter enabled in the options): filt [chunk][10] fp32, likely / spotted [chunk].
+/* Filtered outputs of the LAST push (filter enabled in the options): filt [n][10] fp32, likely / spotted [n], n = the frames of that
+ * push (chunk_frames, or fewer after edison_stream_push_n_dev).
  * host = 1: host pointers, synchronous; host = 0: device pointers, ordered on the context's stream like a push. */
 static int stream_filter_out(edison_stream *s, float *filt, int32_t *likely, int32_t *spotted, int host)
 {
 	if (!s) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
 	if (!s->filter) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: created without the output filter");
+	/* entries of the last push only: after a ragged push (edison_stream_push_n_dev, n < chunk) the rows n.. of the stream's blocks
+	 * are an earlier push's, and a caller that sized its buffers [n][..] must not be written past them */
+	const size_t c = (size_t)s->last_n;
 	if (s->last_push_mapped)
 	{
 		/* the mapped push wrote them into pinned host memory */
-		const size_t c = (size_t)s->chunk;
 		if (host)
 		{
 			if (filt) memcpy(filt, s->m_out + s->off_filt, c * EDISON_NET_OUT * sizeof(float));
@@ -717,16 +727,15 @@ static int stream_filter_out(edison_stream *s, float *filt, int32_t *likely, int
 	if (host && s->last_push_staged)
 	{
 		/* the staged push already brought them to the host */
-		const size_t c = (size_t)s->chunk;
 		if (filt) memcpy(filt, s->h_out + s->off_filt, c * EDISON_NET_OUT * sizeof(float));
 		if (likely) memcpy(likely, s->h_out + s->off_likely, c * sizeof(int32_t));
 		if (spotted) memcpy(spotted, s->h_out + s->off_spotted, c * sizeof(int32_t));
 		return EDISON_OK;
 	}
 	const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-	if (filt) ED_HIP(ctx, hipMemcpyAsync(filt, s->d_filt, sizeof(float) * (size_t)s->chunk * EDISON_NET_OUT, kind, s->own));
-	if (likely) ED_HIP(ctx, hipMemcpyAsync(likely, s->d_likely, sizeof(int32_t) * (size_t)s->chunk, kind, s->own));
-	if (spotted) ED_HIP(ctx, hipMemcpyAsync(spotted, s->d_spotted, sizeof(int32_t) * (size_t)s->chunk, kind, s->own));
+	if (filt) ED_HIP(ctx, hipMemcpyAsync(filt, s->d_filt, sizeof(float) * c * EDISON_NET_OUT, kind, s->own));
+	if (likely) ED_HIP(ctx, hipMemcpyAsync(likely, s->d_likely, sizeof(int32_t) * c, kind, s->own));
+	if (spotted) ED_HIP(ctx, hipMemcpyAsync(spotted, s->d_spotted, sizeof(int32_t) * c, kind, s->own));
 	if (host) ED_HIP(ctx, hipStreamSynchronize(s->own));
 	else
 	{
@@ -742,7 +751,7 @@ static int stream_fsm_out(edison_stream *s, edison_fsm *fsm, int32_t *states, in
 	if (!s) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
 	if (!s->fsm) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: created without the state machine (opts.fsm)");
-	const size_t c = (size_t)s->chunk;
+	const size_t c = (size_t)s->last_n; /* as in stream_filter_out: the last push's entries only */
 	if (s->last_push_mapped)
 	{
 		if (host)
@@ -783,7 +792,12 @@ extern "C" int edison_stream_fsm_dev(edison_stream *s, int32_t *states) { return
 extern "C" int edison_postproc(edison_ctx *ctx, const int8_t *softmax, int64_t n, double alpha, double true_threshold, uint32_t dt_us,
                                float *filt_state, edison_fsm *fsm, float *filt, int32_t *likely, int32_t *spotted, int32_t *states)
 {
-	if (!ctx || !softmax || !filt_state || n < 0 || n >= ((int64_t)1 << 31) || !(alpha >= 0.0 && alpha <= 1.0)) return EDISON_E_ARGUMENT;
+	/* n < 2^30: the kernel indexes with ints and strides of 256; the chain is sequential in time by definition (ten lanes filter, one
+	 * lane walks the machine), so the cost grows linearly with n in ONE workgroup -- a post-processing stage, not a batch kernel */
+	if (!ctx || !softmax || !filt_state || n < 0 || n >= ((int64_t)1 << 30) || !(alpha >= 0.0 && alpha <= 1.0)) return EDISON_E_ARGUMENT;
+	if (!(true_threshold == true_threshold)) return ed_set_err(ctx, EDISON_E_ARGUMENT, "edison_postproc: true_threshold is not a number");
+	/* what edison_fsm_step answers for the same machine: an unknown state is an argument error, not n states of -1 */
+	if (fsm && (fsm->state < EDISON_FSM_RESET || fsm->state > EDISON_FSM_SET)) return ed_set_err(ctx, EDISON_E_ARGUMENT, "edison_postproc: fsm->state is not a state of the machine");
 	if (n == 0) return EDISON_OK;
 	const size_t c = (size_t)n;
 	size_t off = c * EDISON_NET_OUT;                                   /* softmax at 0 */

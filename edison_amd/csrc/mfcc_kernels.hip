@@ -38,6 +38,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include "edison_internal.h"
 
 #include "mfcc_one_frame.h"
@@ -102,9 +104,17 @@ extern "C" { extern const int ed_lab_build_mfcc; const int ed_lab_build_mfcc = 1
 #define ED2_STAMP 0
 #endif
 #if ED2_STAMP
-#define ED2_NPH 17
+#define ED2_NPH 19
 __device__ unsigned long long *g_ed2_dbg = nullptr;
 extern "C" void ed_set_debug_buffer(void *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ed2_dbg), &p, sizeof(p)); }
+/* launches in flight together (tools/lab/stamp_overlap.py) stamp into separate slots of the debug buffer: the slot of a launch is
+ * where its output lies inside one allocation of n_slots outputs of slot_bytes each; slot_waves = stamp records per slot */
+__device__ unsigned long long g_ed2_slot[4] = {0, 0, 0, 0}; /* base, slot_bytes, n_slots, slot_waves */
+extern "C" void ed_set_debug_slots(void *base, unsigned long long slot_bytes, unsigned long long n_slots, unsigned long long slot_waves)
+{
+	const unsigned long long v[4] = {(unsigned long long)base, slot_bytes, n_slots, slot_waves};
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_ed2_slot), v, sizeof(v));
+}
 __device__ __forceinline__ unsigned long long ed2_now()
 {
 	unsigned long long t;
@@ -481,13 +491,25 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 	ph[12] = ed2_now() - tfirst; ph[13] = rt1 - rt0; ph[14] = rt_entry; ph[15] = rt0; ph[16] = rt1;
 	if (g_ed2_dbg && lane == 0)
 	{
-		unsigned long long *dbg = g_ed2_dbg + (size_t)(blockIdx.x * ED2_WPB + wave) * ED2_NPH;
+		size_t slot_off = 0;
+		if (g_ed2_slot[1])
+			slot_off = (size_t)((((unsigned long long)args.mfcc - g_ed2_slot[0]) / g_ed2_slot[1]) % g_ed2_slot[2]) * g_ed2_slot[3];
+		unsigned long long *dbg = g_ed2_dbg + (slot_off + (size_t)(blockIdx.x * ED2_WPB + wave)) * ED2_NPH;
 		ph[11] = i_cur; /* not a time: how far this wave got in the slice */
+		{
+			unsigned hw, xcc; /* which CU this wave ran on: HW_ID = wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13] ..., XCC_ID[3:0] */
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+			ph[17] = hw; ph[18] = xcc;
+		}
 		for (int i_ = 0; i_ < ED2_NPH; i_++) dbg[i_] = ph[i_];
 	}
 #endif
 }
 
+#if defined(ED_LAB)
+static int g_ed_lab_launch_flags = 0; /* lab: hipExtLaunchKernel flags of the fast path (hipExtAnyOrderLaunch = 1) */
+extern "C" void ed_lab_set_launch_flags(int f) { g_ed_lab_launch_flags = f; }
+#endif
 /* occupancy-derived grid sizes and "dynamic-LDS limit raised" flags, per DEVICE (0 = not asked yet; the attribute belongs to
  * the function on the current device, so two contexts on different GPUs of one process must each set it) */
 static int g_mfcc_blocks_per_cu[16][2];
@@ -555,6 +577,10 @@ static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables
 		int64_t blocks2 = (n_pairs + ED2_WPB - 1) / ED2_WPB;
 		if (blocks2 > (int64_t)n_cu * *bpc2) blocks2 = (int64_t)n_cu * *bpc2;
 		void *kargs[] = {(void *)args, (void *)&dev_tab};
+#if defined(ED_LAB)
+		if (g_ed_lab_launch_flags)
+			return (int)hipExtLaunchKernel(fn, dim3((unsigned)blocks2), dim3(64 * ED2_WPB), kargs, lds2, stream, nullptr, nullptr, g_ed_lab_launch_flags);
+#endif
 		return (int)hipLaunchKernel(fn, dim3((unsigned)blocks2), dim3(64 * ED2_WPB), kargs, lds2, stream);
 	}
 	dim3 grid((unsigned)blocks), block(64 * ED_WPB);

@@ -101,7 +101,8 @@ class Stream:
 
     def push_t(self, samples, logits=None, softmax=None, argmax=None, filtered=None, likely=None, spotted=None, n_frames=None):
         """Device tensors (torch, int16 / int8 / int32 / fp32 on the context's GPU); asynchronous on the context's stream.
-        n_frames < chunk_frames: a ragged last push (edison_stream_push_n_dev: n_frames * hop samples, outputs [n_frames][..])."""
+        n_frames < chunk_frames: a ragged last push (edison_stream_push_n_dev: n_frames * hop samples); every output -- logits, softmax,
+        argmax, filtered, likely, spotted -- is [n_frames][..]: the stream copies the entries of THIS push only."""
         n = self.chunk if n_frames is None else int(n_frames)
         if samples.numel() != n * self.hop:
             raise ValueError("push needs exactly n_frames*hop = %d samples" % (n * self.hop))

@@ -335,12 +335,13 @@ typedef struct edison_stream_opts
 #define EDISON_STREAM_LAUNCH_GRAPH 1
 void edison_stream_default_opts(edison_stream_opts *o);
 int edison_stream_create_ex(edison_ctx *ctx, const edison_stream_opts *o, edison_stream **out);
-/* Filtered outputs of the LAST push: filt [chunk][10] fp32 (netOutFilt after each inference), likely [chunk] int32
- * (predMaxIdx), spotted [chunk] int32 (predMaxIdx where predMax > threshold, else -1). Each may be NULL. */
+/* Filtered outputs of the LAST push: filt [n][10] fp32 (netOutFilt after each inference), likely [n] int32 (predMaxIdx), spotted [n]
+ * int32 (predMaxIdx where predMax > threshold, else -1); n = the frames of that push (chunk_frames, or the n_frames of
+ * edison_stream_push_n_dev: exactly n entries are written). Each may be NULL. */
 int edison_stream_filtered(edison_stream *s, float *filt /* host */, int32_t *likely, int32_t *spotted);
 int edison_stream_filtered_dev(edison_stream *s, float *filt /* device */, int32_t *likely, int32_t *spotted);
-/* The state machine of a stream created with fsm = 1, after the LAST push: *fsm = the machine (may be NULL), states [chunk] int32 =
- * the state it was in after each inference of that push (may be NULL). */
+/* The state machine of a stream created with fsm = 1, after the LAST push: *fsm = the machine (may be NULL), states [n] int32 =
+ * the state it was in after each of the n inferences of that push (may be NULL; n as for edison_stream_filtered). */
 struct edison_fsm;
 int edison_stream_fsm(edison_stream *s, struct edison_fsm *fsm /* host */, int32_t *states /* host */);
 int edison_stream_fsm_dev(edison_stream *s, int32_t *states /* device */);
@@ -369,7 +370,10 @@ int edison_fsm_step(edison_fsm *f, float pred_max, uint32_t pred_idx, uint32_t d
 /* The whole post-processing chain of the firmware (app.c:332-371) on n network outputs in time order, as one GPU stage and without a
  * stream: moving average -> first maximum -> threshold -> state machine. softmax [n][10] int8 (host); filt_state [10] fp32 in/out
  * (netOutFilt, zeros at the start), fsm in/out (edison_fsm_init at the start; NULL: no state machine), dt_us = time between two
- * inferences; outputs (host, each may be NULL): filt [n][10], likely [n], spotted [n], states [n]. */
+ * inferences; outputs (host, each may be NULL): filt [n][10], likely [n], spotted [n], states [n]. n < 2^30. The recurrence rounds at every
+ * step, so the chain is sequential in time by definition: ONE workgroup (ten lanes filter, one walks the machine), cost linear in n -- a
+ * post-processing stage for the outputs of a stream, not a batch kernel. EDISON_E_ARGUMENT: alpha outside [0, 1], a threshold that is
+ * not a number, an fsm->state that is not a state of the machine (what edison_fsm_step answers for it). */
 int edison_postproc(edison_ctx *ctx, const int8_t *softmax, int64_t n, double alpha, double true_threshold, uint32_t dt_us,
                     float *filt_state, edison_fsm *fsm, float *filt, int32_t *likely, int32_t *spotted, int32_t *states);
 /* roles of the ten classes in the state machine: the wake word's class index (-1: none), bit masks of the locations and values */

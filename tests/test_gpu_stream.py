@@ -341,24 +341,71 @@ def test_ragged_last_push(ctx, hop, chunk, tail):
         g.close()
 
 
+@pytest.mark.parametrize("hop,chunk,tail", [(512, 64, 17), (1024, 9, 1)])
+def test_ragged_last_push_with_filter_and_state_machine(ctx, oracle_mod, hop, chunk, tail):
+    """The filtered outputs and the machine's states of a ragged push are ITS n entries, nothing more: the caller's device buffers are
+    sized [n][..] inside a larger allocation whose remainder must stay untouched (before the fix the stream copied `chunk` entries:
+    stale rows of an earlier push, written past an [n]-sized buffer), and the chain over all pushes equals the host chain."""
+    import torch
+    from edison_amd.stream import Stream
+    rng = np.random.default_rng(3 * hop + chunk + tail)
+    plan = [chunk, tail, chunk, tail]
+    audio = np.clip(rng.normal(0, 2500, sum(plan) * hop), -32768, 32767).astype(np.int16)
+    dev = torch.device("cuda", 0)
+    a = torch.from_numpy(audio).to(dev)
+    thr, dt_us = 0.5, hop * 1_000_000 // 16000
+    st = Stream(ctx, hop=hop, chunk_frames=chunk, fsm=True, threshold=thr)
+    GUARD = 7777.0
+    soft, filt, likely, spotted, states = [], [], [], [], []
+    at = 0
+    for n in plan:
+        so = torch.zeros((n, 10), dtype=torch.int8, device=dev)
+        fl = torch.full((chunk + 8, 10), GUARD, dtype=torch.float32, device=dev)       # [n] used, the rest is the guard
+        li = torch.full((chunk + 8,), -77, dtype=torch.int32, device=dev)
+        sp = torch.full((chunk + 8,), -77, dtype=torch.int32, device=dev)
+        sd = torch.full((chunk + 8,), -77, dtype=torch.int32, device=dev)
+        st.push_t(a[at * hop:(at + n) * hop], softmax=so, filtered=fl, likely=li, spotted=sp, n_frames=None if n == chunk else n)
+        ctx._check(st._L.edison_stream_fsm_dev(st._h, sd.data_ptr()))
+        torch.cuda.synchronize()
+        assert (fl[n:] == GUARD).all() and (li[n:] == -77).all() and (sp[n:] == -77).all() and (sd[n:] == -77).all(), n
+        soft.append(so.cpu().numpy()); filt.append(fl[:n].cpu().numpy()); likely.append(li[:n].cpu().numpy())
+        spotted.append(sp[:n].cpu().numpy()); states.append(sd[:n].cpu().numpy())
+        at += n
+        # the host-pointer form after a ragged device push answers with n entries too
+        hf, hl, hs = np.full((chunk, 10), GUARD, np.float32), np.full(chunk, -77, np.int32), np.full(chunk, -77, np.int32)
+        hst = np.full(chunk, -77, np.int32)
+        ctx._check(st._L.edison_stream_filtered(st._h, hf.ctypes.data, hl.ctypes.data, hs.ctypes.data))
+        ctx._check(st._L.edison_stream_fsm(st._h, None, hst.ctypes.data))
+        assert np.array_equal(hf[:n].view(np.uint32), filt[-1].view(np.uint32)) and (hf[n:] == GUARD).all() and (hl[n:] == -77).all() and (hst[n:] == -77).all()
+        assert np.array_equal(hst[:n], states[-1])
+    rf, rl, rs, _, rstates, _ = _host_chain(oracle_mod, np.concatenate(soft), 0.9, thr, dt_us)
+    assert np.array_equal(np.concatenate(filt).view(np.uint32), rf.view(np.uint32))
+    assert np.array_equal(np.concatenate(likely), rl) and np.array_equal(np.concatenate(spotted), rs)
+    assert np.array_equal(np.concatenate(states), rstates)
+    st.close()
+
+
 def _host_chain(oracle_mod, soft, alpha, threshold, dt_us, state=None, fsm=None):
-    """The chain on the host, independently of the GPU stage: the oracle's output filter (oracle/postproc_ref.c), then the library's
-    HOST state machine (edison_fsm_step, legacy.c) one inference at a time."""
-    import ctypes
-    from edison_amd import _lib
-    L = _lib.lib()
+    """The chain on the host, independently of the GPU stage AND of the product's state machine: the oracle's output filter
+    (oracle/postproc_ref.c), then oracle/fsm_ref.py -- edisonFSM restated from the reference's app.c:727-928 with the firmware's own
+    tables and pointer walks; it shares no code with csrc/edison_fsm_core.h, which host and device compile. `fsm`: an
+    oracle machine (fsm_ref.EdisonFsmRef) carried in from an earlier call."""
+    from oracle import fsm_ref
     filt, likely, spotted, st = oracle_mod.output_filter(soft, state=state, alpha=alpha, threshold=threshold)
-    if fsm is None:
-        fsm = _lib.Fsm()
-        L.edison_fsm_init(ctypes.byref(fsm))
-    states = np.zeros(len(likely), np.int32)
-    for i in range(len(likely)):
-        states[i] = L.edison_fsm_step(ctypes.byref(fsm), float(filt[i, likely[i]]), int(likely[i]), int(dt_us), float(threshold))
-    return filt, likely, spotted, st, states, fsm
+    states, fsm = fsm_ref.walk(filt[np.arange(len(likely)), likely], likely, dt_us, true_threshold=threshold, machine=fsm)
+    return filt, likely, spotted, st, np.array(states, dtype=np.int32), fsm
 
 
 def _fsm_tuple(f):
-    return (f.state, f.hot_timeout_ms, f.wake_idx, f.loc_idx, f.val_idx, f.last_loc, f.last_val, f.commands)
+    """The product's machine (edison_fsm, or the `raw` tuple of Stream.fsm_snapshot) or the oracle's, reduced to what both have whatever
+    the history: state, counter, wake word, the pending location while it can still be consumed (LOC, SET), the pending value in
+    SET, the last executed command, the number of commands."""
+    if hasattr(f, "ediState"):
+        last = f.last_command_idx()
+        return (f.ediState, f.hotTimeout, f.wakeWordIdx, f.pending_location_idx() if f.ediState in (3, 4) else None,
+                f.pending_value_idx() if f.ediState == 4 else None, last[0], last[1], len(f.executed))
+    t = tuple(f) if isinstance(f, (tuple, list)) else (f.state, f.hot_timeout_ms, f.wake_idx, f.loc_idx, f.val_idx, f.last_loc, f.last_val, f.commands)
+    return (t[0], t[1], t[2], t[3] if t[0] in (3, 4) else None, t[4] if t[0] == 4 else None, t[5], t[6], t[7])
 
 
 def _scenario(rng, n_segments, dt_us):
@@ -394,7 +441,9 @@ def test_postproc_chain_with_the_state_machine_on_the_gpu(ctx, oracle_mod, seed,
     state after EVERY inference, the machine itself at the end (time-out counter, pending location / value, executed commands) --
     incl. both 5 s time-outs, the value that arrives at the very step that times out (dropped), dt below one millisecond (the
     firmware's `hotTimeout += dt/1000` truncates to 0: the machine never times out), and the state carried across calls. The
-    reference holds no vectors for this chain: parity unpinned, the checker is the independent host restatement."""
+    reference holds no vectors for this chain: parity unpinned; the checker is oracle/postproc_ref.c + oracle/fsm_ref.py, neither of
+    which shares code with the product (the product's own host machine, edison_fsm_step, is held against the same oracle on the CPU:
+    tests/test_host_cpu.py::test_fsm_equals_the_independent_restatement_of_edisonFSM)."""
     from edison_amd.context import postproc
     rng = np.random.default_rng(seed)
     soft = _scenario(rng, 80, dt_us if dt_us >= 1000 else 64000)
@@ -407,7 +456,7 @@ def test_postproc_chain_with_the_state_machine_on_the_gpu(ctx, oracle_mod, seed,
     assert _fsm_tuple(got["fsm"]) == _fsm_tuple(fsm)
     if 1000 <= dt_us <= 64000:   # the scenario really gets everywhere: commands executed, both time-outs taken
         timeouts = int(((states[1:] == 1) & (states[:-1] >= 2) & (states[:-1] <= 3)).sum())
-        assert fsm.commands >= 3 and set(states.tolist()) >= {1, 2, 3, 4} and timeouts >= 4, (fsm.commands, set(states.tolist()), timeouts)
+        assert len(fsm.executed) >= 3 and set(states.tolist()) >= {1, 2, 3, 4} and timeouts >= 4, (len(fsm.executed), set(states.tolist()), timeouts)
     # in three pieces, the filter state and the machine carried along: the same answers
     cuts = [0, len(soft) // 3, len(soft) // 3 + 1, len(soft)]
     state, m, parts = None, None, []
@@ -416,6 +465,27 @@ def test_postproc_chain_with_the_state_machine_on_the_gpu(ctx, oracle_mod, seed,
         state, m = g["state"], g["fsm"]
         parts.append(g["fsm_states"])
     assert np.array_equal(np.concatenate(parts), states) and _fsm_tuple(m) == _fsm_tuple(fsm)
+
+
+def test_postproc_argument_checks(ctx):
+    """edison_postproc refuses what edison_fsm_step refuses: a machine in a state that does not exist (it used to run and answer n
+    states of -1 with EDISON_OK), a threshold that is not a number, n beyond 2^30."""
+    import ctypes
+    from edison_amd import _lib
+    from edison_amd.context import postproc
+    L = _lib.lib()
+    soft = np.zeros((4, 10), np.int8)
+    bad = _lib.Fsm(); L.edison_fsm_init(ctypes.byref(bad)); bad.state = 9
+    with pytest.raises(_lib.EdisonError) as ei:
+        postproc(ctx, soft, fsm=bad)
+    assert ei.value.code == _lib.E_ARGUMENT
+    with pytest.raises(_lib.EdisonError) as ei:
+        postproc(ctx, soft, threshold=float("nan"))
+    assert ei.value.code == _lib.E_ARGUMENT
+    st = np.zeros(10, np.float32)
+    assert L.edison_postproc(ctx._h, soft.ctypes.data, 1 << 30, 0.9, 0.5, 64000, st.ctypes.data, None, None, None, None, None) == _lib.E_ARGUMENT
+    ok = postproc(ctx, soft)
+    assert ok["fsm_states"].tolist() == [1, 1, 1, 1]
 
 
 @pytest.mark.parametrize("hop,chunk", [(512, 1), (512, 6), (1024, 64)])
@@ -437,7 +507,7 @@ def test_stream_with_the_state_machine_as_its_last_stage(ctx, oracle_mod, hop, c
     filt, likely, spotted, _, states, fsm = _host_chain(oracle_mod, soft, 0.9, thr, dt_us)
     assert np.array_equal(np.concatenate([o["filtered"] for o in outs]).view(np.uint32), filt.view(np.uint32))
     assert np.array_equal(got, states)
-    assert outs[-1]["fsm"]["raw"] == _fsm_tuple(fsm)
+    assert _fsm_tuple(outs[-1]["fsm"]["raw"]) == _fsm_tuple(fsm)
     assert got[0] == 1                                   # RESET -> IDLE at the first inference (app.c:766-791)
     # device pushes on the same stream object continue the same machine
     dev = torch.device("cuda", 0)

@@ -186,6 +186,79 @@ def test_fsm_scenarios(built_lib):
     assert [f.step(*e) for e in late_value][-1] == "IDLE" and f.commands == 0   # the value came with the timeout: dropped
 
 
+def _fsm_view(f):
+    """What of the product's `edison_fsm` struct has a counterpart in the firmware's statics whatever the history: state, counter, wake
+    word, executed commands; the pending location while it can still be consumed (LOC, SET), the pending value in SET."""
+    return (f.state, f.hot_timeout_ms, f.wake_idx, f.loc_idx if f.state in (3, 4) else None, f.val_idx if f.state == 4 else None,
+            f.last_loc, f.last_val, f.commands)
+
+
+def _ref_view(m):
+    last = m.last_command_idx()
+    return (m.ediState, m.hotTimeout, m.wakeWordIdx, m.pending_location_idx() if m.ediState in (3, 4) else None,
+            m.pending_value_idx() if m.ediState == 4 else None, last[0], last[1], len(m.executed))
+
+
+def test_fsm_equals_the_independent_restatement_of_edisonFSM(built_lib):
+    """`edison_fsm_step` (legacy.c over csrc/edison_fsm_core.h, the function the GPU stages compile too) against oracle/fsm_ref.py,
+    which is written from /root/reference/firmware/src/app.c:727-928 with the firmware's own tables and pointer walks and shares no
+    code with the product. (1) scenario streams: whole commands, both 5 s time-outs, a value on the call that times out, dt below
+    1 ms, thresholds 0.5 .. 80. (2) an exhaustive single-step walk: every state x hit / miss x every class x dt in {999, 1000,
+    64 000, 5 001 000} us x a counter around the 5000 ms limit. Parity unpinned (the reference holds no vectors for the machine)."""
+    from edison_amd import _lib
+    from oracle import fsm_ref
+    L = built_lib
+    rng = np.random.default_rng(11)
+    for thr, dt in [(0.5, 64000), (30.0, 64000), (50.0, 32000), (80.0, 1_000_000), (0.5, 999), (0.5, 1_700_000)]:
+        n = 6000
+        idx = rng.integers(0, 10, n)
+        # long holds of one class (the moving average of a real stream) mixed with jitter
+        for k in range(0, n, 40):
+            if rng.random() < 0.7:
+                idx[k:k + int(rng.integers(1, 120))] = rng.choice([0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+        mx = rng.choice([0.0, 0.4, 0.5, 0.6, 29.9, 30.1, 79.0, 81.0, 127.0], n).astype(np.float32)
+        f = _lib.Fsm()
+        L.edison_fsm_init(ctypes.byref(f))
+        m = fsm_ref.EdisonFsmRef(true_threshold=thr)
+        for i in range(n):
+            got = L.edison_fsm_step(ctypes.byref(f), float(mx[i]), int(idx[i]), dt, float(thr))
+            want = m.step(mx[i], idx[i], dt)
+            assert got == want and _fsm_view(f) == _ref_view(m), (thr, dt, i, _fsm_view(f), _ref_view(m))
+        if thr <= 50.0 and dt >= 1000:
+            assert len(m.executed) > 0 and f.commands == len(m.executed)     # the stream really drives commands through SET
+    # (2) exhaustive single steps
+    locs, vals = [1, 2, 3, 4, 5], [6, 7]
+    n_cases = 0
+    for state in range(5):
+        for hit in (0.0, 127.0):
+            for cls in range(10):
+                for dt in (999, 1000, 64000, 5_001_000):
+                    for t0 in (0, 4935, 4936, 4937, 4999, 5000, 5001, 0xFFFFFFFF - 10):
+                        for li in (locs if state in (3, 4) else [locs[0]]):
+                            for vi in (vals if state == 4 else [vals[0]]):
+                                f = _lib.Fsm()
+                                L.edison_fsm_init(ctypes.byref(f))
+                                m = fsm_ref.EdisonFsmRef()
+                                if state != 0:
+                                    L.edison_fsm_step(ctypes.byref(f), 0.0, 9, 1000, 0.5)     # RESET -> IDLE resolves the roles
+                                    m.step(0.0, 9, 1000)
+                                    f.state, f.hot_timeout_ms, f.loc_idx, f.val_idx = state, t0, li, vi
+                                    m.ediState, m.hotTimeout = state, t0
+                                    m.loc = [e["keywordIdx"] if e["name"] else None for e in m.ediLocations].index(li)
+                                    m.val = [e["keywordIdx"] if e["name"] else None for e in m.ediValues].index(vi)
+                                got = L.edison_fsm_step(ctypes.byref(f), hit, cls, dt, 0.5)
+                                want = m.step(hit, cls, dt)
+                                assert got == want and _fsm_view(f) == _ref_view(m), (state, hit, cls, dt, t0, li, vi, _fsm_view(f), _ref_view(m))
+                                n_cases += 1
+    assert n_cases > 4000
+    # a state that does not exist: an argument error on the host, an exception in the restatement (Error_Handler, app.c:875)
+    f = _lib.Fsm(); L.edison_fsm_init(ctypes.byref(f)); f.state = 7
+    assert L.edison_fsm_step(ctypes.byref(f), 1.0, 0, 1000, 0.5) == _lib.E_ARGUMENT
+    m = fsm_ref.EdisonFsmRef(); m.ediState = 7
+    with pytest.raises(ValueError):
+        m.step(1.0, 0, 1000)
+
+
 def test_fsm_roles_of_the_ten_classes(built_lib):
     """What the GPU stage of the state machine gets instead of strings: the wake word's class and the location / value masks, resolved
     from the firmware's tables (EDI_WAKEWORD app.c:50, ediLocations / ediValues app.c:135-147) against keywords.txt."""

@@ -15,7 +15,7 @@ L.ed_set_debug_buffer.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda", 0)
 h = ctypes.c_void_p(); assert L.edison_init(0, ctypes.byref(h)) == 0
 st = torch.cuda.current_stream(); L.edison_set_stream(h, ctypes.c_void_p(st.cuda_stream))
-NPH, WPB, frames = 17, 12, 65536
+NPH, WPB, frames = 19, 12, 65536
 dbg = torch.zeros((256 * WPB, NPH), dtype=torch.int64, device=dev)
 L.ed_set_debug_buffer(ctypes.c_void_p(dbg.data_ptr())); torch.cuda.synchronize()
 g = torch.Generator(device=dev); g.manual_seed(1)

@@ -18,7 +18,7 @@ L.ed_set_debug_buffer.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda", 0)
 h = ctypes.c_void_p(); assert L.edison_init(0, ctypes.byref(h)) == 0
 st = torch.cuda.current_stream(); L.edison_set_stream(h, ctypes.c_void_p(st.cuda_stream))
-NPH = 17
+NPH = 19
 dbg = torch.zeros((256 * 8 * 16, NPH), dtype=torch.int64, device=dev)
 L.ed_set_debug_buffer(ctypes.c_void_p(dbg.data_ptr())); torch.cuda.synchronize()
 g = torch.Generator(device=dev); g.manual_seed(1)
