@@ -121,23 +121,31 @@ def cnn_counters_from_profiles():
         return None
 
 
-def timed_region(step_fn, steps, warmup, world, settle_ms=0.0, settle_chunk=256, cuda=True):
+def timed_region(step_fn, steps, warmup, world, settle_ms=0.0, settle_chunk=256, cuda=True, fork=None, join=None):
     """W untimed + exactly K timed steps, barrier + synchronize on both sides; returns (wall ms/step, event ms/step).
     settle_ms > 0 (only for steps WITHOUT collectives: the count differs per rank): before the W warm-up steps the
     same step is repeated, untimed, for that long -- the board's power
     management needs ~100 ms of sustained load before its clocks stop moving; with microsecond
     steps a small W alone would time the transient."""
     sync = torch.cuda.synchronize if cuda else (lambda: None)    # cuda=False: the --dry-run rehearsal on CPU tensors
+    # fork / join (the two-queue step: edison_queues_fork / edison_queues_join) bracket every run of steps that ends in a sync: the
+    # steps of such a run go to the context's two queues, the join makes the bench's stream -- and its closing event -- wait for both
+    fork = fork or (lambda: None)
+    join = join or (lambda: None)
     if settle_ms > 0:
         t_end = time.perf_counter() + settle_ms * 1e-3
         i = 0
         while time.perf_counter() < t_end:
+            fork()
             for _ in range(settle_chunk):
                 step_fn(i)
                 i += 1
+            join()
             sync()  # bounds the queue; one ~20 us gap per chunk
+    fork()
     for i in range(warmup):
         step_fn(i)
+    join()
     sync()
     if world > 1:
         dist.barrier()
@@ -148,8 +156,10 @@ def timed_region(step_fn, steps, warmup, world, settle_ms=0.0, settle_chunk=256,
     t0 = time.perf_counter()
     if cuda:
         e0.record()
+    fork()
     for i in range(steps):
         step_fn(warmup + i)
+    join()
     if cuda:
         e1.record()
     sync()
@@ -381,6 +391,69 @@ def cpu_baseline():
     return res
 
 
+MFCC_TOL = {"A": (1e-3, 1e-4), "B": (1e-2, 1e-5)}   # |d| <= abs + rel * |ref| against the float64 reference arithmetic
+
+
+def parity_check(sample):
+    """Part of the cpu_baseline leg (the oracle is loaded there, never inside a timed region): what the LAST TIMED step of each
+    workload wrote, against the oracle on the very samples that step read -- the first 4 096 frames of the MFCC batch (variants B,
+    A, C) and the first 128 utterances of the KWS batch. Reference arithmetic: mfcc_utils.py:287-322 (B), :160-197 (A),
+    audioprocessing.c:116-215 (C), kws_nnom.py:354-361 (net input), NNoM + CMSIS-NN (CNN; nnom_utils.c:275-284 for the argmax).
+    SURVEY.md 7: feature flips (fp32 landing on the other side of an x.5 of the float64 path) and argmax flips are counted
+    separately; CNN exactness is asserted on the features the GPU produced. ok = False fails the run (exit code 5, after the line)."""
+    from oracle import oracle
+    res = dict(ok=True)
+
+    def mfcc_leg(tag, variant, frames, got):
+        ref = oracle.mfcc(frames.reshape(-1), variant, n_threads=8)[:, :got.shape[1]]
+        d = np.abs(got.astype(np.float64) - ref)
+        a_, r_ = MFCC_TOL[tag]
+        bound = a_ + r_ * np.abs(ref)
+        worst = int(np.argmax(d / bound))
+        inside = bool((d <= bound).all())
+        res["mfcc_%s" % tag.lower()] = dict(frames_checked=int(frames.shape[0]), max_abs_err=float(d.max()), at_ref=float(ref.reshape(-1)[worst]),
+                                            tolerance="|d| <= %g + %g |ref|" % (a_, r_), worst_err_over_tolerance=float((d / bound).max()),
+                                            within_tolerance=inside)
+        res["ok"] = res["ok"] and inside
+    if "mfcc_b" in sample:
+        mfcc_leg("B", oracle.VARIANT_B, sample["frames"], sample["mfcc_b"])
+        res["mfcc_max_abs_err"] = res["mfcc_b"]["max_abs_err"]
+        res["mfcc_tolerance"] = res["mfcc_b"]["tolerance"]
+    if "mfcc_a" in sample:
+        mfcc_leg("A", oracle.VARIANT_A, sample["frames_a"], sample["mfcc_a"])
+    if "mfcc_q15" in sample:
+        ref = oracle.mfcc_q15(sample["frames_q15"].reshape(-1), n_threads=8)[:, :sample["mfcc_q15"].shape[1]]
+        same = bool(np.array_equal(ref, sample["mfcc_q15"]))
+        res["q15"] = dict(frames_checked=int(ref.shape[0]), bit_exact=same, values_differing=int((ref != sample["mfcc_q15"]).sum()))
+        res["ok"] = res["ok"] and same
+    if "utt_audio" in sample:
+        au = sample["utt_audio"]
+        n = au.shape[0]
+        m = oracle.mfcc(au.reshape(-1), oracle.VARIANT_B, n_threads=8)[:, :13]
+        feat_ref = oracle.net_input(m).reshape(n, 403)
+        feat_gpu = sample["utt_feat"].reshape(n, 403)
+        step = np.abs(feat_gpu.astype(np.int32) - feat_ref.astype(np.int32))
+        model = oracle.Model()
+        on_gpu_feat = oracle.cnn(model, feat_gpu)
+        exact = bool(np.array_equal(on_gpu_feat["logits"], sample["utt_logits"]) and np.array_equal(on_gpu_feat["softmax"], sample["utt_softmax"])
+                     and np.array_equal(on_gpu_feat["argmax"], sample["utt_argmax"]))
+        on_ref_feat = oracle.cnn(model, feat_ref)
+        kws = dict(utterances_checked=int(n), feature_values=int(feat_ref.size), feature_flips=int((step > 0).sum()), feature_flip_max_step=int(step.max()),
+                   cnn_bit_exact_on_gpu_features=exact, argmax_flips=int((on_ref_feat["argmax"] != sample["utt_argmax"]).sum()),
+                   what="features: float64 reference arithmetic vs the GPU's fp32, rounded to int8 (a flip = fp32 on the other side of an x.5); CNN: the "
+                        "oracle's int8 restatement on the GPU's own features, logits + softmax + argmax bit for bit; argmax flips: end to end, CPU features -> CPU CNN vs the GPU")
+        if oracle.have_ref():
+            r = oracle.nnom_ref_batch(feat_gpu)
+            kws["cnn_bit_exact_vs_reference_nnom"] = bool(np.array_equal(r["logits"], sample["utt_logits"]) and np.array_equal(r["softmax"], sample["utt_softmax"])
+                                                          and np.array_equal(r["argmax"], sample["utt_argmax"]))
+            exact = exact and kws["cnn_bit_exact_vs_reference_nnom"]
+        res["kws"] = kws
+        # a feature may flip by one step on a rounding boundary (measured 0-2 per 26 000); more than one step, or more than 1 in 1000, is an error
+        res["ok"] = res["ok"] and exact and kws["feature_flip_max_step"] <= 1 and kws["feature_flips"] <= max(2, feat_ref.size // 1000)
+    res["what"] = "the outputs of the last TIMED step of each workload against the oracle on the samples that step read (bench.py parity_check)"
+    return res
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -516,7 +589,10 @@ def dry_run(args):
     n_odd = world * 7 + 1
     lo, hi = parallel.shard_range(n_odd, rank, world)
     full = torch.from_numpy(np.random.default_rng(7).integers(-128, 128, (n_odd, 10)).astype(np.int8))
-    if not torch.equal(parallel.all_gather_logits(full[lo:hi].clone(), n_total=n_odd), full):
+    odd_ok = torch.tensor([1 if torch.equal(parallel.all_gather_logits(full[lo:hi].clone(), n_total=n_odd), full) else 0], dtype=torch.int32)
+    if world > 1:
+        dist.all_reduce(odd_ok, op=dist.ReduceOp.MIN)
+    if not int(odd_ok.item()):
         good.zero_()
     if world > 1:
         dist.all_reduce(good, op=dist.ReduceOp.MIN)
@@ -527,7 +603,8 @@ def dry_run(args):
                 config=dict(workload="DRY RUN on CPU over gloo: control flow of the N > 1 bench only, no kernels, no numbers",
                             parallelism="dp%d" % world, collective="all_gather int8 logits (gloo stand-in for RCCL)"),
                 checks=dict(rccl_bindable=rccl, rccl_id_reached_every_rank=id_ok, shard_ranges_rank0=shards,
-                            gathered_logits_correct=bool(int(good.item())), ranks=world))
+                            gathered_logits_correct=bool(int(good.item())), ranks=world,
+                            unequal_shard_gather=dict(rows=n_odd, ranks=world, correct=bool(int(odd_ok.item())))))
 
     # the leg that sits behind the watchdog in the real run (the collective behind the C-ABI), rehearsed with the gloo stand-in.
     # EDISON_BENCH_CABI_HANG_S makes it sleep (on EDISON_BENCH_CABI_HANG_RANK, default every rank) as a stuck ncclCommInitRank /
@@ -559,6 +636,10 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=200.0,
                     help="untimed repetition of each workload's step before its W warm-up steps, until the clocks have settled")
     ap.add_argument("--rotate", type=int, default=3, help="distinct MFCC input batches cycled through (defeats the 256 MiB L3)")
+    ap.add_argument("--queues", type=int, default=0, choices=[0, 1, 2],
+                    help="HIP queues of the headline MFCC step. 0 (default): edison_queues_calibrate decides -- two queues (the next batch's launch in flight while "
+                         "this one drains) when a pair of the context's streams beats the serial sequence by 1 %, else one; 1: the serial sequence; 2: two queues whatever "
+                         "the calibration found")
     ap.add_argument("--skip-kws", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-stream", action="store_true")
@@ -599,26 +680,79 @@ def main():
     bufs = [synth_frames(nf, 20 + 1000 * r + rank, dev) for r in range(max(1, args.rotate))]
     out = torch.empty((nf, 13), dtype=torch.float32, device=dev)
 
+    out_b = torch.empty((nf, 13), dtype=torch.float32, device=dev)
+
     def mfcc_step(i):
         ctx.mfcc_t(bufs[i % len(bufs)], nf, 1024, _lib.MFCC_B, 13, out=out)
+    # ---- one 65 536-frame batch per launch either way; with two queues the NEXT batch's launch is in flight while this one drains
+    # (edison_queues_fork / edison_mfcc_batch_queue_dev / edison_queues_join: independent batches, own output each, alternating
+    # queues). Whether two HIP streams overlap profitably depends on where runtime and driver put their hardware queues -- a third of
+    # all stream pairs gains, a third loses 8-10 % (profiles/r05_mfcc_two_queues_notes.txt) -- so the library measures it once
+    # (edison_queues_calibrate, ~0.15 s on this batch) and the step uses two queues only if a pair beat the serial sequence.
+    outs2 = [out, out_b]
+    q_calls = [ctx.mfcc_queue_call(i & 1, bufs[i % len(bufs)], nf, 1024, _lib.MFCC_B, 13, out=outs2[i & 1]) for i in range(2 * len(bufs))]
+
+    def q_step(i):
+        q_calls[i % len(q_calls)]()
+    # Order of the first measurements, and why. (1) `serial_cold`: W + K serial steps on the board AS IT COMES -- what the headline of rounds
+    # 1-4 was (a board coming from idle runs its first ~25 launches slower than settled: profiles/r03_cold_start_notes.txt). (2) the
+    # calibration: 0.15-0.2 s of GPU work, which also wakes the board. (3) THE HEADLINE: W + K steps of the step the calibration chose.
+    # (4) `serial`: the same W + K on one queue right after it -- the board in the same state, so headline vs `serial` is the queues'
+    # doing and `serial` vs `serial_cold` is the board's. (5) `settled`, both ways.
+    calibration = serial_cold = None
+    if args.queues != 1:
+        cw_ms, cev_ms = timed_region(mfcc_step, args.steps, args.warmup, world, 0.0)
+        serial_cold = dict(value=round(world * nf / (cw_ms * 1e-3), 1), unit="frames/s", ms_per_step=round(cw_ms, 4), kernel_ms=round(cev_ms, 4),
+                           roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (cev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           what="W + K steps, one call per batch on one queue, as the FIRST GPU work of the process: the measurement that was the headline of "
+                                "rounds 1-4 (BENCH_r01-r04), before the queue calibration has run")
+        t_c = time.perf_counter()
+        calibration = ctx.queues_calibrate(bufs[0], nf)
+        calibration = dict(serial_us=round(calibration["serial_us"], 2), best_us=round(calibration["best_us"], 2), pair=calibration["pair"],
+                           seconds=round(time.perf_counter() - t_c, 3),
+                           what="edison_queues_calibrate: the serial sequence and every pair of the context's 5 candidate streams (3 least, 2 greatest priority), "
+                                "interleaved blocks of 32-64 launches of this batch; pair = the candidates kept, null = no pair was 1 % faster: one queue")
+        torch.cuda.synchronize()
+    n_queues = 2 if (args.queues == 2 or (args.queues == 0 and calibration["pair"] is not None)) else 1
+    head_step, head_kw = (q_step, dict(fork=ctx.queues_fork, join=ctx.queues_join)) if n_queues == 2 else (mfcc_step, {})
     # THE HEADLINE is what the command asked for: W warm-up + K timed steps and nothing else, measured first, on the
     # board as it comes. With the driver's small counts (W 5, K 20 = 1.5 ms) that includes the power-management transient
     # of a board that was idle; the same step after `--settle-ms` of untimed repetition is reported
     # beside it as `settled`, never as `value`.
-    wall_ms, ev_ms = timed_region(mfcc_step, args.steps, args.warmup, world, 0.0)
+    wall_ms, ev_ms = timed_region(head_step, args.steps, args.warmup, world, 0.0, **head_kw)
+    # what the LAST timed step left in its output, and the samples it read: checked against the oracle in the cpu_baseline leg (`parity`)
+    sample = {}
+    n_par = min(4096, nf)
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        last = args.warmup + args.steps - 1
+        sample["frames"] = bufs[last % len(bufs)][:n_par].cpu().numpy()
+        sample["mfcc_b"] = (outs2[last & 1] if n_queues == 2 else out)[:n_par].cpu().numpy()
     frames_per_s = world * nf / (wall_ms * 1e-3)
     ach = MFCC_BYTES_PER_FRAME * nf / (ev_ms * 1e-3) / 1e9
     roofline = dict(bound="hbm", kernel=MFCC_KERNEL, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, bytes_per_unit=MFCC_BYTES_PER_FRAME,
                     units_per_launch=nf, kernel_ms=round(ev_ms, 4))
+    if n_queues == 2:
+        roofline["kernel_ms_what"] = ("HIP-event time of the K steps / K = the pitch at which launches complete; with two launches in flight a launch's own "
+                                      "duration (what rocprofv3 --kernel-trace reports per dispatch) is about twice that -- it includes the wait for the CUs the "
+                                      "other launch still holds. `serial.kernel_ms` is the one-queue figure that rocprofv3's average agrees with.")
+    serial = None
+    if args.queues != 1:
+        sw_ms, sev1_ms = timed_region(mfcc_step, args.steps, args.warmup, world, 0.0)
+        serial = dict(value=round(world * nf / (sw_ms * 1e-3), 1), unit="frames/s", ms_per_step=round(sw_ms, 4), kernel_ms=round(sev1_ms, 4),
+                      roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (sev1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      what="the same W + K steps as one call per batch on ONE queue (edison_mfcc_batch_dev), measured right after the headline (same board state)")
     settled = None
     if args.settle_ms > 0:
-        s_ms, sev_ms = timed_region(mfcc_step, args.steps, args.warmup, world, args.settle_ms)
+        s_ms, sev_ms = timed_region(head_step, args.steps, args.warmup, world, args.settle_ms, **head_kw)
         settled = dict(value=round(world * nf / (s_ms * 1e-3), 1), unit="frames/s", ms_per_step=round(s_ms, 4), kernel_ms=round(sev_ms, 4),
                        roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (sev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), settle_ms=args.settle_ms,
                        what="the same workload after settle_ms of untimed repetition of the step in front of the W warm-up steps (clocks and "
                             "power settled); a side figure, the headline is the W + K run above")
-    checksum = float(out.double().sum().item())
+        if n_queues == 2:
+            s1_ms, s1ev_ms = timed_region(mfcc_step, args.steps, args.warmup, world, args.settle_ms)
+            settled["serial"] = dict(value=round(world * nf / (s1_ms * 1e-3), 1), ms_per_step=round(s1_ms, 4), kernel_ms=round(s1ev_ms, 4),
+                                     roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (s1ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     # ---- the same batches, several per launch (edison_mfcc_rows_dev: batches that sit at a constant stride are the rows of ONE launch).
     # The 65 536-frame launch above pays per launch what a longer one amortises -- 2.4 us until the median wave computes, then
     # waves leaving over 4-5 us at the end: 15 % of the launch window idle, of which the power manager gives ~6 % back as clock
@@ -643,10 +777,88 @@ def main():
     except Exception as e:  # a side figure must never cost the headline numbers
         rows_launch = dict(error=repr(e))
 
+    # ---- ... and as a LIST of independent batches (edison_mfcc_batches_dev, round 5): separate allocations, own output each, no common
+    # stride -- what a caller has whose batches come from different producers. Same loop, one launch per list.
+    batch_list = None
+    try:
+        n_b = 8
+        pads, ins, outs_l = [], [], []
+        for b in range(n_b):
+            pads.append(torch.empty((4099 * (b + 1),), dtype=torch.int8, device=dev))   # keeps the allocations from lining up
+            ins.append(bufs[b % len(bufs)].clone())
+            outs_l.append(torch.empty((nf, 13), dtype=torch.float32, device=dev))
+
+        def list_step(i):
+            ctx.mfcc_batches_t(ins, nf, 1024, _lib.MFCC_B, 13, outs=outs_l)
+        l_ms, lev_ms = timed_region(list_step, max(20, args.steps // n_b), max(3, min(args.warmup, 2000) // n_b), world, args.settle_ms)
+        ctx.mfcc_t(ins[n_b - 1], nf, 1024, _lib.MFCC_B, 13, out=out)
+        same_l = bool(torch.equal(out, outs_l[n_b - 1]))
+        batch_list = dict(batches_per_launch=n_b, value=round(world * n_b * nf / (l_ms * 1e-3), 1), unit="frames/s", ms_per_launch=round(l_ms, 4),
+                          us_per_65536_frames=round(lev_ms * 1e3 / n_b * 65536 / nf, 2),
+                          roofline_frac=round(MFCC_BYTES_PER_FRAME * n_b * nf / (lev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          outputs_bit_identical_to_one_call_per_batch=same_l,
+                          what="%d independent batches of %d frames (separate allocations, own outputs) as ONE edison_mfcc_batches_dev launch (settled); kernel ed_mfcc2_list_kernel<true, 2, 5>" % (n_b, nf))
+        del pads, ins, outs_l
+    except Exception as e:  # a side figure must never cost the headline numbers
+        batch_list = dict(error=repr(e))
+
+    # ---- two queues against one, interleaved (8 blocks of 300 batches each, medians): the evidence behind `config.queues`, whatever the
+    # calibration chose. The library's own two queues (the calibrated pair, or one stream of each priority without a calibration).
+    two_queues = None
+    try:
+        ctx.queues_fork()
+        for i in range(4):
+            q_step(i)
+        ctx.queues_join()
+        ref_o = torch.empty((nf, 13), dtype=torch.float32, device=dev)
+        ctx.mfcc_t(bufs[2 % len(bufs)], nf, 1024, _lib.MFCC_B, 13, out=ref_o)
+        same = bool(torch.equal(outs2[0], ref_o))
+        ctx.mfcc_t(bufs[3 % len(bufs)], nf, 1024, _lib.MFCC_B, 13, out=ref_o)
+        same = same and bool(torch.equal(outs2[1], ref_o))
+        torch.cuda.synchronize()
+        n2 = 300     # batches per timed block; a 40-batch block of this step scatters by +-5 %
+
+        def block(step, two):
+            for i in range(30):
+                if not two:
+                    step(i)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            if two:
+                ctx.queues_fork()
+            for i in range(n2):
+                step(i)
+            if two:
+                ctx.queues_join()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n2
+        t_end = time.perf_counter() + 0.2           # settle the clocks on the serial step
+        while time.perf_counter() < t_end:
+            for i in range(256):
+                mfcc_step(i)
+            torch.cuda.synchronize()
+        ts2, ts1 = [], []
+        for r in range(8):
+            for leg in ((1, 2) if r % 2 == 0 else (2, 1)):
+                (ts2 if leg == 2 else ts1).append(block(q_step, True) if leg == 2 else block(mfcc_step, False))
+        t2, t1 = sorted(ts2)[len(ts2) // 2], sorted(ts1)[len(ts1) // 2]
+        two_queues = dict(queues=2, ms_per_batch=round(t2, 4), serial_ms_per_batch=round(t1, 4), vs_serial=round(t1 / t2, 4),
+                          value=round(world * nf / (t2 * 1e-3), 1), unit="frames/s", outputs_bit_identical_to_serial=same,
+                          roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          what="one %d-frame batch per launch, own output each, launches alternating over the context's two queues (edison_queues_fork / "
+                               "edison_mfcc_batch_queue_dev / edison_queues_join); medians of 8 interleaved blocks of %d batches each, settled, the serial control beside it" % (nf, n2))
+        del ref_o
+    except Exception as e:  # a side figure must never cost the headline numbers
+        two_queues = dict(error=repr(e))
+
     # ------------------------------------------------------------------ variant A (log-mel, mfcc_utils.mfcc), same batch
     def mfcc_a_step(i):
         ctx.mfcc_t(bufs[i % len(bufs)], nf, 1024, _lib.MFCC_A, 13, out=out)
     a_ms, aev_ms = timed_region(mfcc_a_step, args.steps, args.warmup, world, args.settle_ms)
+    if sample:
+        sample["frames_a"] = bufs[(args.warmup + args.steps - 1) % len(bufs)][:n_par].cpu().numpy()
+        sample["mfcc_a"] = out[:n_par].cpu().numpy()
     variant_a = dict(metric="MFCC frames/sec, variant A (ln + DCT, mfcc_utils.mfcc)", unit="frames/s",
                      value=round(world * nf / (a_ms * 1e-3), 1), ms_per_step=round(a_ms, 4), kernel_ms=round(aev_ms, 4),
                      roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (aev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
@@ -659,6 +871,9 @@ def main():
         def q15_step(i):
             ctx.mfcc_q15_t(bufs[i % len(bufs)], nf, 1024, 13, out=out16)
         q_ms, qev_ms = timed_region(q15_step, args.steps, args.warmup, world, args.settle_ms)
+        if sample:
+            sample["frames_q15"] = bufs[(args.warmup + args.steps - 1) % len(bufs)][:n_par].cpu().numpy()
+            sample["mfcc_q15"] = out16[:n_par].cpu().numpy()
         qbytes = 2048 + 13 * 2
         qach = qbytes * nf / (qev_ms * 1e-3) / 1e9
         q15 = dict(metric="MFCC frames/sec, variant C (firmware Q15 arithmetic, bit-exact)", unit="frames/s",
@@ -667,7 +882,7 @@ def main():
                    roofline=dict(bound="hbm", kernel="ed_mfcc_q15_kernel<false>", achieved=round(qach, 1), peak=HBM_PEAK_GBS,
                                  unit="GB/s", frac=round(qach / HBM_PEAK_GBS, 4), traffic=None, bytes_per_unit=qbytes,
                                  units_per_launch=nf, kernel_ms=round(qev_ms, 4)),
-                   checksum=int(out16.to(torch.int64).sum().item()))
+                   )
         q15["roofline"]["kernel"] = "ed_mfcc_q15_kernel<false, true, 6, 18>"
         qtr = hbm_traffic_from_profiles("ed_mfcc_q15_kernel<false, true, 6, 18>:short") if nf == 65536 else None
         if qtr is not None:
@@ -691,7 +906,7 @@ def main():
         md.close()
     except Exception as e:  # an extra workload must never cost the headline numbers
         variant_d = dict(error=repr(e))
-    del bufs
+    del bufs, q_calls, outs2
     # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
     # this command, FETCH_SIZE doubled as the gfx950 guide prescribes); only valid for the default batch size
     tr = hbm_traffic_from_profiles(MFCC_KERNEL + ":short") if nf == 65536 else None
@@ -725,6 +940,11 @@ def main():
         # 7 ms steps: up to 50 warm-up steps = 0.35 s. No time-based settle phase here: for N > 1 the step ends in a
         # collective, and ranks must execute the same number of steps.
         kw_ms, kev_ms = timed_region(kws_step, args.steps, min(args.warmup, 50), world)
+        if sample:
+            n_pu = min(128, nu)
+            sample["utt_audio"] = audio[:n_pu].cpu().numpy()
+            sample["utt_feat"], sample["utt_logits"] = feat[:n_pu].cpu().numpy(), logits[:n_pu].cpu().numpy()
+            sample["utt_softmax"], sample["utt_argmax"] = soft[:n_pu].cpu().numpy(), am[:n_pu].cpu().numpy()
         inf_per_s = world * nu / (kw_ms * 1e-3)
         kach = KWS_BYTES_PER_UTT * nu / (kev_ms * 1e-3) / 1e9
         hist = torch.bincount(am.to(torch.int64), minlength=10).tolist()
@@ -735,7 +955,10 @@ def main():
                    roofline=dict(bound="hbm", kernel=MFCC_KERNEL_KWS + " + ed_cnn_mfma_kernel", achieved=round(kach, 1),
                                  peak=HBM_PEAK_GBS, unit="GB/s", frac=round(kach / HBM_PEAK_GBS, 4), traffic=None,
                                  bytes_per_unit=KWS_BYTES_PER_UTT, units_per_launch=nu, kernel_ms=round(kev_ms, 4)),
-                   class_histogram=hist)
+                   class_histogram=hist,
+                   # which gather `value` used: the product's own (edison_kws_batch_sharded_dev: ncclAllGather behind the C-ABI) is the
+                   # guarded leg at the end of the run; when that leg returns ok its figure is `value_cabi` right here
+                   collective_path="torch.distributed" if world > 1 else "none (one rank: nothing to gather)")
         # HBM bytes of the step's dominant kernel (the MFCC over 8.1 M frames: 95 % of the step) from the committed PMC pass;
         # the CNN adds 403 B read + 24 B written per utterance (its counters: kws.cnn.roofline.counters)
         ktr = hbm_traffic_from_profiles(MFCC_KERNEL_KWS + ":long") if nu == 262144 else None
@@ -806,12 +1029,16 @@ def main():
         streaming = stream_bench(ctx, dev)
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.skip_cpu:
         try:
             cpu = cpu_baseline()
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU numbers
             cpu = dict(error=repr(e))
+        try:
+            parity = parity_check(sample)
+        except Exception as e:  # noqa: BLE001 -- a checker that cannot run is reported as such and fails the run
+            parity = dict(ok=False, error=repr(e))
 
     line = None
     exit_code = 0
@@ -821,12 +1048,27 @@ def main():
                     ms_per_step=round(wall_ms, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                     dtype="f32", data="synthetic",
                     config=dict(workload="mfcc_batch_%dx1024_int16_per_gpu_variantB_13coef" % nf, global_batch=world * nf,
-                                frame_len=1024, parallelism="dp%d" % world, rotate_buffers=args.rotate),
-                    roofline=roofline, device=info["name"], checksum=checksum)
+                                frame_len=1024, parallelism="dp%d" % world, rotate_buffers=args.rotate, queues=n_queues),
+                    roofline=roofline, device=info["name"])
+        if parity is not None:
+            line["parity"] = parity
+            if not parity.get("ok"):
+                print("bench.py: the timed batch does NOT agree with the oracle: %s" % json.dumps(parity), file=sys.stderr, flush=True)
+                exit_code = 5
+        if serial is not None:
+            line["serial"] = serial
+        if serial_cold is not None:
+            line["serial_cold"] = serial_cold
+        if calibration is not None:
+            line["queue_calibration"] = calibration
         if settled is not None:
             line["settled"] = settled
         if rows_launch is not None:
             line["rows_launch"] = rows_launch
+        if batch_list is not None:
+            line["batch_list"] = batch_list
+        if two_queues is not None:
+            line["two_queues"] = two_queues
         line["mfcc_variant_a"] = variant_a
         if variant_d is not None:
             line["mfcc_variant_d"] = variant_d
@@ -879,6 +1121,9 @@ def main():
         cabi = guarded_leg(rank, line, line["kws"] if rank == 0 else {}, cabi_leg, float(os.environ.get("EDISON_BENCH_WATCHDOG_S", "120")))
         if rank == 0:
             line["kws"]["cabi_collective"] = cabi
+            if cabi.get("status", "").startswith("ok") and "value" in cabi:
+                line["kws"]["value_cabi"] = cabi["value"]            # the product's path: shard scoring + ncclAllGather in one C call
+                line["kws"]["ms_per_step_cabi"] = cabi["ms_per_step"]
         # the line is printed either way (the figures above do not depend on this leg), but a collective behind the C-ABI that
         # failed or disagreed on ANY rank is a failed run: every rank learns it and leaves non-zero after the line
         bad = torch.tensor([0 if cabi["status"].startswith(("ok", "not available")) else 1], dtype=torch.int32, device=dev)

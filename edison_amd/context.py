@@ -263,6 +263,48 @@ class Context:
         self._check(self._L.edison_mfcc_rows_dev(self._h, _t_ptr(audio), int(n_rows), int(row_stride), int(frames_per_row), int(frame_step),
                                                  variant, int(n_coef), _t_ptr(out), _t_ptr(feat), float(feat_scale)))
 
+    def mfcc_batches_t(self, audios, n_frames_each, frame_step=FRAME_LEN, variant=MFCC_B, n_coef=NUM_MFCC, outs=None, feats=None,
+                       feat_scale=1.0, use_log=False):
+        """edison_mfcc_batches_dev: a LIST of independent batches (int16 CUDA tensors at any addresses) with their own outputs (lists of
+        fp32 / int8 tensors [n_frames_each, n_coef], or None), ONE launch per 16 batches."""
+        n = len(audios)
+        arr = (ctypes.c_void_p * n)
+        a = arr(*[t.data_ptr() for t in audios])
+        o = arr(*[t.data_ptr() for t in outs]) if outs is not None else None
+        f = arr(*[t.data_ptr() for t in feats]) if feats is not None else None
+        v = variant | (MFCC_USE_LOG if use_log else 0)
+        self._check(self._L.edison_mfcc_batches_dev(self._h, n, a, int(n_frames_each), int(frame_step), v, int(n_coef), o, f, float(feat_scale)))
+
+    def queues_calibrate(self, audio, n_frames, frame_step=FRAME_LEN, variant=MFCC_B):
+        """edison_queues_calibrate on a representative batch (int16 CUDA tensor): dict(serial_us, best_us, pair) -- pair None when no pair
+        of streams beat the serial sequence by 1 % (the queue calls then run serially)."""
+        su, bu, pk = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        self._check(self._L.edison_queues_calibrate(self._h, _t_ptr(audio), int(n_frames), int(frame_step), int(variant), ctypes.byref(su), ctypes.byref(bu),
+                                                    ctypes.byref(pk)))
+        return dict(serial_us=su.value, best_us=bu.value, pair=(pk.value // 10, pk.value % 10) if pk.value else None)
+
+    def queues_fork(self):
+        """Both of the context's two queues start behind the context's stream (edison_queues_fork)."""
+        self._check(self._L.edison_queues_fork(self._h))
+
+    def queues_join(self):
+        self._check(self._L.edison_queues_join(self._h))
+
+    def mfcc_queue_call(self, queue, audio, n_frames, frame_step=FRAME_LEN, variant=MFCC_B, n_coef=NUM_MFCC, out=None, feat=None, feat_scale=1.0):
+        """A prepared edison_mfcc_batch_queue_dev call: returns a function of no arguments that enqueues THIS batch on `queue` (0 / 1)
+        between queues_fork() and queues_join(). The ctypes arguments are converted once: a Python host spends ~10 us per call
+        this way instead of ~25, which is what keeping two queues fed takes (the GPU needs ~45 us per 65 536-frame batch)."""
+        fn = self._L.edison_mfcc_batch_queue_dev
+        args = (self._h, ctypes.c_int(int(queue)), _t_ptr(audio), ctypes.c_int64(int(n_frames)), ctypes.c_int64(int(frame_step)), ctypes.c_int(int(variant)),
+                ctypes.c_int(int(n_coef)), _t_ptr(out), _t_ptr(feat), ctypes.c_float(float(feat_scale)))
+        keep = (audio, out, feat)
+
+        def call(_keep=keep):
+            r = fn(*args)
+            if r != _lib.OK:
+                self._check(r)
+        return call
+
     def cnn_t(self, feat, n_utt, logits=None, softmax=None, argmax=None):
         self._check(self._L.edison_cnn_batch_dev(self._h, _t_ptr(feat), int(n_utt), _t_ptr(logits), _t_ptr(softmax),
                                                  _t_ptr(argmax)))

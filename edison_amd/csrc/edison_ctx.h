@@ -13,6 +13,8 @@
 
 extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
                               hipStream_t stream);
+extern "C" int ed_launch_mfcc_list(const ed_mfcc_args_t *args, const ed_mfcc_list_t *list, int n_batches, const ed_mfcc_tables_t *dev_tab, int n_cu,
+                                   hipStream_t stream);
 extern "C" int ed_launch_cnn(const ed_cnn_model_t *dev_model, const int8_t *feat, int64_t n_utt, int8_t *logits,
                              int8_t *softmax, int32_t *argmax, int8_t *acts, int n_cu, hipStream_t stream);
 extern "C" int ed_launch_cnn_mfma(const ed_cnn_mfma_model_t *dev_model, const int8_t *feat, int64_t n_utt,
@@ -75,6 +77,15 @@ struct edison_ctx
 	/* multi-GPU (edison_dist.hip): the RCCL communicator this context belongs to, NULL for a single-GPU context */
 	void *dist_comm;
 	int dist_rank, dist_world;
+	/* two library-owned HIP queues for independent batches (edison_queues_fork / edison_mfcc_batch_queue_dev / edison_queues_join):
+	 * created at the first fork with DIFFERENT priorities, i.e. on different hardware queues by construction (HIP shares a pool of
+	 * hardware queues among the streams of one priority) */
+	hipStream_t pipe_q[2];       /* the pair in use (two of pipe_cand, or twice the same one after a calibration that found no winning pair) */
+	hipStream_t pipe_cand[5];    /* candidates: 3 of the least, 2 of the greatest priority */
+	hipEvent_t pipe_fork, pipe_join[2], pipe_t0, pipe_t1;
+	int pipe_ready, pipe_forked;
+	int pipe_pair[2];            /* indices into pipe_cand */
+	double pipe_cal_serial_us, pipe_cal_best_us; /* edison_queues_calibrate's findings (0: never calibrated) */
 	void *dist_scratch; /* padded send + receive blocks of edison_dist_allgather_logits_total (unequal shards) */
 	size_t dist_scratch_bytes;
 	char err[512];

@@ -140,6 +140,12 @@ extern "C" void edison_shutdown(edison_ctx *ctx)
 	if (ctx->d_mm_frag) (void)hipFree(ctx->d_mm_frag);
 	if (ctx->d_mm_seeds) (void)hipFree(ctx->d_mm_seeds);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
+	if (ctx->pipe_ready)
+	{
+		for (int k = 0; k < 5; k++) (void)hipStreamDestroy(ctx->pipe_cand[k]);
+		for (int k = 0; k < 2; k++) (void)hipEventDestroy(ctx->pipe_join[k]);
+		(void)hipEventDestroy(ctx->pipe_fork); (void)hipEventDestroy(ctx->pipe_t0); (void)hipEventDestroy(ctx->pipe_t1);
+	}
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	free(ctx);
 }
@@ -480,6 +486,214 @@ extern "C" int edison_mfcc_rows_dev(edison_ctx *ctx, const int16_t *audio, int64
 	                   feat_scale, 0, NULL, NULL, NULL, NULL);
 }
 
+/* Up to 16 INDEPENDENT batches -- any addresses, own outputs -- per launch; more than 16 go out as several launches. Variants A, B
+ * (+ USE_LOG) on the two-frame kernel; the batches of one call share n_frames_each, frame_step, variant, n_coef and feat_scale. */
+extern "C" int edison_mfcc_batches_dev(edison_ctx *ctx, int n_batches, const int16_t *const *audio, int64_t n_frames_each, int64_t frame_step,
+                                       int variant, int n_coef, float *const *mfcc, int8_t *const *feat, float feat_scale)
+{
+	const int v = variant & 0xff;
+	if (!ctx || n_batches < 0 || (n_batches > 0 && !audio) || n_frames_each < 0 || frame_step < 0) return EDISON_E_ARGUMENT;
+	if (v != EDISON_MFCC_A && v != EDISON_MFCC_B) return set_err(ctx, EDISON_E_NO_IMPL, "edison_mfcc_batches_dev: variants A and B (the other variants: one call per batch)");
+	if (n_coef < 1 || n_coef > EDISON_NUM_MEL) return set_err(ctx, EDISON_E_ARGUMENT, "n_coef must be 1..32");
+	if (n_batches == 0 || n_frames_each == 0) return EDISON_OK;
+	if (n_frames_each > INT32_MAX / ED_MFCC_LIST_MAX) return set_err(ctx, EDISON_E_SIZE, "edison_mfcc_batches_dev: more than 2^31 frames in one launch");
+	for (int b = 0; b < n_batches; b++)
+		if (!audio[b] || (mfcc && !mfcc[b]) || (feat && !feat[b])) return set_err(ctx, EDISON_E_ARGUMENT, "edison_mfcc_batches_dev: a NULL pointer in a batch list");
+	for (int b0 = 0; b0 < n_batches; b0 += ED_MFCC_LIST_MAX)
+	{
+		const int nb = n_batches - b0 < ED_MFCC_LIST_MAX ? n_batches - b0 : ED_MFCC_LIST_MAX;
+		ed_mfcc_list_t list;
+		memset(&list, 0, sizeof(list));
+		for (int b = 0; b < nb; b++)
+		{
+			list.audio[b] = audio[b0 + b];
+			list.mfcc[b] = mfcc ? mfcc[b0 + b] : NULL;
+			list.feat[b] = feat ? feat[b0 + b] : NULL;
+		}
+		ed_mfcc_args_t a;
+		memset(&a, 0, sizeof(a));
+		a.audio = list.audio[0]; a.n_frames = (int64_t)nb * n_frames_each; a.frames_per_group = n_frames_each; a.group_stride = 0;
+		a.frame_step = frame_step; a.n_coef = n_coef; a.use_log = (variant & EDISON_MFCC_USE_LOG) ? 1 : 0;
+		a.mel_NLO = ctx->mel_NLO[v];
+		a.mel_NHI = ctx->mel_NHI[v];
+		a.mfcc = list.mfcc[0]; a.feat = list.feat[0]; a.feat_scale = feat_scale; /* flags: which outputs the launch writes */
+		const int e = ed_launch_mfcc_list(&a, &list, nb, ctx->d_tab[v], ctx->n_cu, ctx->stream);
+		if (e != 0)
+		{
+			snprintf(ctx->err, sizeof(ctx->err), "MFCC list kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+			return EDISON_E_RUNTIME;
+		}
+	}
+	return EDISON_OK;
+}
+
+struct dev_buf
+{
+	void *p;
+	dev_buf() : p(NULL) {}
+	~dev_buf() { if (p) (void)hipFree(p); }
+	hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+
+/* ---- two queues for independent batches: the NEXT launch is in flight while this one drains -------------------------------------
+ * A 65 536-frame launch idles ~15 % of its window (256 workgroups starting up, waves leaving over the last pair time) and the next
+ * launch of the same queue starts only when this one has completed. On a second hardware queue the next launch's workgroups are
+ * dispatched onto CUs as this launch's leave them. Worth +4 ... 5 % from a host that keeps both queues fed (a C host: 47.7 -> 45.7 us
+ * per batch; profiles/r05_mfcc_two_queues_notes.txt), nothing when the host needs as long per call as the GPU per batch. */
+static int pipe_setup(edison_ctx *ctx)
+{
+	if (ctx->pipe_ready) return EDISON_OK;
+	ED_HIP(ctx, hipSetDevice(ctx->device));
+	int least = 0, greatest = 0;
+	ED_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+	hipError_t e = hipSuccess;
+	for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipStreamCreateWithPriority(&ctx->pipe_cand[k], hipStreamNonBlocking, k < 3 ? least : greatest);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipe_fork, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipe_join[0], hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipe_join[1], hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreate(&ctx->pipe_t0);
+	if (e == hipSuccess) e = hipEventCreate(&ctx->pipe_t1);
+	ED_HIP(ctx, e);
+	/* until a calibration says otherwise: one stream of each priority -- different hardware queues by construction */
+	ctx->pipe_pair[0] = 0; ctx->pipe_pair[1] = 3;
+	ctx->pipe_q[0] = ctx->pipe_cand[0]; ctx->pipe_q[1] = ctx->pipe_cand[3];
+	ctx->pipe_ready = 1;
+	return EDISON_OK;
+}
+
+extern "C" int edison_queues_fork(edison_ctx *ctx)
+{
+	if (!ctx) return EDISON_E_ARGUMENT;
+	{ const int r = pipe_setup(ctx); if (r != EDISON_OK) return r; }
+	/* both queues start behind everything the caller's stream holds so far (the producers of the batches) */
+	ED_HIP(ctx, hipEventRecord(ctx->pipe_fork, ctx->stream));
+	ED_HIP(ctx, hipStreamWaitEvent(ctx->pipe_q[0], ctx->pipe_fork, 0));
+	ED_HIP(ctx, hipStreamWaitEvent(ctx->pipe_q[1], ctx->pipe_fork, 0));
+	ctx->pipe_forked = 1;
+	return EDISON_OK;
+}
+
+extern "C" int edison_queues_join(edison_ctx *ctx)
+{
+	if (!ctx) return EDISON_E_ARGUMENT;
+	if (!ctx->pipe_forked) return EDISON_OK;
+	for (int k = 0; k < 2; k++)
+	{
+		ED_HIP(ctx, hipEventRecord(ctx->pipe_join[k], ctx->pipe_q[k]));
+		ED_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_join[k], 0));
+	}
+	ctx->pipe_forked = 0;
+	return EDISON_OK;
+}
+
+/* `n` launches of the caller's batch, alternating over streams a and b (a == b: the serial sequence), timed with events on the
+ * context's stream around a fork / join; microseconds per launch */
+static int pipe_time_pair(edison_ctx *ctx, hipStream_t a, hipStream_t b, const int16_t *audio, int64_t n_frames, int64_t frame_step, int variant,
+                          float *const out[2], int n, double *us)
+{
+	hipStream_t q[2] = {a, b};
+	for (int timed = 0; timed < 2; timed++)
+	{
+		ED_HIP(ctx, hipEventRecord(timed ? ctx->pipe_t0 : ctx->pipe_fork, ctx->stream));
+		for (int k = 0; k < 2; k++) ED_HIP(ctx, hipStreamWaitEvent(q[k], timed ? ctx->pipe_t0 : ctx->pipe_fork, 0));
+		const int m = timed ? n : 6;
+		for (int i = 0; i < m; i++)
+		{
+			const int r = mfcc_launch_on(ctx, q[i & 1], audio, n_frames, n_frames, 0, frame_step, variant, EDISON_NUM_MFCC, out[i & 1], NULL, 1.0f, 0, NULL, NULL, NULL, NULL);
+			if (r != EDISON_OK) return r;
+		}
+		for (int k = 0; k < 2; k++)
+		{
+			ED_HIP(ctx, hipEventRecord(ctx->pipe_join[k], q[k]));
+			ED_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_join[k], 0));
+		}
+	}
+	ED_HIP(ctx, hipEventRecord(ctx->pipe_t1, ctx->stream));
+	ED_HIP(ctx, hipEventSynchronize(ctx->pipe_t1));
+	float ms = 0;
+	ED_HIP(ctx, hipEventElapsedTime(&ms, ctx->pipe_t0, ctx->pipe_t1));
+	*us = (double)ms * 1e3 / n;
+	return EDISON_OK;
+}
+
+static double median_of(double *v, int n)
+{
+	for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) if (v[j] < v[i]) { const double t = v[i]; v[i] = v[j]; v[j] = t; }
+	return v[n / 2];
+}
+
+/* Which two of the context's candidate streams let two launches of THIS workload overlap profitably -- if any. Whether the next
+ * launch backfills the CUs this one leaves depends on where the runtime and the driver put the streams' hardware queues, which
+ * nothing in the HIP API controls: of all pairs of nine streams in one process about a third gained (+1 % on a box whose serial launch
+ * takes 43.5 us, +4 ... 7 % on boxes at 47-48 us), a third changed nothing and a third LOST 8-10 % (profiles/r05_mfcc_two_queues_notes.txt).
+ * So the library measures: every pair of its five candidates and the serial sequence, interleaved, on the caller's own batch (device
+ * pointer, read only; outputs go to scratch), then the winner against the serial sequence once more; it keeps the pair only if it
+ * is at least 1 % faster, otherwise both queue indices mean ONE stream and the queue calls are the serial sequence. ~0.1 s. */
+extern "C" int edison_queues_calibrate(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step, int variant,
+                                       double *serial_us, double *best_us, int *pair_kept)
+{
+	if (!ctx || !audio || n_frames < 1 || frame_step < 0) return EDISON_E_ARGUMENT;
+	if (ctx->pipe_forked) return set_err(ctx, EDISON_E_ARGUMENT, "edison_queues_calibrate between fork and join");
+	const int v = variant & 0xff;
+	if (v != EDISON_MFCC_A && v != EDISON_MFCC_B) return set_err(ctx, EDISON_E_NO_IMPL, "edison_queues_calibrate: variants A and B");
+	{ const int r = pipe_setup(ctx); if (r != EDISON_OK) return r; }
+	dev_buf o0, o1;
+	const size_t ob = (size_t)n_frames * EDISON_NUM_MFCC * sizeof(float);
+	ED_HIP(ctx, o0.alloc(ob));
+	ED_HIP(ctx, o1.alloc(ob));
+	float *const out[2] = {(float *)o0.p, (float *)o1.p};
+	enum { NC = 5, NP = NC * (NC - 1) / 2, ROUNDS = 5, LAUNCHES = 32 };
+	int pa[NP + 1], pb[NP + 1], np = 0;
+	pa[np] = 0; pb[np] = 0; np++;                                  /* entry 0: the serial sequence */
+	for (int i = 0; i < NC; i++) for (int j = i + 1; j < NC; j++) { pa[np] = i; pb[np] = j; np++; }
+	double t[NP + 1][ROUNDS];
+	for (int r = 0; r < ROUNDS; r++)
+		for (int k0 = 0; k0 < np; k0++)
+		{
+			const int k = (r & 1) ? np - 1 - k0 : k0;                 /* interleaved, the order reversed every other round */
+			const int rc = pipe_time_pair(ctx, ctx->pipe_cand[pa[k]], ctx->pipe_cand[pb[k]], audio, n_frames, frame_step, variant, out, LAUNCHES, &t[k][r]);
+			if (rc != EDISON_OK) return rc;
+		}
+	const double serial = median_of(t[0], ROUNDS);
+	int best = 0;
+	double best_t = serial;
+	for (int k = 1; k < np; k++) { const double m = median_of(t[k], ROUNDS); if (m < best_t) { best_t = m; best = k; } }
+	int keep = 0;
+	double s2 = serial, b2 = best_t;
+	if (best > 0)
+	{
+		/* the winner against the serial sequence once more, longer: a pair that won on noise does not win twice */
+		double ts[ROUNDS], tb[ROUNDS];
+		for (int r = 0; r < ROUNDS; r++)
+		{
+			int rc = pipe_time_pair(ctx, ctx->pipe_cand[0], ctx->pipe_cand[0], audio, n_frames, frame_step, variant, out, 2 * LAUNCHES, &ts[r]);
+			if (rc == EDISON_OK) rc = pipe_time_pair(ctx, ctx->pipe_cand[pa[best]], ctx->pipe_cand[pb[best]], audio, n_frames, frame_step, variant, out, 2 * LAUNCHES, &tb[r]);
+			if (rc != EDISON_OK) return rc;
+		}
+		s2 = median_of(ts, ROUNDS); b2 = median_of(tb, ROUNDS);
+		keep = b2 < 0.99 * s2;
+	}
+	ctx->pipe_pair[0] = keep ? pa[best] : 0;
+	ctx->pipe_pair[1] = keep ? pb[best] : 0;
+	ctx->pipe_q[0] = ctx->pipe_cand[ctx->pipe_pair[0]];
+	ctx->pipe_q[1] = ctx->pipe_cand[ctx->pipe_pair[1]];
+	ctx->pipe_cal_serial_us = s2; ctx->pipe_cal_best_us = keep ? b2 : s2;
+	if (serial_us) *serial_us = s2;
+	if (best_us) *best_us = keep ? b2 : s2;
+	if (pair_kept) *pair_kept = keep ? 10 * pa[best] + pb[best] : 0;
+	ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return EDISON_OK;
+}
+
+extern "C" int edison_mfcc_batch_queue_dev(edison_ctx *ctx, int queue, const int16_t *audio, int64_t n_frames, int64_t frame_step,
+                                           int variant, int n_coef, float *mfcc, int8_t *feat, float feat_scale)
+{
+	if (!ctx || queue < 0 || queue > 1) return EDISON_E_ARGUMENT;
+	if (!ctx->pipe_forked) return set_err(ctx, EDISON_E_ARGUMENT, "edison_mfcc_batch_queue_dev outside edison_queues_fork ... edison_queues_join");
+	return mfcc_launch_on(ctx, ctx->pipe_q[queue], audio, n_frames, n_frames > 0 ? n_frames : 1, 0, frame_step, variant, n_coef, mfcc, feat, feat_scale,
+	                      0, NULL, NULL, NULL, NULL);
+}
+
 extern "C" int edison_mfcc_stages_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step,
                                       int variant, float *fft, float *spec, float *mel, float *logmel, float *mfcc32)
 {
@@ -614,13 +828,6 @@ extern "C" int edison_kws_batch_q15_dev(edison_ctx *ctx, const int16_t *audio, i
 }
 
 /* ---------------------------------------------------------------------------------------- hot path, host  */
-struct dev_buf
-{
-	void *p;
-	dev_buf() : p(NULL) {}
-	~dev_buf() { if (p) (void)hipFree(p); }
-	hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
-};
 
 #define ED_UP(ctx, dst, src, n) ED_HIP(ctx, hipMemcpyAsync((dst), (src), (n), hipMemcpyHostToDevice, (ctx)->stream))
 #define ED_DOWN(ctx, dst, src, n) \

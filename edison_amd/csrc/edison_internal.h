@@ -404,6 +404,17 @@ typedef struct {
 	float *fft, *spec, *mel, *logmel;
 } ed_mfcc_args_t;
 
+/* Batches of a list launch (edison_mfcc_batches_dev): up to ED_MFCC_LIST_MAX independent batches of the same frame count, each at its
+ * own address with its own outputs, as the groups of ONE launch -- group g's samples start at audio[g], its rows at mfcc[g] / feat[g].
+ * Passed by value as the list kernel's third argument (kernarg memory: a uniform index is one scalar load). */
+#define ED_MFCC_LIST_MAX 16
+typedef struct {
+	const int16_t *audio[ED_MFCC_LIST_MAX];
+	float *mfcc[ED_MFCC_LIST_MAX];
+	int8_t *feat[ED_MFCC_LIST_MAX];
+} ed_mfcc_list_t;
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,9 +135,11 @@ __device__ __forceinline__ unsigned long long ed2_now()
 #endif
 
 /* The two frames of pair `pr`: A = 2 pr, B = 2 pr + 1 (the last pair of an odd batch repeats A). PLAIN: one group, frame f
- * starts at f * frame_step; otherwise f = (g, i) with ONE division per pair, B follows A by increment. */
-template <bool PLAIN>
-__device__ __forceinline__ void ed_pair_ptrs(const ed_mfcc_args_t &a, uint32_t pr, const int16_t *&pa, const int16_t *&pb)
+ * starts at f * frame_step; otherwise f = (g, i) with ONE division per pair, B follows A by increment. LIST: group g's first frame
+ * is list->audio[g] instead of audio + g * group_stride; (g, i) of frame A are handed back for the store. */
+template <bool PLAIN, bool LIST>
+__device__ __forceinline__ void ed_pair_ptrs(const ed_mfcc_args_t &a, const ed_mfcc_list_t *list, uint32_t pr, const int16_t *&pa, const int16_t *&pb,
+                                             uint32_t &g_out, uint32_t &i_out)
 {
 	const uint32_t fA = 2 * pr;
 	const bool haveB = fA + 1 < (uint32_t)a.n_frames;
@@ -150,8 +152,17 @@ __device__ __forceinline__ void ed_pair_ptrs(const ed_mfcc_args_t &a, uint32_t p
 	{
 		const uint32_t fpg = (uint32_t)a.frames_per_group;
 		const uint32_t g = fA / fpg, i = fA - g * fpg;
-		pa = a.audio + ((int64_t)g * a.group_stride + (int64_t)i * a.frame_step);
-		pb = !haveB ? pa : (i + 1 < fpg ? pa + a.frame_step : a.audio + (int64_t)(g + 1) * a.group_stride);
+		if (LIST)
+		{
+			pa = list->audio[g] + (int64_t)i * a.frame_step;
+			pb = !haveB ? pa : (i + 1 < fpg ? pa + a.frame_step : list->audio[g + 1]);
+			g_out = g; i_out = i;
+		}
+		else
+		{
+			pa = a.audio + ((int64_t)g * a.group_stride + (int64_t)i * a.frame_step);
+			pb = !haveB ? pa : (i + 1 < fpg ? pa + a.frame_step : a.audio + (int64_t)(g + 1) * a.group_stride);
+		}
 	}
 }
 
@@ -169,8 +180,8 @@ __device__ __forceinline__ void ed_pair_ptrs(const ed_mfcc_args_t &a, uint32_t p
  * workgroups' finishing times and buys nothing -- the board sits at its power cap and takes the recovered idle time back as
  * clock (profiles/r04_mfcc_launch_structure_notes.txt).
  */
-template <bool ALIGNED, bool PLAIN, int NLO, int NHI>
-__global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
+template <bool ALIGNED, bool PLAIN, int NLO, int NHI, bool LIST>
+__device__ __forceinline__ void ed_mfcc2_body(const ed_mfcc_args_t &args, const ed_mfcc_tables_t *__restrict__ tab, const ed_mfcc_list_t *list)
 {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	const int lane = threadIdx.x & 63;
@@ -192,6 +203,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 	const uint32_t s0 = (uint32_t)(((uint64_t)blockIdx.x * n_pairs) / gridDim.x);
 	const uint32_t cnt = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_pairs) / gridDim.x) - s0;
 	uint32_t i_cur = wave, i_next;
+	uint32_t g_cur = 0, gi_cur = 0, g_nxt = 0, gi_nxt = 0; /* LIST: batch and frame-in-batch of the current / the prefetched pair's frame A */
 	uint32_t rawA[8], rawB[8];
 	/* No workgroup barrier behind the table staging: the first four waves (one per SIMD) stage the tables and raise a counter in
 	 * LDS; every wave checks that counter once, in front of its first use of the tables (the split of its first pair), by which
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 	if (i_cur < cnt)
 	{
 		const int16_t *pa, *pb;
-		ed_pair_ptrs<PLAIN>(args, s0 + i_cur, pa, pb);
+		ed_pair_ptrs<PLAIN, LIST>(args, list, s0 + i_cur, pa, pb, g_cur, gi_cur);
 		ed_load_frame<ALIGNED>(pa, lane, rawA);
 		ed_load_frame<ALIGNED>(pb, lane, rawB);
 	}
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(drawn));
 			i_next = __builtin_amdgcn_readfirstlane(drawn);
 			const int16_t *pa, *pb;
-			ed_pair_ptrs<PLAIN>(args, s0 + (i_next < cnt ? i_next : cnt - 1), pa, pb);
+			ed_pair_ptrs<PLAIN, LIST>(args, list, s0 + (i_next < cnt ? i_next : cnt - 1), pa, pb, g_nxt, gi_nxt);
 			ed_load_frame<ALIGNED>(pa, lane, rawA);
 			ed_load_frame<ALIGNED>(pb, lane, rawB);
 		}
@@ -472,9 +484,23 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 		const int c = lane & 31;
 		if (c < args.n_coef && (lane < 32 || haveB))
 		{
-			const int64_t at = (int64_t)(fA + (lane >> 5)) * args.n_coef + c;
-			if (args.mfcc) args.mfcc[at] = coef;
-			if (args.feat) args.feat[at] = (int8_t)__float2int_rn(fminf(fmaxf(coef * args.feat_scale, -128.0f), 127.0f));
+			if (LIST)
+			{
+				/* frame A is row gi_cur of batch g_cur; frame B the next row, or row 0 of the next batch */
+				const uint32_t fpg = (uint32_t)args.frames_per_group;
+				const bool wrap = gi_cur + 1 >= fpg;
+				const uint32_t gB = wrap ? g_cur + 1 : g_cur, iB = wrap ? 0u : gi_cur + 1;
+				const bool isB = lane >= 32;
+				const int64_t at = (int64_t)(isB ? iB : gi_cur) * args.n_coef + c;
+				if (args.mfcc) { float *o = isB ? list->mfcc[gB] : list->mfcc[g_cur]; o[at] = coef; }
+				if (args.feat) { int8_t *o = isB ? list->feat[gB] : list->feat[g_cur]; o[at] = (int8_t)__float2int_rn(fminf(fmaxf(coef * args.feat_scale, -128.0f), 127.0f)); }
+			}
+			else
+			{
+				const int64_t at = (int64_t)(fA + (lane >> 5)) * args.n_coef + c;
+				if (args.mfcc) args.mfcc[at] = coef;
+				if (args.feat) args.feat[at] = (int8_t)__float2int_rn(fminf(fmaxf(coef * args.feat_scale, -128.0f), 127.0f));
+			}
 		}
 		ED2_ST(11)
 		/* the next pair's samples (requested at the top of this iteration) become the floats the next iteration starts from */
@@ -485,6 +511,7 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
 		}
 		i_cur = i_next;
+		if (LIST) { g_cur = g_nxt; gi_cur = gi_nxt; }
 	}
 #if ED2_STAMP
 	asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) :: "memory");
@@ -504,6 +531,20 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 		for (int i_ = 0; i_ < ED2_NPH; i_++) dbg[i_] = ph[i_];
 	}
 #endif
+}
+
+template <bool ALIGNED, bool PLAIN, int NLO, int NHI>
+__global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
+{
+	ed_mfcc2_body<ALIGNED, PLAIN, NLO, NHI, false>(args, tab, nullptr);
+}
+
+/* the same loop over a LIST of independent batches (edison_mfcc_batches_dev): one launch keeps the chip busy across them (what the
+ * launch interface cannot do for separate launches: profiles/r05_mfcc_two_queues_notes.txt) */
+template <bool ALIGNED, int NLO, int NHI>
+__global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_list_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab, ed_mfcc_list_t list)
+{
+	ed_mfcc2_body<ALIGNED, false, NLO, NHI, true>(args, tab, &list);
 }
 
 #if defined(ED_LAB)
@@ -595,6 +636,46 @@ static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables
 		else hipLaunchKernelGGL((ed_mfcc_kernel<false, false, NLO, NHI>), grid, block, lds, stream, *args, dev_tab);
 	}
 	return (int)hipGetLastError();
+}
+
+static int g_mfcc2_list_blocks_per_cu[16][4];
+
+template <int NLO, int NHI>
+static int ed_launch_mfcc_list_shape(const ed_mfcc_args_t *args, const ed_mfcc_list_t *list, int n_batches, const ed_mfcc_tables_t *dev_tab, int n_cu, hipStream_t stream)
+{
+	const size_t lds2 = sizeof(float) * (ED_FIXTAB_FLOATS + (NLO + NHI) * 256 + ED2_WPB * ED2_XBUF_FLOATS) + 16 /* queue */;
+	bool aligned = args->frame_step % 2 == 0;
+	for (int b = 0; b < n_batches; b++) aligned = aligned && (reinterpret_cast<uintptr_t>(list->audio[b]) & 3) == 0;
+	const void *fn = aligned ? (const void *)ed_mfcc2_list_kernel<true, NLO, NHI> : (const void *)ed_mfcc2_list_kernel<false, NLO, NHI>;
+	int dev_ = 0;
+	(void)hipGetDevice(&dev_);
+	int *bpc = &g_mfcc2_list_blocks_per_cu[dev_ & 15][(NLO == 2 ? 0 : 2) + (aligned ? 1 : 0)];
+	if (*bpc <= 0)
+	{
+		if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return (int)hipGetLastError();
+		int nb = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * ED2_WPB, lds2) != hipSuccess || nb < 1) nb = 1;
+		*bpc = nb;
+	}
+	const int64_t n_pairs = (args->n_frames + 1) / 2;
+	int64_t blocks = (n_pairs + ED2_WPB - 1) / ED2_WPB;
+	if (blocks > (int64_t)n_cu * *bpc) blocks = (int64_t)n_cu * *bpc;
+	void *kargs[] = {(void *)args, (void *)&dev_tab, (void *)list};
+	return (int)hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(64 * ED2_WPB), kargs, lds2, stream);
+}
+
+/* n_batches (1 .. ED_MFCC_LIST_MAX) batches of args->frames_per_group frames each as the groups of one launch; args->n_frames =
+ * n_batches * frames_per_group; args->audio / mfcc / feat are used as flags only (NULL: that output is not written) */
+extern "C" int ed_launch_mfcc_list(const ed_mfcc_args_t *args, const ed_mfcc_list_t *list, int n_batches, const ed_mfcc_tables_t *dev_tab, int n_cu,
+                                   hipStream_t stream)
+{
+	if (args->n_frames <= 0) return 0;
+	if (n_batches < 1 || n_batches > ED_MFCC_LIST_MAX || args->frames_per_group < 1 || args->n_frames != (int64_t)n_batches * args->frames_per_group)
+		return (int)hipErrorInvalidValue;
+	if (args->mel_NLO == 2 && args->mel_NHI == 5) return ed_launch_mfcc_list_shape<2, 5>(args, list, n_batches, dev_tab, n_cu, stream);
+	if (args->mel_NLO == ED_MEL_NLO_MAX && args->mel_NHI == ED_MEL_NHI_MAX)
+		return ed_launch_mfcc_list_shape<ED_MEL_NLO_MAX, ED_MEL_NHI_MAX>(args, list, n_batches, dev_tab, n_cu, stream);
+	return (int)hipErrorInvalidValue;
 }
 
 extern "C" int ed_launch_mfcc(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,

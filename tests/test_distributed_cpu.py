@@ -157,6 +157,23 @@ def test_bench_starts_its_own_ranks_dry_run():
         assert c["rccl_id_reached_every_rank"] is True
 
 
+def test_bench_dry_run_with_eight_ranks_and_a_batch_the_world_does_not_divide():
+    """BASELINE configs[3]'s world size, rehearsed: `python bench.py --gpus 8 --dry-run` starts eight ranks over gloo; the shard
+    ranges of a batch that 8 does not divide (8 * 4096 + 1 utterances) tile it in rank order, the unequal-shard gather
+    (8 * 7 + 1 rows: shards of 8, 7, 7, ...) returns every row in place, and ONE line with n_gpus = 8 comes back."""
+    r = _run_bench(["--gpus", "8", "--dry-run", "--steps", "3", "--warmup", "1"], timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 8 and d["dry_run"] is True and d["value"] is None and d["config"]["parallelism"] == "dp8"
+    c = d["checks"]
+    assert c["ranks"] == 8 and c["gathered_logits_correct"] is True
+    assert c["shard_ranges_rank0"] == [[0, 4096], [0, 4097]]          # the odd utterance goes to the first rank
+    assert c["unequal_shard_gather"] == dict(rows=57, ranks=8, correct=True)
+    assert c["cabi_collective"]["status"].startswith("ok")
+
+
 def test_bench_dry_run_under_torchrun():
     """The driver's own launch form for N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N):
     WORLD_SIZE comes from the launcher, bench.py must not start ranks of its own on top."""

@@ -118,3 +118,89 @@ def test_mfcc_full_size_scaling_property(ctx):
     ctx.mfcc_t(z, 4096, 1024, _lib.MFCC_B, 32, out=a[:4096])
     torch.cuda.synchronize()
     assert float(a[:4096].abs().max()) == 0.0
+
+
+def test_independent_batches_in_flight_together_equal_serial_calls(ctx):
+    """Two 65 536-frame batches in flight at once: edison_mfcc_batch_dev on two HIP streams of ONE context (edison_set_stream per
+    call; streams of different priority are on different hardware queues by construction), each batch with its own input and
+    output, forked from and joined into one stream by events. The MFCC entry points share only read-only state (tables), so the
+    outputs must be bit-identical to serial calls on the same batches -- whatever the launches' overlap does to the speed
+    (it does not pay on this hardware; profiles/r05_mfcc_two_queues_notes.txt)."""
+    import torch
+    from edison_amd import _lib
+    dev = torch.device("cuda", ctx.device)
+    main = torch.cuda.Stream(device=dev)
+    qs = [torch.cuda.Stream(device=dev, priority=0), torch.cuda.Stream(device=dev, priority=-1)]
+    N = 65536
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    with torch.cuda.stream(main):
+        bufs = [(torch.randn((N, 1024), generator=g, device=dev) * 3000).clamp_(-32768, 32767).to(torch.int16) for _ in range(4)]
+        ref = []
+        ctx.use_torch_stream(main)
+        for b in bufs:
+            o = torch.empty((N, 13), dtype=torch.float32, device=dev)
+            ctx.mfcc_t(b, N, 1024, _lib.MFCC_B, 13, out=o)
+            ref.append(o)
+        outs = [torch.zeros((N, 13), dtype=torch.float32, device=dev) for _ in bufs]
+        feats = [torch.zeros((N, 13), dtype=torch.int8, device=dev) for _ in bufs]
+        ev = torch.cuda.Event()
+        ev.record(main)
+    for q in qs:
+        q.wait_event(ev)
+    try:
+        for rep in range(3):                               # 12 launches, two in flight at any time
+            for i, b in enumerate(bufs):
+                ctx.use_torch_stream(qs[i % 2])
+                ctx.mfcc_t(b, N, 1024, _lib.MFCC_B, 13, out=outs[i], feat=feats[i])
+        for q in qs:
+            e = torch.cuda.Event()
+            e.record(q)
+            main.wait_event(e)
+    finally:
+        ctx.use_torch_stream()
+    torch.cuda.synchronize()
+    for i in range(len(bufs)):
+        assert torch.equal(outs[i], ref[i]), i
+        assert torch.equal(feats[i].to(torch.float32), ref[i].clamp(-128, 127).round()), i
+
+
+@pytest.mark.parametrize("n_batches,n_each,variant_log", [(5, 1001, (1, False)), (3, 64, (0, False)), (19, 33, (1, True)), (1, 7, (1, False)), (2, 1, (0, False))])
+def test_batch_list_launch_equals_one_call_per_batch(ctx, n_batches, n_each, variant_log):
+    """edison_mfcc_batches_dev: independent batches at unrelated addresses (separate allocations, one of them 2-byte aligned only
+    in the last case set), own fp32 and int8 outputs each, ONE launch per 16 batches -- bit-identical to edison_mfcc_batch_dev per
+    batch. Odd frame counts make frame pairs straddle two batches (frame A the last row of batch g, frame B row 0 of batch g + 1);
+    19 batches take two launches; guard rows behind every output stay untouched."""
+    import torch
+    from edison_amd import _lib
+    variant, use_log = variant_log
+    dev = torch.device("cuda", ctx.device)
+    ctx.use_torch_stream()
+    g = torch.Generator(device=dev)
+    g.manual_seed(100 * n_batches + n_each)
+    audios, pads = [], []
+    for b in range(n_batches):
+        pads.append(torch.empty((1 + 37 * b,), dtype=torch.int8, device=dev))          # unrelated addresses between the batches
+        raw = (torch.randn((n_each * 1024 + 2,), generator=g, device=dev) * (3000 if b % 3 else 30)).clamp_(-32768, 32767).to(torch.int16)
+        audios.append(raw[1:1 + n_each * 1024] if (b == 1 and n_batches > 1) else raw[:n_each * 1024])   # batch 1: 2-byte aligned only
+    GUARD = 4321.0
+    outs = [torch.full((n_each + 2, 13), GUARD, dtype=torch.float32, device=dev) for _ in range(n_batches)]
+    feats = [torch.full((n_each + 2, 13), 99, dtype=torch.int8, device=dev) for _ in range(n_batches)]
+    ctx.mfcc_batches_t(audios, n_each, 1024, variant, 13, outs=[o[:n_each] for o in outs], feats=[f[:n_each] for f in feats], use_log=use_log)
+    torch.cuda.synchronize()
+    for b in range(n_batches):
+        ro = torch.empty((n_each, 13), dtype=torch.float32, device=dev)
+        rf = torch.empty((n_each, 13), dtype=torch.int8, device=dev)
+        ctx.mfcc_t(audios[b], n_each, 1024, variant, 13, out=ro, feat=rf, use_log=use_log)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[b][:n_each], ro), b
+        assert torch.equal(feats[b][:n_each], rf), b
+        assert (outs[b][n_each:] == GUARD).all() and (feats[b][n_each:] == 99).all(), b
+    # only one kind of output; and the argument checks
+    o2 = [torch.zeros((n_each, 13), dtype=torch.float32, device=dev) for _ in range(n_batches)]
+    ctx.mfcc_batches_t(audios, n_each, 1024, variant, 13, outs=o2, use_log=use_log)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o2[b], outs[b][:n_each]) for b in range(n_batches))
+    with pytest.raises(_lib.EdisonError) as ei:
+        ctx.mfcc_batches_t(audios, n_each, 1024, _lib.MFCC_C, 13, outs=o2)
+    assert ei.value.code == _lib.E_NO_IMPL

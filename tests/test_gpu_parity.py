@@ -434,6 +434,22 @@ def test_c_program_links_against_the_abi(built_lib, ctx, kws_golden, tmp_path):
     assert "AI net information" in out.stdout and "last inference time:" in out.stdout and "#8 Softmax" in out.stdout
 
 
+def test_c_host_runs_independent_batches_three_ways(built_lib, ctx):
+    """examples/host_mfcc_pipeline.c: independent batches from a plain C host -- one call per batch, ONE
+    edison_mfcc_batches_dev call for the list, one call per batch alternating over two HIP streams of different priority -- must
+    agree bit for bit (the program exits 3 otherwise) and print one JSON line with the three rates."""
+    import json
+    import os
+    import subprocess
+    from edison_amd import build as edbuild
+    edbuild.build_examples()
+    exe = os.path.join(edbuild.EXAMPLES_BIN, "host_mfcc_pipeline")
+    out = subprocess.run([exe, "5", "8191", "3"], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["list_equals_serial"] is True and d["two_queues_equals_serial"] is True and d["batches"] == 5 and d["frames_per_batch"] == 8191
+
+
 def test_batch_mfcc_rows_in_one_launch(ctx, oracle_mod):
     """edison_mfcc_rows (the mirror of batch_mfcc, mfcc_utils.py:75-131) handles all rows with ONE launch through the
     kernel's grouped addressing: the result must equal the per-row calls bit for bit -- on the reference's config-2

@@ -42,12 +42,21 @@ class V:
         assert self.L.edison_init(0, ctypes.byref(self.h)) == 0
         self.outs = [torch.zeros((a.frames, 13), dtype=torch.float32, device=dev) for _ in range(max(QS + [2]))]
         self.t = {q: [] for q in QS}
+        self.cache = {}
     def anyorder(self, on):
         if hasattr(self.L, "ed_lab_set_launch_flags"): self.L.ed_lab_set_launch_flags(1 if on else 0)
         else: assert not on, "queues 0 (any-order launches in one queue) needs a lab library"
     def launch(self, i, stream, out):
-        assert self.L.edison_set_stream(self.h, ctypes.c_void_p(stream.cuda_stream)) == 0
-        r = self.L.edison_mfcc_batch_dev(self.h, bufs[i % 3].data_ptr(), a.frames, 1024, a.variant, 13, out.data_ptr(), None, 1.0)
+        # prepared ctypes arguments: the host must stay well below the ~45 us a batch takes on the GPU, or it -- not the queues -- is
+        # what the two-queue figure measures (the first version of this tool converted its arguments per call and was host-bound)
+        key = (i % 3, id(stream), id(out))
+        c = self.cache.get(key)
+        if c is None:
+            c = self.cache[key] = ((self.h, ctypes.c_void_p(stream.cuda_stream)),
+                                   (self.h, ctypes.c_void_p(bufs[i % 3].data_ptr()), ctypes.c_int64(a.frames), ctypes.c_int64(1024), ctypes.c_int(a.variant),
+                                    ctypes.c_int(13), ctypes.c_void_p(out.data_ptr()), None, ctypes.c_float(1.0)))
+        self.L.edison_set_stream(*c[0])
+        r = self.L.edison_mfcc_batch_dev(*c[1])
         assert r == 0, (self.name, r, self.L.edison_last_error(self.h))
     def run(self, q, reps, timed):
         """reps batches over q queues, forked from and joined into `main`; returns us per batch when timed"""
