@@ -350,10 +350,11 @@ def cpu_baseline():
     x = _synth_frames_np(65536, 20)                                   # seed 20: SURVEY.md 8(d) config 2
     n1 = 4096                                                         # 1-thread sample: ~0.1-0.2 s per pass
 
-    def leg(fn_1, units_1, fn_all, units_all, unit, what):
+    def leg(fn_1, units_1, fn_all, units_all, unit, what, arith="float64: the reference's CPU path (numpy / scipy, mfcc_utils.py) computes in float64 and the port restates THAT; an fp32 "
+                                                                "port would time a program the reference does not run (SURVEY 8(d) suggested one: not built, for this reason)"):
         r1 = _median_rate(fn_1, units_1)
         ra = _median_rate(fn_all, units_all)
-        return dict(value=ra, unit=unit, cores=n_all, kind="port", single_thread=dict(value=r1, cores=1, sample_units=units_1),
+        return dict(value=ra, unit=unit, cores=n_all, kind="port", arithmetic=arith, single_thread=dict(value=r1, cores=1, sample_units=units_1),
                     sample="%s; all-cores leg %d units, 1-thread leg %d units; median of 3 passes after 1 warm-up" % (what, units_all, units_1),
                     host=host)
     # MFCC variant B (the features the net was trained on), float64 like the reference's numpy path it restates
@@ -366,7 +367,7 @@ def cpu_baseline():
     # MFCC variant C = the firmware's own C path (Q15 CMSIS-DSP arithmetic restated)
     res["q15"] = leg(lambda: oracle.mfcc_q15(x[:n1 * 1024], n_threads=1), n1,
                      lambda: oracle.mfcc_q15(x, n_threads=n_all), 65536, "frames/s",
-                     "oracle/mfcc_q15_ref.c (firmware audioCalcMFCCs arithmetic), same frames")
+                     "oracle/mfcc_q15_ref.c (firmware audioCalcMFCCs arithmetic), same frames", arith="int16 / int32 (Q15 / Q31), the firmware's own")
     # full KWS: MFCC B + int8 CNN restatement; 4096 utterances (126 976 frames) for the all-cores leg keeps the whole
     # baseline inside ~30 s of CPU work on a 16-core host
     nu_all, nu_1 = 4096, 128
@@ -377,7 +378,7 @@ def cpu_baseline():
         m = oracle.mfcc(a[:n * 31744], oracle.VARIANT_B, n_threads=th)[:, :13]
         return oracle.cnn(model, oracle.net_input(m).reshape(n, 403), n_threads=th)
     res["kws"] = leg(lambda: kws(nu_1, 1), nu_1, lambda: kws(nu_all, n_all), nu_all, "inferences/s",
-                     "oracle MFCC B + int8 CNN restatement (NNoM arithmetic), utterances of 31 frames, seed 21")
+                     "oracle MFCC B + int8 CNN restatement (NNoM arithmetic), utterances of 31 frames, seed 21", arith="float64 MFCC (as the reference's host path) + int8 / int32 CNN (NNoM's)")
     if oracle.have_ref():
         rng = np.random.default_rng(5)
         f = rng.integers(-128, 128, (2000, 403)).astype(np.int8)

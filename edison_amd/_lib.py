@@ -87,6 +87,10 @@ SIGNATURES = {
     "edison_mfcc_batch_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_float]),
     "edison_mfcc_rows_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_float]),
     "edison_mfcc_batches_dev": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_float]),
+    "edison_mfcc_generic_dev": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_double, c_double, c_double, c_double, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float]),
+    "edison_mfcc_generic": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_double, c_double, c_double, c_double, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float]),
     "edison_queues_calibrate": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_double), ctypes.POINTER(c_int)]),
     "edison_queues_fork": (c_int, [c_void_p]),
     "edison_queues_join": (c_int, [c_void_p]),

@@ -16,10 +16,12 @@ kws_keras.py:450, kws_on_mcu.py:293,343,...) can import this module in its place
                                                   TensorFlow is not in this image: PARITY UNPINNED, checked against a
                                                   float64 restatement of tf.signal's published definitions only
 
-The GPU path is specialised for the reference's shipped geometry: 1024-sample frames and 32 mel bins
-(audio/config.py:15,19). Other values raise NotImplementedError rather than silently taking another path.
-The returned arrays are float32 promoted to float64 (the reference computes in float64); see DESIGN.md for
-the measured tolerance.
+The fast GPU kernels are specialised for the reference's shipped geometry: 1024-sample frames and 32 mel bins
+(audio/config.py:15,19) -- what every caller in the reference passes; their arrays are float32 promoted to float64 (the
+reference computes in float64; DESIGN.md has the measured tolerance). Any OTHER geometry the reference's functions accept
+(frame_len 4 .. 4096, power of two or not; mel_nbins 1 .. 256) goes through the generality kernel (`edison_mfcc_generic`:
+float64 on the GPU, one workgroup per frame, the reference's values to ~1e-12; round 5). Outside those limits:
+NotImplementedError, never another path.
 """
 import ctypes
 
@@ -63,12 +65,19 @@ def gen_mel_weight_matrix(num_mel_bins=20, num_spectrogram_bins=129, sample_rate
 _configured = None
 
 
+def _is_fast_geometry(frame_len, mel_nbins):
+    return frame_len == _lib.FRAME_LEN and mel_nbins == _lib.NUM_MEL
+
+
 def _prepare(fs, frame_len, mel_nbins, mel_lower_hz, mel_upper_hz, mel_mtx_scale=128):
+    """The context, configured for this filterbank when the geometry is the fast kernels' (1024 / 32); other geometries take the
+    generality kernel, which builds its tables per call and needs no configuration."""
     global _configured
-    if frame_len != _lib.FRAME_LEN or mel_nbins != _lib.NUM_MEL:
-        raise NotImplementedError("the MI355X path implements the reference configuration frame_len=1024, "
-                                  "mel_nbins=32 (audio/config.py:15,19); got frame_len=%r mel_nbins=%r"
-                                  % (frame_len, mel_nbins))
+    if not _is_fast_geometry(frame_len, mel_nbins):
+        if not (4 <= int(frame_len) <= 4096 and 1 <= int(mel_nbins) <= 256):   # before anything touches the device
+            raise NotImplementedError("the MI355X path implements frame_len 4 .. 4096 and mel_nbins 1 .. 256; got frame_len=%r mel_nbins=%r"
+                                      % (frame_len, mel_nbins))
+        return default_context()
     ctx = default_context()
     key = (float(fs), float(mel_lower_hz), float(mel_upper_hz), float(mel_mtx_scale))
     default = (16000.0, 80.0, 7600.0, 128.0)
@@ -76,6 +85,26 @@ def _prepare(fs, frame_len, mel_nbins, mel_lower_hz, mel_upper_hz, mel_mtx_scale
         ctx.configure_mfcc(*key)
         _configured = key
     return ctx
+
+
+def _generic(ctx, data, frame_count, frame_len, frame_step, variant, mel_nbins, fs, lo, hi, scale=128.0, use_log=False, stages=True):
+    """edison_mfcc_generic on a host int16 stream: dict of float64 arrays (fft complex, spectrogram, mel_spectrogram,
+    log_mel_spectrogram, mfcc) shaped like the reference's per-frame entries stacked over the frames."""
+    x = _as_int16(data).ravel()
+    n = int(frame_count)
+    if n > 0 and (n - 1) * frame_step + frame_len > x.shape[0]:
+        raise ValueError("data too short for %d frames of %d samples" % (n, frame_len))
+    fo = frame_len // 2 if variant == _lib.MFCC_A else frame_len
+    fft = np.zeros((max(n, 0), fo, 2), np.float64) if stages else None
+    spec = np.zeros((max(n, 0), fo), np.float64) if stages else None
+    mel = np.zeros((max(n, 0), mel_nbins), np.float64) if stages else None
+    lm = np.zeros((max(n, 0), mel_nbins), np.float64) if stages else None
+    mf = np.zeros((max(n, 0), mel_nbins), np.float64)
+    p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    v = variant | (_lib.MFCC_USE_LOG if use_log else 0)
+    ctx._check(_lib.lib().edison_mfcc_generic(ctx._h, p(x), n, int(frame_len), int(frame_step), v, int(mel_nbins), float(fs), float(lo), float(hi),
+                                              float(scale), p(fft), p(spec), p(mel), p(lm), p(mf), 0, None, 1.0))
+    return dict(fft=None if fft is None else fft[..., 0] + 1j * fft[..., 1], spectrogram=spec, mel_spectrogram=mel, log_mel_spectrogram=lm, mfcc=mf)
 
 
 def _frame_count(frame_count, nSamples, frame_len, frame_step):
@@ -102,6 +131,9 @@ def batch_mfcc(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, 
     data = _as_int16(data)
     print("Running mfcc for %d frames with %d step on %d samples" % (frame_count, frame_step, data.shape[0]))
     data = np.atleast_2d(data)
+    if not _is_fast_geometry(frame_len, mel_nbins):
+        rows = [_generic(ctx, r, frame_count, frame_len, frame_step, _lib.MFCC_A, mel_nbins, fs, mel_lower_hz, mel_upper_hz, stages=False)["mfcc"] for r in data]
+        return np.stack(rows) if rows else np.zeros((0, frame_count, mel_nbins))
     # one C-ABI call, one kernel launch for all rows (the kernel's grouped addressing: row = group, row stride = samples)
     return ctx.mfcc_rows(data, frame_count, frame_step=frame_step, variant=_lib.MFCC_A, n_coef=mel_nbins).astype(np.float64)
 
@@ -111,7 +143,10 @@ def mfcc(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, mel_nb
     """Variant A; list of per-frame dicts with the reference's keys (mfcc_utils.py:134-199)."""
     ctx = _prepare(fs, frame_len, mel_nbins, mel_lower_hz, mel_upper_hz)
     frame_count = _frame_count(frame_count, nSamples, frame_len, frame_step)
-    st = ctx.mfcc_stages(_as_int16(data), n_frames=frame_count, frame_step=frame_step, variant=_lib.MFCC_A)
+    if _is_fast_geometry(frame_len, mel_nbins):
+        st = ctx.mfcc_stages(_as_int16(data), n_frames=frame_count, frame_step=frame_step, variant=_lib.MFCC_A)
+    else:
+        st = _generic(ctx, data, frame_count, frame_len, frame_step, _lib.MFCC_A, mel_nbins, fs, mel_lower_hz, mel_upper_hz)
     W = gen_mel_weight_matrix(num_mel_bins=mel_nbins, num_spectrogram_bins=frame_len // 2, sample_rate=fs,
                               lower_edge_hertz=mel_lower_hz, upper_edge_hertz=mel_upper_hz)
     output = []
@@ -134,8 +169,12 @@ def mfcc_mcu(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, me
     """Variant B (the features the net was trained on); list of per-frame dicts (mfcc_utils.py:255-323)."""
     ctx = _prepare(fs, frame_len, mel_nbins, mel_lower_hz, mel_upper_hz, mel_mtx_scale)
     frame_count = _frame_count(frame_count, nSamples, frame_len, frame_step)
-    st = ctx.mfcc_stages(_as_int16(data), n_frames=frame_count, frame_step=frame_step, variant=_lib.MFCC_B,
-                         use_log=use_log)
+    generic = not _is_fast_geometry(frame_len, mel_nbins)
+    if generic:
+        st = _generic(ctx, data, frame_count, frame_len, frame_step, _lib.MFCC_B, mel_nbins, fs, mel_lower_hz, mel_upper_hz, mel_mtx_scale, use_log)
+    else:
+        st = ctx.mfcc_stages(_as_int16(data), n_frames=frame_count, frame_step=frame_step, variant=_lib.MFCC_B,
+                             use_log=use_log)
     W = mel_mtx_scale * gen_mel_weight_matrix(num_mel_bins=mel_nbins, num_spectrogram_bins=frame_len // 2 + 1,
                                               sample_rate=fs, lower_edge_hertz=mel_lower_hz,
                                               upper_edge_hertz=mel_upper_hz)
@@ -145,11 +184,15 @@ def mfcc_mcu(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, me
         frame = {}
         frame['t_start'] = f * frame_step / fs
         frame['t_end'] = (f * frame_step + frame_len) / fs
-        # full-length spectrum of a real signal from its 513 unique bins (conjugate symmetry)
-        X = st['fft'][f].astype(np.complex128)
-        frame['fft'] = 1.0 / 1024 * np.concatenate([X, np.conj(X[half - 1:0:-1])])
-        s = st['spectrogram'][f].astype(np.float64)
-        frame['spectrogram'] = np.concatenate([s, s[half - 1:0:-1]])
+        if generic:   # the generality kernel returns the reference's full-length entries as they are (scaled, mirrored)
+            frame['fft'] = st['fft'][f]
+            frame['spectrogram'] = st['spectrogram'][f]
+        else:
+            # full-length spectrum of a real signal from its 513 unique bins (conjugate symmetry)
+            X = st['fft'][f].astype(np.complex128)
+            frame['fft'] = 1.0 / 1024 * np.concatenate([X, np.conj(X[half - 1:0:-1])])
+            s = st['spectrogram'][f].astype(np.float64)
+            frame['spectrogram'] = np.concatenate([s, s[half - 1:0:-1]])
         frame['mel_weight_matrix'] = W
         frame['mel_spectrogram'] = st['mel_spectrogram'][f].astype(np.float64)
         frame['log_mel_spectrogram'] = st['log_mel_spectrogram'][f].astype(np.float64)
@@ -182,6 +225,9 @@ def mfcc_tf(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, mel
     reference does (:245-249); float32 arithmetic like TensorFlow's. Parity unpinned (see the module docstring)."""
     if fft_len != frame_len:
         raise NotImplementedError("the MI355X path implements fft_len == frame_len (audio/config.py:15-16)")
+    if not _is_fast_geometry(frame_len, mel_nbins):
+        raise NotImplementedError("variant TF (a comparison curve, mfcc.py:189 its only caller) is built for the reference configuration "
+                                  "frame_len=1024, mel_nbins=32 only; got frame_len=%r mel_nbins=%r" % (frame_len, mel_nbins))
     ctx = _prepare(fs, frame_len, mel_nbins, mel_lower_hz, mel_upper_hz)
     frame_count = _frame_count(frame_count, nSamples, frame_len, frame_step)
     st = ctx.mfcc_stages(_as_int16(data), n_frames=frame_count, frame_step=frame_step, variant=_lib.MFCC_TF)

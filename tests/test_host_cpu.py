@@ -86,10 +86,14 @@ def test_frames_and_mel_helpers():
     assert f.shape == (3, 4) and f[2].tolist() == [6, 7, 8, 9]
     assert mfu.frames(np.arange(3), 3, 1).shape == (1, 3)
     assert abs(mfu.hertz_to_mel(700.0) - 1127.0 * np.log(2.0)) < 1e-12
+    # geometries beyond the generality kernel's limits are refused before anything touches the device; inside them (512 / 32,
+    # 1024 / 26 ...) the call goes to edison_mfcc_generic (tests/test_gpu_generic.py)
     with pytest.raises(NotImplementedError):
-        mfu._prepare(16000, 512, 32, 80.0, 7600.0)
+        mfu._prepare(16000, 8192, 32, 80.0, 7600.0)
     with pytest.raises(NotImplementedError):
-        mfu._prepare(16000, 1024, 26, 20.0, 4000.0)
+        mfu._prepare(16000, 1024, 300, 20.0, 4000.0)
+    with pytest.raises(NotImplementedError):
+        mfu._prepare(16000, 2, 32, 20.0, 4000.0)
 
 
 def test_config_matches_reference_values():

@@ -17,7 +17,7 @@ ap.add_argument("--wpb", type=int, default=12); ap.add_argument("--queues", defa
 a = ap.parse_args()
 _lib._share_torch_hip_runtime()
 L = ctypes.CDLL(os.path.join(ROOT, "edison_amd/csrc/abl/libedison_hip_%s.so" % a.name))
-for n in ("edison_init", "edison_set_stream", "edison_mfcc_batch_dev"):
+for n in ("edison_init", "edison_set_stream", "edison_mfcc_batch_dev", "edison_queues_calibrate", "edison_queues_fork", "edison_queues_join", "edison_mfcc_batch_queue_dev"):
     fn = getattr(L, n); fn.restype, fn.argtypes = _lib.SIGNATURES[n]
 L.ed_set_debug_buffer.argtypes = [ctypes.c_void_p]
 L.ed_set_debug_slots.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
@@ -33,9 +33,15 @@ L.ed_set_debug_slots(ctypes.c_void_p(outs.data_ptr()), a.frames * 13 * 4, NSLOT,
 g = torch.Generator(device=dev); g.manual_seed(1)
 bufs = [(torch.randn((a.frames, 1024), generator=g, device=dev) * 3000).clamp_(-32768, 32767).to(torch.int16) for _ in range(3)]
 
-def launch(i, stream):
-    L.edison_set_stream(h, ctypes.c_void_p(stream.cuda_stream))
-    assert L.edison_mfcc_batch_dev(h, bufs[i % 3].data_ptr(), a.frames, 1024, _lib.MFCC_B, 13, outs[i % NSLOT].data_ptr(), None, 1.0) == 0
+# prepared calls: the host must stay far below the GPU's ~45 us per batch (the first version of this tool converted its arguments per
+# call, was host-bound, and "found" that the second queue's launch starts late)
+L.edison_set_stream(h, ctypes.c_void_p(main.cuda_stream))
+C1 = [(h, ctypes.c_void_p(bufs[i % 3].data_ptr()), ctypes.c_int64(a.frames), ctypes.c_int64(1024), ctypes.c_int(_lib.MFCC_B), ctypes.c_int(13),
+       ctypes.c_void_p(outs[i % NSLOT].data_ptr()), None, ctypes.c_float(1.0)) for i in range(12)]
+C2 = [(h, ctypes.c_int(i & 1)) + C1[i][1:] for i in range(12)]
+su, bu, pk = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+assert L.edison_queues_calibrate(h, bufs[0].data_ptr(), a.frames, 1024, _lib.MFCC_B, ctypes.byref(su), ctypes.byref(bu), ctypes.byref(pk)) == 0
+print("calibration (stamped build): serial %.2f us, kept %.2f us, pair %d" % (su.value, bu.value, pk.value), flush=True)
 
 def cu_key(d):
     hw, xcc = d[:, 17].astype(np.int64), d[:, 18].astype(np.int64)
@@ -47,12 +53,11 @@ for q in [int(x) for x in a.queues.split(",")]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(main)
         if q == 1:
-            for i in range(a.launches): launch(i, main)
+            for i in range(a.launches): L.edison_mfcc_batch_dev(*C1[i % 12])
         else:
-            for s in side[:q]: s.wait_event(e0)
-            for i in range(a.launches): launch(i, side[i % q])
-            for s in side[:q]:
-                ev = torch.cuda.Event(); ev.record(s); main.wait_event(ev)
+            L.edison_queues_fork(h)
+            for i in range(a.launches): L.edison_mfcc_batch_queue_dev(*C2[i % 12])
+            L.edison_queues_join(h)
         e1.record(main); torch.cuda.synchronize()
     print("==== %d queue(s): %.2f us per launch over %d launches (stamped build)" % (q, e0.elapsed_time(e1) / a.launches * 1e3, a.launches))
     d = dbg.cpu().numpy().astype(np.float64).reshape(NSLOT, SLOTW, NPH)
