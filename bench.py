@@ -221,9 +221,8 @@ def stream_bench(ctx, dev):
                     p99=round(float(np.percentile(lat, 99)), 1), pushes=int(lat.size))
 
     def throughput(graph, chunk=4096, min_ms=50.0):
-        """The WHOLE hour, every frame of it: 27 pushes of 4096 frames and the ragged last push of the remaining 1 907 (direct
-        launches: edison_stream_push_n_dev; the captured graph holds the chunk, so the graph leg pushes the tail through a second
-        stream object of that size after moving nothing -- it simply ends 1 907 frames short and says so). One hour is ~0.7 ms of
+        """The WHOLE hour, every frame of it, in both launch modes: 27 pushes of 4096 frames and the ragged last push of the remaining
+        1 907 (edison_stream_push_n_dev; under the captured graph the short push runs the same kernels launched directly). One hour is ~0.7 ms of
         GPU time: the hour is streamed again and again (audio continuing seamlessly: later hours start at sample 0 and have
         112 500 frames) until the timed region is at least min_ms long."""
         st = Stream(ctx, hop=hop, chunk_frames=chunk, graph=graph)
@@ -235,10 +234,9 @@ def stream_bench(ctx, dev):
             full, rest = divmod(n, chunk)
             for i in range(full):
                 st.push_t(body[i * chunk * hop:(i + 1) * chunk * hop], argmax=am)
-            if rest and not graph:
+            if rest:
                 st.push_t(body[full * chunk * hop:(full * chunk + rest) * hop], argmax=am, n_frames=rest)
-                return n
-            return full * chunk
+            return n
         hour(True)                                                   # warm-up: one whole hour
         torch.cuda.synchronize()
         st.reset()
@@ -255,8 +253,8 @@ def stream_bench(ctx, dev):
         dt = time.perf_counter() - t0
         st.close()
         return dict(frames_per_s=round(done / dt, 1), inferences_per_s=round(done / dt, 1), frames=done, hours_streamed=hours,
-                    frames_first_hour=n_frames if not graph else (n_frames // chunk) * chunk, chunk_frames=chunk,
-                    ragged_last_push_frames=(n_frames % chunk) if not graph else 0, seconds=round(dt, 4),
+                    frames_first_hour=n_frames, chunk_frames=chunk,
+                    ragged_last_push_frames=n_frames % chunk, seconds=round(dt, 4),
                     realtime_factor=round(done * hop / 16000.0 / dt, 1))
     lat_direct = latency(False)
     lat_direct["what"] = ("host push of 512 new samples -> softmax/argmax on the host through the Python mirror (edison_amd/stream.py): MFCC + CNN "
@@ -807,6 +805,8 @@ def main():
     # calibration chose. The library's own two queues (the calibrated pair, or one stream of each priority without a calibration).
     two_queues = None
     try:
+        if args.queues == 1:
+            raise RuntimeError("--queues 1: every launch of this run is on one queue (the profiled passes whose per-launch durations are quoted)")
         ctx.queues_fork()
         for i in range(4):
             q_step(i)

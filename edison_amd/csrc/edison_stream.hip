@@ -563,8 +563,6 @@ extern "C" int edison_stream_push_n_dev(edison_stream *s, const int16_t *samples
 	if (!s || !samples) return EDISON_E_ARGUMENT;
 	edison_ctx *ctx = s->ctx;
 	if (n_frames < 1 || n_frames > s->chunk) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: n_frames must be 1 .. chunk_frames");
-	if (n_frames != s->chunk && s->use_graph)
-		return ed_set_err(ctx, EDISON_E_NO_IMPL, "stream: a push shorter than the chunk needs launch_mode = EDISON_STREAM_LAUNCH_DIRECT (the captured graph holds the chunk)");
 	if (s->model_epoch != ctx->model_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: the model was reloaded after this stream was created; create a new stream");
 	if (s->tables_epoch != ctx->tables_epoch) return ed_set_err(ctx, EDISON_E_ARGUMENT, "stream: edison_mfcc_configure was called after this stream was created; create a new stream");
 	const size_t nnew = (size_t)n_frames * s->hop;
@@ -593,21 +591,30 @@ extern "C" int edison_stream_push_n_dev(edison_stream *s, const int16_t *samples
 	ED_HIP(ctx, hipEventRecord(s->ev_in, ctx->stream));
 	ED_HIP(ctx, hipStreamWaitEvent(s->own, s->ev_in, 0));
 	ED_HIP(ctx, hipMemcpyAsync(s->d_audio + s->tail, samples, nnew * sizeof(int16_t), hipMemcpyDeviceToDevice, s->own));
+	if (n_frames == s->chunk)
 	{
-		/* the kernels of a push are launched directly: on this platform replaying the captured graph is SLOWER than its
-		 * three or four plain launches (1 h stream in 4096-frame pushes: 60.0 M frames/s with hipGraphLaunch, 67.2 M
-		 * without; one-frame pushes: 39 -> 32 us). launch_mode = EDISON_STREAM_LAUNCH_GRAPH replays the graph. */
+		/* launch_mode = EDISON_STREAM_LAUNCH_GRAPH: the captured nodes of a whole chunk (on this platform the replay measures SLOWER
+		 * than its three or four plain launches -- 60.0 M frames/s against 67.2 M over the 1 h stream, 39 against 32 us per
+		 * one-frame push -- which is why direct launches are the default) */
 		ED_HIP(ctx, hipGraphLaunch(s->exec, s->own));
 	}
+	else
+	{
+		/* the ragged last push of a recording (n_frames < chunk): the captured graph has the chunk baked in, so these few frames take
+		 * the same kernels launched directly, on the same private stream and on the same state (history at the front, as the graph
+		 * leaves it) -- a graph-mode stream consumes every frame of a recording too (round 5; it used to end short of the tail) */
+		const int rd = enqueue_push_on(s, s->own, s->d_logits, s->d_soft, s->d_argmax, 0, n_frames);
+		if (rd != EDISON_OK) return rd;
+	}
 	s->last_push_staged = 0;
-	if (logits) ED_HIP(ctx, hipMemcpyAsync(logits, s->d_logits, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToDevice, s->own));
-	if (softmax) ED_HIP(ctx, hipMemcpyAsync(softmax, s->d_soft, (size_t)s->chunk * EDISON_NET_OUT, hipMemcpyDeviceToDevice, s->own));
-	if (argmax) ED_HIP(ctx, hipMemcpyAsync(argmax, s->d_argmax, (size_t)s->chunk * sizeof(int32_t), hipMemcpyDeviceToDevice, s->own));
+	if (logits) ED_HIP(ctx, hipMemcpyAsync(logits, s->d_logits, (size_t)n_frames * EDISON_NET_OUT, hipMemcpyDeviceToDevice, s->own));
+	if (softmax) ED_HIP(ctx, hipMemcpyAsync(softmax, s->d_soft, (size_t)n_frames * EDISON_NET_OUT, hipMemcpyDeviceToDevice, s->own));
+	if (argmax) ED_HIP(ctx, hipMemcpyAsync(argmax, s->d_argmax, (size_t)n_frames * sizeof(int32_t), hipMemcpyDeviceToDevice, s->own));
 	/* ... and the context's stream continues only after the outputs are written */
 	ED_HIP(ctx, hipEventRecord(s->ev_out, s->own));
 	ED_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_out, 0));
-	s->last_n = s->chunk;
-	s->frames_seen += s->chunk;
+	s->last_n = n_frames;
+	s->frames_seen += n_frames;
 	return EDISON_OK;
 }
 

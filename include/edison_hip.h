@@ -359,8 +359,9 @@ int edison_stream_reset(edison_stream *s);
 int edison_stream_push_dev(edison_stream *s, const int16_t *samples /* device, chunk*hop */, int8_t *logits,
                            int8_t *softmax, int32_t *argmax /* device, may be NULL */);
 /* n_frames <= chunk_frames new frames (n_frames * hop samples, outputs [n_frames][..]): the ragged last push of a recording that the
- * chunk does not divide (the firmware has no counterpart: its microphone never ends, app.c:288-371). Direct launch mode only for
- * n_frames < chunk_frames (EDISON_E_NO_IMPL otherwise). The filtered outputs of such a push: its first n_frames entries. */
+ * chunk does not divide (the firmware has no counterpart: its microphone never ends, app.c:288-371). Either launch mode (under
+ * EDISON_STREAM_LAUNCH_GRAPH a short push runs the same kernels launched directly: the captured graph holds the chunk). The filtered
+ * outputs of such a push: its n_frames entries. */
 int edison_stream_push_n_dev(edison_stream *s, const int16_t *samples /* device, n_frames*hop */, int n_frames, int8_t *logits,
                              int8_t *softmax, int32_t *argmax /* device, may be NULL */);
 int edison_stream_push(edison_stream *s, const int16_t *samples /* host */, int8_t *logits, int8_t *softmax,
