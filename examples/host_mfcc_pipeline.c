@@ -5,16 +5,17 @@
  *
  *   (a) one edison_mfcc_batch_dev call per batch on the context's stream            -- the serial launch sequence
  *   (b) ONE edison_mfcc_batches_dev call for the whole list                         -- one launch keeps the chip busy across batches
- *   (c) one call per batch, alternating over two HIP streams (edison_set_stream)    -- the next launch in flight while this one drains
+ *   (c) one call per batch on the context's two queues (edison_queues_calibrate once, then edison_queues_fork /
+ *       edison_mfcc_batch_queue_dev / edison_queues_join)                           -- the next launch in flight while this one drains
  *
- * (b) is the fast one (0.41-0.42 of 8 TB/s against 0.37-0.39 for (a) at 65 536 frames per batch); (c) is correct and measures 3-7 %
- * SLOWER than (a) on MI355X: profiles/r05_mfcc_two_queues_notes.txt. Streams of one priority share HIP's pool of hardware queues and
- * may land on the same one; two streams of DIFFERENT priority are on different hardware queues by construction, which is what (c) uses.
+ * (b) is the fast one (0.41-0.42 of 8 TB/s against 0.37-0.39 for (a) at 65 536 frames per batch). (c) gains +1 ... +5 % over (a) when the
+ * calibration finds a pair of streams whose hardware queues lie well, and IS (a) when it does not -- which two HIP streams overlap
+ * profitably is decided by where runtime and driver put their hardware queues, so the library measures it
+ * (profiles/r05_mfcc_two_queues_notes.txt).
  *
- *   hipcc examples/host_mfcc_pipeline.c -Iinclude -Ledison_amd/csrc -ledison_hip -Wl,-rpath,$PWD/edison_amd/csrc -o host_mfcc_pipeline
+ *   cc examples/host_mfcc_pipeline.c -Iinclude -Ledison_amd/csrc -ledison_hip -Wl,-rpath,$PWD/edison_amd/csrc -o host_mfcc_pipeline
  *   ./host_mfcc_pipeline [n_batches = 8] [frames_per_batch = 65536] [repetitions = 50]
  */
-#include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,7 +24,6 @@
 #include "edison_hip.h"
 
 #define CHECK(x) do { int r_ = (x); if (r_ != EDISON_OK) { fprintf(stderr, "%s -> %d: %s\n", #x, r_, edison_last_error(ctx)); return 1; } } while (0)
-#define HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 static double now_ms(void)
 {
@@ -65,17 +65,10 @@ int main(int argc, char **argv)
 	}
 	free(host);
 
-	/* (c)'s two queues and the events that fork them from / join them into the context's own stream */
-	hipStream_t q[2], mainq;
-	int lo = 0, hi = 0;
-	HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));              /* lo = least, hi = greatest priority */
-	HIP(hipStreamCreateWithPriority(&mainq, hipStreamNonBlocking, lo));
-	HIP(hipStreamCreateWithPriority(&q[0], hipStreamNonBlocking, lo));
-	HIP(hipStreamCreateWithPriority(&q[1], hipStreamNonBlocking, hi));
-	hipEvent_t fork_ev, join_ev[2];
-	HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
-	HIP(hipEventCreateWithFlags(&join_ev[0], hipEventDisableTiming));
-	HIP(hipEventCreateWithFlags(&join_ev[1], hipEventDisableTiming));
+	/* (c): which of the context's candidate streams make a pair worth using, measured on batch 0 (~0.17 s) */
+	double cal_serial_us = 0, cal_best_us = 0;
+	int cal_pair = 0;
+	CHECK(edison_queues_calibrate(ctx, audio[0], nf, EDISON_FRAME_LEN, EDISON_MFCC_B, &cal_serial_us, &cal_best_us, &cal_pair));
 
 	enum { PASSES = 6 };             /* pass 0 warms up (clocks, code objects); the medians of passes 1..5 are reported: a, b, c interleaved */
 	double ta[PASSES], tb[PASSES], tc[PASSES];
@@ -83,7 +76,6 @@ int main(int argc, char **argv)
 	{
 		double t_a, t_b, t_c;
 		/* (a) serial */
-		CHECK(edison_set_stream(ctx, mainq));
 		double t0 = now_ms();
 		for (int r = 0; r < reps; r++)
 			for (int b = 0; b < nb; b++)
@@ -96,19 +88,13 @@ int main(int argc, char **argv)
 			CHECK(edison_mfcc_batches_dev(ctx, nb, audio, nf, EDISON_FRAME_LEN, EDISON_MFCC_B, EDISON_NUM_MFCC, out_b, NULL, 1.0f));
 		CHECK(edison_sync(ctx));
 		t_b = now_ms() - t0;
-		/* (c) two launches in flight: fork the two queues from the main stream, alternate, join */
+		/* (c) two launches in flight: fork the context's two queues from its stream, alternate, join */
 		t0 = now_ms();
-		HIP(hipEventRecord(fork_ev, mainq));
-		HIP(hipStreamWaitEvent(q[0], fork_ev, 0));
-		HIP(hipStreamWaitEvent(q[1], fork_ev, 0));
+		CHECK(edison_queues_fork(ctx));
 		for (int r = 0; r < reps; r++)
 			for (int b = 0; b < nb; b++)
-			{
-				CHECK(edison_set_stream(ctx, q[(r * nb + b) & 1]));
-				CHECK(edison_mfcc_batch_dev(ctx, audio[b], nf, EDISON_FRAME_LEN, EDISON_MFCC_B, EDISON_NUM_MFCC, out_c[b], NULL, 1.0f));
-			}
-		for (int k = 0; k < 2; k++) { HIP(hipEventRecord(join_ev[k], q[k])); HIP(hipStreamWaitEvent(mainq, join_ev[k], 0)); }
-		CHECK(edison_set_stream(ctx, mainq));
+				CHECK(edison_mfcc_batch_queue_dev(ctx, (r * nb + b) & 1, audio[b], nf, EDISON_FRAME_LEN, EDISON_MFCC_B, EDISON_NUM_MFCC, out_c[b], NULL, 1.0f));
+		CHECK(edison_queues_join(ctx));
 		CHECK(edison_sync(ctx));
 		t_c = now_ms() - t0;
 		ta[pass] = t_a; tb[pass] = t_b; tc[pass] = t_c;
@@ -130,9 +116,10 @@ int main(int argc, char **argv)
 	printf("{\"batches\": %d, \"frames_per_batch\": %lld, \"repetitions\": %d, "
 	       "\"serial_us_per_batch\": %.2f, \"list_us_per_batch\": %.2f, \"two_queues_us_per_batch\": %.2f, "
 	       "\"serial_frac_of_8TBs\": %.4f, \"list_frac_of_8TBs\": %.4f, \"two_queues_frac_of_8TBs\": %.4f, "
+	       "\"calibration\": {\"serial_us\": %.2f, \"kept_us\": %.2f, \"pair\": %d}, "
 	       "\"list_equals_serial\": %s, \"two_queues_equals_serial\": %s}\n",
 	       nb, (long long)nf, reps, t_a * 1e3 / n, t_b * 1e3 / n, t_c * 1e3 / n, bytes / (t_a * 1e-3 / n) / 8e12, bytes / (t_b * 1e-3 / n) / 8e12,
-	       bytes / (t_c * 1e-3 / n) / 8e12, same_b ? "true" : "false", same_c ? "true" : "false");
+	       bytes / (t_c * 1e-3 / n) / 8e12, cal_serial_us, cal_best_us, cal_pair, same_b ? "true" : "false", same_c ? "true" : "false");
 	free(ha); free(hb);
 	edison_shutdown(ctx);
 	return same_b && same_c ? 0 : 3;

@@ -204,3 +204,41 @@ def test_batch_list_launch_equals_one_call_per_batch(ctx, n_batches, n_each, var
     with pytest.raises(_lib.EdisonError) as ei:
         ctx.mfcc_batches_t(audios, n_each, 1024, _lib.MFCC_C, 13, outs=o2)
     assert ei.value.code == _lib.E_NO_IMPL
+
+
+def test_the_contexts_two_queues(ctx):
+    """edison_queues_calibrate / fork / edison_mfcc_batch_queue_dev / join: whatever pair of streams the calibration keeps (or none: both
+    indices then mean one stream), the outputs equal serial calls bit for bit; what was kept is never slower than the serial sequence by
+    the calibration's own measure; the queue call outside fork ... join and a calibration between them are refused."""
+    import torch
+    from edison_amd import _lib
+    dev = torch.device("cuda", ctx.device)
+    ctx.use_torch_stream()
+    N = 65536
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    bufs = [(torch.randn((N, 1024), generator=g, device=dev) * 3000).clamp_(-32768, 32767).to(torch.int16) for _ in range(3)]
+    ref = []
+    for b in bufs:
+        o = torch.empty((N, 13), dtype=torch.float32, device=dev)
+        ctx.mfcc_t(b, N, 1024, _lib.MFCC_B, 13, out=o)
+        ref.append(o)
+    cal = ctx.queues_calibrate(bufs[0], N)
+    assert 20.0 < cal["serial_us"] < 200.0 and cal["best_us"] <= cal["serial_us"]
+    assert cal["pair"] is None or (0 <= cal["pair"][0] < cal["pair"][1] <= 4 and cal["best_us"] < 0.99 * cal["serial_us"])
+    outs = [torch.zeros((N, 13), dtype=torch.float32, device=dev) for _ in bufs]
+    calls = [ctx.mfcc_queue_call(i & 1, bufs[i], N, 1024, _lib.MFCC_B, 13, out=outs[i]) for i in range(3)]
+    with pytest.raises(_lib.EdisonError) as ei:
+        calls[0]()                                             # not forked
+    assert ei.value.code == _lib.E_ARGUMENT
+    ctx.queues_fork()
+    with pytest.raises(_lib.EdisonError):
+        ctx.queues_calibrate(bufs[0], N)                       # not between fork and join
+    for rep in range(4):
+        for c in calls:
+            c()
+    ctx.queues_join()
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(outs[i], ref[i]), i
+    ctx.queues_join()                                          # a second join is a no-op
