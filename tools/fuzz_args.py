@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Random call shapes of the MFCC entry points against the oracle on the GPU box: frame steps 1..2048 (odd steps take
 the unaligned load path), frame counts 1..300 (odd counts end the two-frame kernel on a half pair), coefficient
-subsets, variants A / B / B+log / C, KWS with random utterance strides.   usage (box): tools/fuzz_args.py [n [seed]]"""
+subsets, variants A / B / B+log / C, KWS with random utterance strides; since round 5 also random LISTS of batches in one launch
+(edison_mfcc_batches_dev: 1..40 batches, odd frame counts, one batch 2-byte aligned only) and the two-queue calls against one call per
+batch, bit for bit, and the generality kernel (edison_mfcc_generic: random frame lengths 4..1500, steps, mel bins, edges, scales) against
+a numpy statement of the reference's formulas.   usage (box): tools/fuzz_args.py [n [seed]]"""
 import os
 import sys
 
@@ -14,6 +17,29 @@ from edison_amd.context import Context  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 
+def np_mfcc(x, N, step, n, variant, nm, fs, lo, hi, scale, use_log):
+    """mfcc_utils.py:160-197 (A) / :287-322 (B) in numpy float64, the mel matrix from the library's host function (itself pinned on the
+    reference's: tests/test_host_cpu.py)."""
+    from edison_amd.mfcc import mfcc_utils as mfu
+    nb = N // 2 if variant == _lib.MFCC_A else N // 2 + 1
+    W = mfu.gen_mel_weight_matrix(nm, nb, fs, lo, hi)
+    k = np.arange(nm)
+    D = 2.0 * np.cos(np.pi * np.outer(k, 2 * np.arange(nm) + 1) / (2.0 * nm))
+    out = np.zeros((n, nm))
+    for f in range(n):
+        X = np.fft.fft(x[f * step:f * step + N].astype(np.float64))
+        if variant == _lib.MFCC_A:
+            e = np.abs(X[:nb]) @ W
+            l = np.log(e + 1e-6)
+            out[f] = D @ l / np.sqrt(2.0 * nm)
+        else:
+            s_ = np.abs(X / 1024.0) / np.sqrt(2.0)
+            e = (s_[:nb] @ (scale * W)) / scale
+            l = np.log(e + 1e-6) if use_log else e
+            out[f] = D @ l / 64.0
+    return out
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
@@ -22,7 +48,49 @@ def main():
     model = oracle.Model()
     worst = 0.0
     for case in range(n_cases):
-        kind = rng.choice(["A", "B", "Blog", "C", "kws"])
+        kind = rng.choice(["A", "B", "Blog", "C", "kws", "list", "queues", "generic"])
+        if kind == "generic":
+            N, nm = int(rng.integers(4, 1501)), int(rng.integers(1, 81))
+            step, n = int(rng.integers(1, 2 * N + 1)), int(rng.integers(1, 12))
+            fs = float(rng.choice([8000.0, 16000.0, 44100.0]))
+            lo = float(rng.uniform(0.0, 0.1 * fs)); hi = float(rng.uniform(lo + 0.05 * fs, 0.5 * fs)); scale = float(rng.choice([1.0, 16.0, 128.0, 1000.0]))
+            variant = _lib.MFCC_A if rng.random() < 0.5 else _lib.MFCC_B
+            use_log = bool(variant == _lib.MFCC_B and rng.random() < 0.5)
+            x = np.clip(rng.normal(0, 10.0 ** rng.uniform(0.5, 4.3), (n - 1) * step + N), -32768, 32767).astype(np.int16)
+            got = np.zeros((n, nm))
+            r_ = _lib.lib().edison_mfcc_generic(ctx._h, x.ctypes.data, n, N, step, variant | (_lib.MFCC_USE_LOG if use_log else 0), nm, fs, lo, hi, scale,
+                                                None, None, None, None, got.ctypes.data, 0, None, 1.0)
+            assert r_ == 0, (kind, N, nm, r_)
+            ref = np_mfcc(x, N, step, n, variant, nm, fs, lo, hi, scale, use_log)
+            assert np.abs(got - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max()), (kind, N, step, n, nm, variant, use_log, np.abs(got - ref).max())
+            continue
+        if kind in ("list", "queues"):
+            nb, n_each, step = int(rng.integers(1, 41 if kind == "list" else 7)), int(rng.integers(1, 120)), int(rng.choice([1024, 512, 1000, 333]))
+            variant, use_log = (_lib.MFCC_A, False) if rng.random() < 0.4 else (_lib.MFCC_B, bool(rng.random() < 0.3))
+            dev = torch.device("cuda", 0)
+            ctx.use_torch_stream()
+            span = (n_each - 1) * step + 1024
+            raws = [torch.from_numpy(np.clip(rng.normal(0, 10.0 ** rng.uniform(0.5, 4.3), span + 2), -32768, 32767).astype(np.int16)).to(dev) for _ in range(nb)]
+            odd = int(rng.integers(0, nb))
+            audios = [r[1:1 + span] if (b == odd and rng.random() < 0.5) else r[:span] for b, r in enumerate(raws)]
+            outs = [torch.zeros((n_each, 13), dtype=torch.float32, device=dev) for _ in range(nb)]
+            feats = [torch.zeros((n_each, 13), dtype=torch.int8, device=dev) for _ in range(nb)]
+            if kind == "list":
+                ctx.mfcc_batches_t(audios, n_each, step, variant, 13, outs=outs, feats=feats, use_log=use_log)
+            else:
+                v = variant | (_lib.MFCC_USE_LOG if use_log else 0)
+                calls = [ctx.mfcc_queue_call(b & 1, audios[b], n_each, step, v, 13, out=outs[b], feat=feats[b]) for b in range(nb)]
+                ctx.queues_fork()
+                for c in calls:
+                    c()
+                ctx.queues_join()
+            torch.cuda.synchronize()
+            for b in range(nb):
+                ro = torch.empty((n_each, 13), dtype=torch.float32, device=dev); rf = torch.empty((n_each, 13), dtype=torch.int8, device=dev)
+                ctx.mfcc_t(audios[b], n_each, step, variant, 13, out=ro, feat=rf, use_log=use_log)
+                torch.cuda.synchronize()
+                assert torch.equal(ro, outs[b]) and torch.equal(rf, feats[b]), (kind, nb, n_each, step, b)
+            continue
         if kind == "kws":
             n_utt, stride = int(rng.integers(1, 9)), int(rng.integers(31 * 1024, 40000))
             audio = np.clip(rng.normal(0, 10.0 ** rng.uniform(1, 4), (n_utt - 1) * stride + 31 * 1024), -32768, 32767).astype(np.int16)
