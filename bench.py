@@ -714,10 +714,11 @@ def main():
         torch.cuda.synchronize()
     n_queues = 2 if (args.queues == 2 or (args.queues == 0 and calibration["pair"] is not None)) else 1
     head_step, head_kw = (q_step, dict(fork=ctx.queues_fork, join=ctx.queues_join)) if n_queues == 2 else (mfcc_step, {})
-    # THE HEADLINE is what the command asked for: W warm-up + K timed steps and nothing else, measured first, on the
-    # board as it comes. With the driver's small counts (W 5, K 20 = 1.5 ms) that includes the power-management transient
-    # of a board that was idle; the same step after `--settle-ms` of untimed repetition is reported
-    # beside it as `settled`, never as `value`.
+    # THE HEADLINE is what the command asked for: W warm-up + K timed steps of the step, and nothing else inside the region. Since round 5
+    # it is NOT the first GPU work of the process any more (with --queues 1 it still is): `serial_cold` above is, and the calibration
+    # between them has kept the board busy for ~0.2 s -- with the driver's small counts (W 5, K 20 = 1.5 ms) the headline is then a burst on
+    # an awake board (boost clocks: faster than settled), where `serial_cold` is a burst on an idle one (slower than settled, DESIGN.md
+    # section 5). `serial` right after it shows what of the difference is the board's; `settled` is the figure that lasts.
     wall_ms, ev_ms = timed_region(head_step, args.steps, args.warmup, world, 0.0, **head_kw)
     # what the LAST timed step left in its output, and the samples it read: checked against the oracle in the cpu_baseline leg (`parity`)
     sample = {}

@@ -10,6 +10,7 @@ from edison_amd import _lib
 from edison_amd.context import Context
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=65536); ap.add_argument("--reps", type=int, default=200); ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--kinds", default="n,n,n,n,h,h,m,m,m")
+ap.add_argument("--tuple", type=int, default=2, help="2: all pairs; 3: all triples (launches rotate over three streams)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 main = torch.cuda.Stream(); torch.cuda.set_stream(main)
@@ -46,14 +47,14 @@ def run(pair, reps):
     else:
         ss = [setter(streams[p][1]) for p in pair]; st = [streams[p][2] for p in pair]
         for s_ in st: s_.wait_event(e0)
-        for i in range(reps): ss[i % 2](); T[i % 6]()
+        for i in range(reps): ss[i % len(ss)](); T[i % 6]()
         for s_ in st:
             d = torch.cuda.Event(); d.record(s_); main.wait_event(d)
         SETMAIN()
     e1.record(main); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 for _ in range(10): run(None, 400)
-pairs = [None] + list(itertools.combinations(range(len(streams)), 2))
+pairs = [None] + list(itertools.combinations(range(len(streams)), a.tuple))
 t = {p: [] for p in pairs}
 for r in range(a.rounds):
     for p in (pairs if r % 2 == 0 else pairs[::-1]):
@@ -62,4 +63,4 @@ base = statistics.median(t[None])
 print("serial: %.2f us" % base)
 for p in pairs[1:]:
     med = statistics.median(t[p])
-    print("%-3s + %-3s: %.2f us  %+5.1f %%" % (streams[p[0]][0], streams[p[1]][0], med, (base / med - 1) * 100))
+    print("%s: %.2f us  %+5.1f %%" % (" + ".join("%-3s" % streams[q][0] for q in p), med, (base / med - 1) * 100))

@@ -38,7 +38,8 @@ def main():
     free0 = torch.cuda.mem_get_info()[0]
     rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     t0 = last = time.time()
-    n = dict(contexts=0, loads=0, own_kernels=0, net_inputs=0, stream_pushes=0, kws_utterances=0, mfcc_frames=0, q15_frames=0)
+    n = dict(contexts=0, loads=0, own_kernels=0, net_inputs=0, stream_pushes=0, kws_utterances=0, mfcc_frames=0, q15_frames=0, calibrations=0, list_launches=0,
+             queue_calls=0, generic_frames=0)
     big = Context(0)
     big.use_torch_stream()
     audio = torch.from_numpy(np.clip(rng.normal(0, 3000, 16384 * 31744), -32768, 32767).astype(np.int16)).to(dev)
@@ -87,9 +88,9 @@ def main():
         feat_t = torch.zeros((nu, 403), dtype=torch.int8, device=dev)
         lo = torch.zeros((nu, 10), dtype=torch.int8, device=dev)
         am = torch.zeros((nu,), dtype=torch.int32, device=dev)
-        big.kws_t(audio, nu, 31744, feat=feat_t, logits=lo, argmax=am, q15=bool(n["contexts"] & 1))
+        big.kws_t(audio, nu, 31744, feat=feat_t, logits=lo, argmax=am, q15=bool(n["loads"] & 1))
         torch.cuda.synchronize()
-        key = (bool(n["contexts"] & 1), am.cpu().numpy().copy())
+        key = (bool(n["loads"] & 1), am.cpu().numpy().copy())
         if ref_am is None:
             ref_am = {}
         if key[0] in ref_am:
@@ -97,6 +98,44 @@ def main():
         ref_am[key[0]] = key[1]
         n["kws_utterances"] += nu
         n["q15_frames" if key[0] else "mfcc_frames"] += nu * 31
+        # ---- D (round 5): a fresh context calibrates its two queues (five streams, events: created and destroyed with the context), runs a list of
+        # batches in one launch and the same batches over its queues -- both bit-identical to one call per batch; a random other geometry
+        # through the generality kernel against numpy
+        c = Context(0, model_path=None)
+        c.use_torch_stream()
+        nb, n_each = int(rng.integers(2, 20)), int(rng.integers(1, 3000))
+        xs = [audio[b * n_each * 1024:(b + 1) * n_each * 1024] for b in range(nb)]
+        cal = c.queues_calibrate(audio[:8192 * 1024], 8192)
+        refs = []
+        for b in range(nb):
+            o = torch.empty((n_each, 13), dtype=torch.float32, device=dev)
+            c.mfcc_t(xs[b], n_each, 1024, _lib.MFCC_B, 13, out=o)
+            refs.append(o)
+        outs = [torch.zeros((n_each, 13), dtype=torch.float32, device=dev) for _ in range(nb)]
+        c.mfcc_batches_t(xs, n_each, 1024, _lib.MFCC_B, 13, outs=outs)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(outs, refs)), ("list", nb, n_each)
+        outs = [torch.zeros((n_each, 13), dtype=torch.float32, device=dev) for _ in range(nb)]
+        calls = [c.mfcc_queue_call(b & 1, xs[b], n_each, 1024, _lib.MFCC_B, 13, out=outs[b]) for b in range(nb)]
+        c.queues_fork()
+        for cl in calls:
+            cl()
+        c.queues_join()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(outs, refs)), ("queues", nb, n_each, cal)
+        N, nm = int(rng.integers(4, 1200)), int(rng.integers(1, 60))
+        gx = np.clip(rng.normal(0, 3000, 3 * N), -32768, 32767).astype(np.int16)
+        got = np.zeros((3, nm))
+        assert _lib.lib().edison_mfcc_generic(c._h, gx.ctypes.data, 3, N, N, _lib.MFCC_B, nm, 16000.0, 80.0, 7600.0, 128.0, None, None, None, None, got.ctypes.data, 0, None, 1.0) == 0
+        from edison_amd.mfcc import mfcc_utils as mfu
+        W = mfu.gen_mel_weight_matrix(nm, N // 2 + 1, 16000, 80.0, 7600.0)
+        D = 2.0 * np.cos(np.pi * np.outer(np.arange(nm), 2 * np.arange(nm) + 1) / (2.0 * nm))
+        for f in range(3):
+            e = ((np.abs(np.fft.fft(gx[f * N:(f + 1) * N].astype(np.float64)) / 1024.0) / np.sqrt(2.0))[:N // 2 + 1] @ (128.0 * W)) / 128.0
+            assert np.abs(got[f] - D @ e / 64.0).max() <= 1e-8 * max(1.0, np.abs(e).max()), ("generic", N, nm)
+        c.close()
+        del refs, outs, calls, xs, cl, o
+        n["contexts"] += 1; n["calibrations"] += 1; n["list_launches"] += 1; n["queue_calls"] += nb; n["generic_frames"] += 3
         if time.time() - last > 20:
             last = time.time()
             torch.cuda.synchronize()
