@@ -547,13 +547,25 @@ static int pipe_setup(edison_ctx *ctx)
 	int least = 0, greatest = 0;
 	ED_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
 	hipError_t e = hipSuccess;
-	for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipStreamCreateWithPriority(&ctx->pipe_cand[k], hipStreamNonBlocking, k < 3 ? least : greatest);
-	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipe_fork, hipEventDisableTiming);
-	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipe_join[0], hipEventDisableTiming);
-	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipe_join[1], hipEventDisableTiming);
-	if (e == hipSuccess) e = hipEventCreate(&ctx->pipe_t0);
-	if (e == hipSuccess) e = hipEventCreate(&ctx->pipe_t1);
-	ED_HIP(ctx, e);
+	int n_streams = 0, n_events = 0;
+	hipEvent_t *ev[5] = {&ctx->pipe_fork, &ctx->pipe_join[0], &ctx->pipe_join[1], &ctx->pipe_t0, &ctx->pipe_t1};
+	for (int k = 0; k < 5 && e == hipSuccess; k++)
+	{
+		e = hipStreamCreateWithPriority(&ctx->pipe_cand[k], hipStreamNonBlocking, k < 3 ? least : greatest);
+		if (e == hipSuccess) n_streams++;
+	}
+	for (int k = 0; k < 5 && e == hipSuccess; k++)
+	{
+		e = k < 3 ? hipEventCreateWithFlags(ev[k], hipEventDisableTiming) : hipEventCreate(ev[k]); /* the last two time the calibration */
+		if (e == hipSuccess) n_events++;
+	}
+	if (e != hipSuccess)
+	{
+		/* all or nothing: a half-built set is taken down again, the next call starts over */
+		for (int k = 0; k < n_events; k++) (void)hipEventDestroy(*ev[k]);
+		for (int k = 0; k < n_streams; k++) (void)hipStreamDestroy(ctx->pipe_cand[k]);
+		ED_HIP(ctx, e);
+	}
 	/* until a calibration says otherwise: one stream of each priority -- different hardware queues by construction */
 	ctx->pipe_pair[0] = 0; ctx->pipe_pair[1] = 3;
 	ctx->pipe_q[0] = ctx->pipe_cand[0]; ctx->pipe_q[1] = ctx->pipe_cand[3];
@@ -628,7 +640,7 @@ static double median_of(double *v, int n)
  * takes 43.5 us, +4 ... 7 % on boxes at 47-48 us), a third changed nothing and a third LOST 8-10 % (profiles/r05_mfcc_two_queues_notes.txt).
  * So the library measures: every pair of its five candidates and the serial sequence, interleaved, on the caller's own batch (device
  * pointer, read only; outputs go to scratch), then the winner against the serial sequence once more; it keeps the pair only if it
- * is at least 1 % faster, otherwise both queue indices mean ONE stream and the queue calls are the serial sequence. ~0.1 s. */
+ * is at least 1 % faster, otherwise both queue indices mean ONE stream and the queue calls are the serial sequence. ~0.17 s at 65 536 frames. */
 extern "C" int edison_queues_calibrate(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step, int variant,
                                        double *serial_us, double *best_us, int *pair_kept)
 {

@@ -155,7 +155,7 @@ __device__ __forceinline__ void ed_pair_ptrs(const ed_mfcc_args_t &a, const ed_m
 		if (LIST)
 		{
 			pa = list->audio[g] + (int64_t)i * a.frame_step;
-			pb = !haveB ? pa : (i + 1 < fpg ? pa + a.frame_step : list->audio[g + 1]);
+			pb = !haveB ? pa : (i + 1 < fpg ? pa + a.frame_step : list->audio[g + 1 < ED_MFCC_LIST_MAX ? g + 1 : g]);
 			g_out = g; i_out = i;
 		}
 		else
@@ -489,7 +489,7 @@ __device__ __forceinline__ void ed_mfcc2_body(const ed_mfcc_args_t &args, const 
 				/* frame A is row gi_cur of batch g_cur; frame B the next row, or row 0 of the next batch */
 				const uint32_t fpg = (uint32_t)args.frames_per_group;
 				const bool wrap = gi_cur + 1 >= fpg;
-				const uint32_t gB = wrap ? g_cur + 1 : g_cur, iB = wrap ? 0u : gi_cur + 1;
+				const uint32_t gB = wrap ? (g_cur + 1 < ED_MFCC_LIST_MAX ? g_cur + 1 : g_cur) : g_cur, iB = wrap ? 0u : gi_cur + 1; /* (never past the table: a last odd frame has no B) */
 				const bool isB = lane >= 32;
 				const int64_t at = (int64_t)(isB ? iB : gi_cur) * args.n_coef + c;
 				if (args.mfcc) { float *o = isB ? list->mfcc[gB] : list->mfcc[g_cur]; o[at] = coef; }
