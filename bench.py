@@ -706,13 +706,16 @@ def main():
                            what="W + K steps, one call per batch on one queue, as the FIRST GPU work of the process: the measurement that was the headline of "
                                 "rounds 1-4 (BENCH_r01-r04), before the queue calibration has run")
         t_c = time.perf_counter()
-        calibration = ctx.queues_calibrate(bufs[0], nf)
-        calibration = dict(serial_us=round(calibration["serial_us"], 2), best_us=round(calibration["best_us"], 2), pair=calibration["pair"],
-                           seconds=round(time.perf_counter() - t_c, 3),
-                           what="edison_queues_calibrate: the serial sequence and every pair of the context's 5 candidate streams (3 least, 2 greatest priority), "
-                                "interleaved blocks of 32-64 launches of this batch; pair = the candidates kept, null = no pair was 1 % faster: one queue")
+        try:
+            calibration = ctx.queues_calibrate(bufs[0], nf)
+            calibration = dict(serial_us=round(calibration["serial_us"], 2), best_us=round(calibration["best_us"], 2), pair=calibration["pair"],
+                               seconds=round(time.perf_counter() - t_c, 3),
+                               what="edison_queues_calibrate: the serial sequence and every pair of the context's 5 candidate streams (3 least, 2 greatest priority), "
+                                    "interleaved blocks of 32-64 launches of this batch; pair = the candidates kept, null = no pair was 1 % faster: one queue")
+        except Exception as e:  # noqa: BLE001 -- a calibration that cannot run costs the second queue, not the line
+            calibration = dict(pair=None, error=repr(e))
         torch.cuda.synchronize()
-    n_queues = 2 if (args.queues == 2 or (args.queues == 0 and calibration["pair"] is not None)) else 1
+    n_queues = 2 if ((args.queues == 2 and "error" not in (calibration or {})) or (args.queues == 0 and calibration["pair"] is not None)) else 1
     head_step, head_kw = (q_step, dict(fork=ctx.queues_fork, join=ctx.queues_join)) if n_queues == 2 else (mfcc_step, {})
     # THE HEADLINE is what the command asked for: W warm-up + K timed steps of the step, and nothing else inside the region. Since round 5
     # it is NOT the first GPU work of the process any more (with --queues 1 it still is): `serial_cold` above is, and the calibration
