@@ -221,3 +221,21 @@ def test_variant_d_restatement_against_the_reference_made_fixture(oracle_mod):
         assert d.max() <= 1 and (d == 0).mean() >= bar, (i, d.max(), (d == 0).mean())
         from test_oracle_refpins import _variant_d_logmel_close
         _variant_d_logmel_close(x, int(hop), int(flen), float(pre), rlm, plm)
+
+
+def test_numpy_restatement_for_other_geometries_equals_the_reference(oracle_mod):
+    """oracle.mfcc_numpy (variants A / B at any frame length, numpy's FFT as in the reference) against the vectors the REFERENCE's own
+    functions produced for six other geometries (tests/golden/gen_fixtures_geom.py): 33 ... 2048 samples, powers of two and not,
+    5 ... 64 mel bins, other edges and scales. This is the checker the GPU fuzzers use for the generality kernel."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mfcc_geom_golden.npz"))
+    for idx, name in enumerate(g["names"]):
+        N, step, nm, lo, hi, scale = g["configs"][idx]
+        N, step, nm = int(N), int(step), int(nm)
+        for sname in ("edison", "noise"):
+            x = g["in_" + sname]
+            k = "%s_%s_" % (name, sname)
+            for tag, variant, use_log in (("A", oracle_mod.VARIANT_A, False), ("B", oracle_mod.VARIANT_B, False), ("Blog", oracle_mod.VARIANT_B, True)):
+                got = oracle_mod.mfcc_numpy(x, variant, N, step, num_mel_bins=nm, lower_edge_hertz=lo, upper_edge_hertz=hi, mel_mtx_scale=scale, use_log=use_log)
+                ref = g[k + tag + "_mfcc"]
+                assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), (name, sname, tag)

@@ -4,7 +4,7 @@ the unaligned load path), frame counts 1..300 (odd counts end the two-frame kern
 subsets, variants A / B / B+log / C, KWS with random utterance strides; since round 5 also random LISTS of batches in one launch
 (edison_mfcc_batches_dev: 1..40 batches, odd frame counts, one batch 2-byte aligned only) and the two-queue calls against one call per
 batch, bit for bit, and the generality kernel (edison_mfcc_generic: random frame lengths 4..1500, steps, mel bins, edges, scales) against
-a numpy statement of the reference's formulas.   usage (box): tools/fuzz_args.py [n [seed]]"""
+oracle.mfcc_numpy (numpy's FFT like the reference; pinned on the reference's own outputs for six geometries).   usage (box): tools/fuzz_args.py [n [seed]]"""
 import os
 import sys
 
@@ -15,29 +15,6 @@ import torch  # noqa: F401,E402
 from edison_amd import _lib  # noqa: E402
 from edison_amd.context import Context  # noqa: E402
 from oracle import oracle  # noqa: E402
-
-
-def np_mfcc(x, N, step, n, variant, nm, fs, lo, hi, scale, use_log):
-    """mfcc_utils.py:160-197 (A) / :287-322 (B) in numpy float64, the mel matrix from the library's host function (itself pinned on the
-    reference's: tests/test_host_cpu.py)."""
-    from edison_amd.mfcc import mfcc_utils as mfu
-    nb = N // 2 if variant == _lib.MFCC_A else N // 2 + 1
-    W = mfu.gen_mel_weight_matrix(nm, nb, fs, lo, hi)
-    k = np.arange(nm)
-    D = 2.0 * np.cos(np.pi * np.outer(k, 2 * np.arange(nm) + 1) / (2.0 * nm))
-    out = np.zeros((n, nm))
-    for f in range(n):
-        X = np.fft.fft(x[f * step:f * step + N].astype(np.float64))
-        if variant == _lib.MFCC_A:
-            e = np.abs(X[:nb]) @ W
-            l = np.log(e + 1e-6)
-            out[f] = D @ l / np.sqrt(2.0 * nm)
-        else:
-            s_ = np.abs(X / 1024.0) / np.sqrt(2.0)
-            e = (s_[:nb] @ (scale * W)) / scale
-            l = np.log(e + 1e-6) if use_log else e
-            out[f] = D @ l / 64.0
-    return out
 
 
 def main():
@@ -61,7 +38,8 @@ def main():
             r_ = _lib.lib().edison_mfcc_generic(ctx._h, x.ctypes.data, n, N, step, variant | (_lib.MFCC_USE_LOG if use_log else 0), nm, fs, lo, hi, scale,
                                                 None, None, None, None, got.ctypes.data, 0, None, 1.0)
             assert r_ == 0, (kind, N, nm, r_)
-            ref = np_mfcc(x, N, step, n, variant, nm, fs, lo, hi, scale, use_log)
+            ref = oracle.mfcc_numpy(x, oracle.VARIANT_A if variant == _lib.MFCC_A else oracle.VARIANT_B, N, step, n_frames=n, num_mel_bins=nm, sample_rate=fs,
+                                    lower_edge_hertz=lo, upper_edge_hertz=hi, mel_mtx_scale=scale, use_log=use_log)   # pinned on the reference's outputs: tests/test_oracle.py
             assert np.abs(got - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max()), (kind, N, step, n, nm, variant, use_log, np.abs(got - ref).max())
             continue
         if kind in ("list", "queues"):
