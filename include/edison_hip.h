@@ -225,7 +225,7 @@ int edison_mfcc_rows_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_rows, 
  * launch per 16 batches (`audio`, `mfcc`, `feat` are HOST arrays of DEVICE pointers, read during the call). Rows of batch_mfcc that
  * do not share an allocation (mfcc_utils.py:75-131: rows are independent), or batches arriving from different producers. Why it
  * exists: a 65 536-frame launch idles ~15 % of its window (start-up, drain), a launch that runs on does not (0.41-0.42 of 8 TB/s
- * against 0.37-0.39), and keeping the NEXT launch in flight on a second HIP queue does not recover it on this hardware
+ * against 0.37-0.40), and keeping the NEXT launch in flight on a second HIP queue (below) recovers a quarter of it at best
  * (profiles/r05_mfcc_two_queues_notes.txt). Variants A and B (EDISON_E_NO_IMPL otherwise). Results are bit-identical to one
  * edison_mfcc_batch_dev call per batch.
  */
@@ -234,21 +234,22 @@ int edison_mfcc_batches_dev(edison_ctx *ctx, int n_batches, const int16_t *const
 
 /*
  * One call per batch with the NEXT launch already in flight: two library-owned HIP queues per context (created with different
- * priorities, hence on different hardware queues: HIP shares a pool of hardware queues among the streams of ONE priority).
+ * priorities by default: HIP shares a pool of hardware queues among the streams of ONE priority, two such streams may serialise).
  *   edison_queues_fork(ctx)                  both queues wait for what the context's stream holds so far (the batches' producers)
  *   edison_mfcc_batch_queue_dev(ctx, q, ...) edison_mfcc_batch_dev on queue q = 0 / 1; batches in flight together must be independent
  *                                            (own input, own outputs); alternate q from call to call
  *   edison_queues_join(ctx)                  the context's stream waits for both queues; outputs are ordered as usual after it
  * Between fork and join the context's stream must not be changed (edison_set_stream) and only the queue call may be used. Results
  * are bit-identical to the plain calls. From a host that keeps both queues fed (a C host, ~5 us per call) a 65 536-frame batch
- * takes 45.7 us instead of 47.7 (+4.5 %); a host that needs as long per call as the GPU per batch gains nothing
+ * takes 45.7 us instead of 47.7 (+4.5 %; +1 ... +2.6 % on boards that sit at their power cap); a host that needs as long per call as the
+ * GPU per batch gains nothing
  * (profiles/r05_mfcc_two_queues_notes.txt). The list call above is the faster way whenever the batches are known together.
  * Which two streams: whether the next launch really backfills the CUs this one leaves depends on where runtime and driver put the two
  * streams' hardware queues, which HIP does not let a program choose -- of all pairs of nine streams in one process a third gained, a
  * third changed nothing, a third LOST 8-10 %. edison_queues_calibrate measures it: every pair of the context's five candidate streams
  * (three of the least, two of the greatest priority) and the serial sequence, interleaved, on the caller's own batch (`audio`: device
  * pointer, n_frames frames, read only), the winner once more against the serial sequence; the pair is kept only if it is at least 1 %
- * faster, otherwise both queue indices mean one stream and the queue calls ARE the serial sequence (never slower than it). ~0.1 s for a
+ * faster, otherwise both queue indices mean one stream and the queue calls ARE the serial sequence (never slower than it). ~0.17 s for a
  * 65 536-frame batch; call it once, after edison_init / edison_mfcc_configure, with a batch of the size that will be used. Outputs (each
  * may be NULL): microseconds per batch of the serial sequence and of what was kept, pair_kept = 10 * i + j (candidate indices) or 0.
  * Without a calibration the queues are one stream of each priority.
