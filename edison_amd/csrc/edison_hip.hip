@@ -659,6 +659,24 @@ extern "C" int edison_queues_calibrate(edison_ctx *ctx, const int16_t *audio, in
 	pa[np] = 0; pb[np] = 0; np++;                                  /* entry 0: the serial sequence */
 	for (int i = 0; i < NC; i++) for (int j = i + 1; j < NC; j++) { pa[np] = i; pb[np] = j; np++; }
 	double t[NP + 1][ROUNDS];
+	/* A launch that takes milliseconds has nothing to gain from a second queue (its fixed cost is a few microseconds) and the calibration would
+	 * take seconds: one short serial block decides, and such a batch keeps one queue. */
+	{
+		double probe = 0;
+		const int rc = pipe_time_pair(ctx, ctx->pipe_cand[0], ctx->pipe_cand[0], audio, n_frames, frame_step, variant, out, 4, &probe);
+		if (rc != EDISON_OK) return rc;
+		if (probe > 1000.0)
+		{
+			ctx->pipe_pair[0] = ctx->pipe_pair[1] = 0;
+			ctx->pipe_q[0] = ctx->pipe_q[1] = ctx->pipe_cand[0];
+			ctx->pipe_cal_serial_us = ctx->pipe_cal_best_us = probe;
+			if (serial_us) *serial_us = probe;
+			if (best_us) *best_us = probe;
+			if (pair_kept) *pair_kept = 0;
+			ED_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			return EDISON_OK;
+		}
+	}
 	for (int r = 0; r < ROUNDS; r++)
 		for (int k0 = 0; k0 < np; k0++)
 		{

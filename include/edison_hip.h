@@ -252,6 +252,7 @@ int edison_mfcc_batches_dev(edison_ctx *ctx, int n_batches, const int16_t *const
  * faster, otherwise both queue indices mean one stream and the queue calls ARE the serial sequence (never slower than it). ~0.17 s for a
  * 65 536-frame batch; call it once, after edison_init / edison_mfcc_configure, with a batch of the size that will be used. Outputs (each
  * may be NULL): microseconds per batch of the serial sequence and of what was kept, pair_kept = 10 * i + j (candidate indices) or 0.
+ * A batch whose launch takes more than a millisecond keeps one queue without further measurement (its fixed cost is microseconds).
  * Without a calibration the queues are one stream of each priority.
  */
 int edison_queues_calibrate(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int64_t frame_step, int variant, double *serial_us,

@@ -242,3 +242,21 @@ def test_the_contexts_two_queues(ctx):
     for i in range(3):
         assert torch.equal(outs[i], ref[i]), i
     ctx.queues_join()                                          # a second join is a no-op
+
+
+def test_queue_calibration_of_a_long_launch_is_short(ctx):
+    """A batch whose launch takes milliseconds (2 M frames: ~1.4 ms) keeps one queue after one short probe: the calibration must not spend
+    seconds on launches that have nothing to gain from a second queue."""
+    import time
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    ctx.use_torch_stream()
+    N = 1 << 21
+    x = torch.zeros((N, 1024), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cal = ctx.queues_calibrate(x, N)
+    dt = time.perf_counter() - t0
+    assert cal["pair"] is None and cal["serial_us"] > 1000.0 and dt < 1.0, (cal, dt)
+    del x
+    torch.cuda.empty_cache()
