@@ -510,3 +510,29 @@ def test_retrained_kws_conv_with_other_output_shifts_on_the_matrix_core_kernel(s
         assert np.array_equal(got["logits"], ref["logits"]), (shifts, n)
         assert np.array_equal(got["softmax"], ref["softmax"]) and np.array_equal(got["argmax"], ref["argmax"]), (shifts, n)
     c2.close()
+
+
+def test_dataset_features_equal_the_per_utterance_loop(ctx, oracle_mod, kws_golden):
+    """edison_amd.kws.features.dataset_features = the MFCC leg of the reference's load_data (kws_keras.py:443-468: mfcc_mcu per
+    utterance, [first_mfcc : first_mfcc + num_mfcc], * net_input_scale, clip -- floats, not rounded --, channel axis) for a whole data
+    set in ONE launch: against the oracle's float64 variant B utterance by utterance (variant B's fp32 bar, where nothing is clipped;
+    clipped entries equal the bound), and rounded it is the int8 net input of the KWS path."""
+    from edison_amd.kws.features import dataset_features
+    rng = np.random.default_rng(31)
+    x = np.clip(rng.normal(0, 2500, (7, 32000)), -32768, 32767).astype(np.int16)
+    x[3] = kws_golden["kws_zero_audio"][:32000]
+    x[5] = 0
+    f = dataset_features(x, ctx=ctx)
+    assert f.shape == (7, 31, 13, 1) and f.dtype == np.float64
+    for u in range(7):
+        ref = oracle_mod.mfcc(x[u, :31 * 1024], oracle_mod.VARIANT_B)[:, :13]
+        want = np.clip(ref * 1.0, -128, 127)
+        got = f[u, :, :, 0]
+        inside = (ref > -128) & (ref < 127)
+        assert np.all(np.abs(got - want)[inside] <= 1e-2 + 1e-5 * np.abs(ref)[inside]) and np.all(got[~inside] == want[~inside]), u
+    r = ctx.kws(x.reshape(-1), n_utt=7, utt_stride=32000)
+    assert np.abs(np.round(f[..., 0]).astype(int) - r["feat"].reshape(7, 31, 13).astype(int)).max() <= 1   # x.5 cases may round the other way
+    # a sub-range of coefficients and the logarithm
+    g = dataset_features(x[:2], first_mfcc=2, num_mfcc=5, use_mfcc_log=True, ctx=ctx)
+    ref = oracle_mod.mfcc(x[1, :31 * 1024], oracle_mod.VARIANT_B, use_log=True)[:, 2:7]
+    assert g.shape == (2, 31, 5, 1) and np.abs(g[1, :, :, 0] - np.clip(ref, -128, 127)).max() <= 2e-3
