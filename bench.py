@@ -193,6 +193,25 @@ def _c_host_latency(graph):
         return dict(error=repr(e))
 
 
+def _c_host_pipeline():
+    """examples/host_mfcc_pipeline.c: 8 independent 65 536-frame batches from a plain C host, one call per batch / one list launch / the context's two calibrated
+    queues, medians of five interleaved passes, wall clock, results compared bit for bit -- its own JSON line, or an error."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "bin", "host_mfcc_pipeline")
+    if not os.path.exists(exe):
+        return dict(error="examples/bin/host_mfcc_pipeline not built (python -m edison_amd.build)")
+    try:
+        r = subprocess.run([exe, "8", "65536", "100"], capture_output=True, text=True, timeout=120)
+        if r.returncode != 0:
+            return dict(error="exit %d: %s" % (r.returncode, (r.stderr or r.stdout).strip()[-200:]))
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        d["what"] = ("examples/host_mfcc_pipeline.c (no Python): microseconds of wall clock per batch for the serial sequence, one edison_mfcc_batches_dev launch per 8 batches, "
+                     "and one edison_mfcc_batch_queue_dev call per batch on the calibrated queues; a child process with its own context and its own calibration")
+        return d
+    except Exception as e:  # noqa: BLE001 -- a side figure must never cost the line
+        return dict(error=repr(e))
+
+
 def stream_bench(ctx, dev):
     """BASELINE configs[4]: 1 h of synthetic 16 kHz audio (57.6 M samples), 1024-sample frames at hop 512
     (50 % overlap) -> 112 499 frames, an inference on the newest 31 frames after every frame.
@@ -1032,9 +1051,10 @@ def main():
             del audio
 
     # ------------------------------------------------------------------ streaming (configs[4]): rank 0, N = 1 only
-    streaming = None
+    streaming = c_pipeline = None
     if rank == 0 and world == 1 and not args.skip_stream:
         streaming = stream_bench(ctx, dev)
+        c_pipeline = _c_host_pipeline()
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     cpu = parity = None
@@ -1088,6 +1108,8 @@ def main():
             line["kws"] = kws
         if streaming is not None:
             line["streaming"] = streaming
+        if c_pipeline is not None:
+            line["batches_from_a_c_host"] = c_pipeline
         if cpu is not None:
             if "mfcc" in cpu:
                 line["cpu_baseline"] = cpu["mfcc"]
