@@ -736,6 +736,12 @@ def main():
         torch.cuda.synchronize()
     n_queues = 2 if ((args.queues == 2 and "error" not in (calibration or {})) or (args.queues == 0 and calibration["pair"] is not None)) else 1
     head_step, head_kw = (q_step, dict(fork=ctx.queues_fork, join=ctx.queues_join)) if n_queues == 2 else (mfcc_step, {})
+    # N > 1: every rank calibrates its own streams, so `config.queues` is rank 0's finding; how many ranks run two queues rides beside it
+    ranks_two_queues = None
+    if world > 1:
+        tq = torch.tensor([1 if n_queues == 2 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(tq)
+        ranks_two_queues = int(tq.item())
     # THE HEADLINE is what the command asked for: W warm-up + K timed steps of the step, and nothing else inside the region. Since round 5
     # it is NOT the first GPU work of the process any more (with --queues 1 it still is): `serial_cold` above is, and the calibration
     # between them has kept the board busy for ~0.2 s -- with the driver's small counts (W 5, K 20 = 1.5 ms) the headline is then a burst on
@@ -774,7 +780,8 @@ def main():
                        roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (sev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), settle_ms=args.settle_ms,
                        what="the same workload after settle_ms of untimed repetition of the step in front of the W warm-up steps (clocks and "
                             "power settled); a side figure, the headline is the W + K run above")
-        if n_queues == 2:
+        # (N > 1: whether a pair was kept is each rank's own finding, and timed_region holds barriers -- every rank runs this leg or none does)
+        if (n_queues == 2) if world == 1 else (args.queues != 1):
             s1_ms, s1ev_ms = timed_region(mfcc_step, n_settled, args.warmup, world, args.settle_ms)
             settled["serial"] = dict(value=round(world * nf / (s1_ms * 1e-3), 1), ms_per_step=round(s1_ms, 4), kernel_ms=round(s1ev_ms, 4),
                                      roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (s1ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
@@ -1076,7 +1083,8 @@ def main():
                     ms_per_step=round(wall_ms, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
                     dtype="f32", data="synthetic",
                     config=dict(workload="mfcc_batch_%dx1024_int16_per_gpu_variantB_13coef" % nf, global_batch=world * nf,
-                                frame_len=1024, parallelism="dp%d" % world, rotate_buffers=args.rotate, queues=n_queues),
+                                frame_len=1024, parallelism="dp%d" % world, rotate_buffers=args.rotate, queues=n_queues,
+                                **({} if ranks_two_queues is None else {"ranks_with_two_queues": ranks_two_queues})),
                     roofline=roofline, device=info["name"])
         if parity is not None:
             line["parity"] = parity

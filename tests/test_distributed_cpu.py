@@ -226,3 +226,48 @@ def test_bench_guarded_leg_that_returns_is_not_disturbed():
     r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"], env_extra=dict(EDISON_BENCH_WATCHDOG_S="60"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert _json_lines(r.stdout)[0]["checks"]["cabi_collective"]["status"].startswith("ok")
+
+
+def test_bench_collectives_do_not_sit_under_rank_local_conditions():
+    """At N > 1 `timed_region(..., world, ...)` holds barriers and an all-reduce, so every rank must reach every such call: none may sit
+    under an `if` whose test reads something a rank finds out for itself (the queue calibration's outcome, the parity sample that only
+    rank 0 keeps, the rank). A test may name such a value only when it also pins world == 1. Round 5 had `if n_queues == 2:` around one."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    rank_local = {"n_queues", "calibration", "sample", "rank", "same", "same_l", "parity", "local_rank"}
+    found = []
+
+    def names(node):
+        return {n.id for n in ast.walk(node) if isinstance(n, ast.Name)}
+
+    def pins_world_one(test):
+        # `... world == 1 ...` anywhere in the test: at N > 1 the rank-local part cannot decide alone only if it is the `X if world == 1 else Y`
+        # form (the rank-local X is then dead at N > 1) or an `and` with world == 1 (the whole branch is dead at N > 1)
+        if isinstance(test, ast.IfExp):
+            return "world" in names(test.test) and not (names(test.orelse) & rank_local)
+        if isinstance(test, ast.BoolOp) and isinstance(test.op, ast.And):
+            return any(isinstance(v, ast.Compare) and "world" in names(v) for v in test.values)
+        return False
+
+    def walk(node, guards):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == "timed_region":
+            if len(node.args) >= 4 and "world" in names(node.args[3]):
+                found.append(node.lineno)
+                for g in guards:
+                    assert not (names(g) & rank_local) or pins_world_one(g), \
+                        "bench.py:%d: timed_region(..., world) under a rank-local condition (line %d)" % (node.lineno, g.lineno)
+        if isinstance(node, ast.If):
+            walk(node.test, guards)
+            for c in node.body:
+                walk(c, guards + [node.test])
+            for c in node.orelse:
+                walk(c, guards + [node.test])
+            return
+        if isinstance(node, (ast.FunctionDef, ast.Lambda)) and node is not main:
+            return        # nested step functions: called from timed_region, not the other way round
+        for c in ast.iter_child_nodes(node):
+            walk(c, guards)
+
+    walk(main, [])
+    assert len(found) >= 10, found
