@@ -5,6 +5,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -56,6 +57,7 @@ static int check_geometry(edison_ctx *ctx, int64_t n_frames, int frame_len, int6
 	if (v != EDISON_MFCC_A && v != EDISON_MFCC_B) return ed_set_err(ctx, EDISON_E_NO_IMPL, "edison_mfcc_generic: variants A and B");
 	if (v == EDISON_MFCC_A && (variant & EDISON_MFCC_USE_LOG)) return ed_set_err(ctx, EDISON_E_ARGUMENT, "variant A always takes the logarithm");
 	if (n_frames < 0 || frame_step < 0) return EDISON_E_ARGUMENT;
+	if (n_frames > INT32_MAX) return ed_set_err(ctx, EDISON_E_SIZE, "edison_mfcc_generic: more than 2^31 frames in one call");
 	if (frame_len < 4 || frame_len > ED_GEN_MAX_FRAME) return ed_set_err(ctx, EDISON_E_NO_IMPL, "edison_mfcc_generic: frame_len 4 .. 4096");
 	if (mel_nbins < 1 || mel_nbins > ED_GEN_MAX_MEL) return ed_set_err(ctx, EDISON_E_NO_IMPL, "edison_mfcc_generic: mel_nbins 1 .. 256");
 	if (!(fs > 0) || !(lo >= 0) || !(hi > lo) || !(scale > 0)) return ed_set_err(ctx, EDISON_E_ARGUMENT, "edison_mfcc_generic: bad filterbank edges / scale");
