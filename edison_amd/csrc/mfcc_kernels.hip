@@ -180,7 +180,7 @@ __device__ __forceinline__ void ed_pair_ptrs(const ed_mfcc_args_t &a, const ed_m
  * workgroups' finishing times and buys nothing -- the board sits at its power cap and takes the recovered idle time back as
  * clock (profiles/r04_mfcc_launch_structure_notes.txt).
  */
-template <bool ALIGNED, bool PLAIN, int NLO, int NHI, bool LIST>
+template <bool ALIGNED, bool PLAIN, int NLO, int NHI, bool LIST, bool WINDOW = false>
 __device__ __forceinline__ void ed_mfcc2_body(const ed_mfcc_args_t &args, const ed_mfcc_tables_t *__restrict__ tab, const ed_mfcc_list_t *list)
 {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -296,6 +296,16 @@ __device__ __forceinline__ void ed_mfcc2_body(const ed_mfcc_args_t &args, const 
 		{
 			re[a] = ed_mk2((float)(int16_t)(rawA[a] & 0xffffu), (float)(int16_t)(rawB[a] & 0xffffu));
 			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
+		}
+		if (WINDOW) /* variant TF: tf.signal.stft's Hann window on the float32 samples, (w[2m], w[2m+1]) per packed point, the same for both frames */
+		{
+#pragma unroll
+			for (int a = 0; a < 8; a++)
+			{
+				const float2 w = *reinterpret_cast<const float2 *>(&tab->window2[lane + 64 * a][0]);
+				re[a] = re[a] * ed_splat(w.x);
+				im[a] = im[a] * ed_splat(w.y);
+			}
 		}
 	}
 	while (i_cur < cnt)
@@ -458,6 +468,16 @@ __device__ __forceinline__ void ed_mfcc2_body(const ed_mfcc_args_t &args, const 
 		if (do_log) { asm volatile(""); t = __logf(t + log_offset); } /* the empty asm keeps this a branch (wave-uniform) */
 
 		ED2_ST(9)
+		/* WINDOW: the next pair's window values are asked for here, behind the mel stage and its folds, where the fewest registers are live; the lane number is
+		 * made opaque so that the sixteen values are not kept in registers across the loop (the kernel sits at the 160 that three waves per SIMD allow) */
+		float2 wv[8];
+		if (WINDOW)
+		{
+			int wl = lane;
+			asm volatile("" : "+v"(wl));
+#pragma unroll
+			for (int a = 0; a < 8; a++) wv[a] = *reinterpret_cast<const float2 *>(&tab->window2[wl + 64 * a][0]);
+		}
 		/* ---- 6. DCT-II through cos symmetry, both frames: u = L[b] + L[31-b] (even rows), v = L[b] - L[31-b] (odd) */
 		ed_f2 *Lb2 = reinterpret_cast<ed_f2 *>(xbuf + ED2_L_OFF); /* u[16] | v[16] as float2 (A, B) */
 		{
@@ -509,6 +529,11 @@ __device__ __forceinline__ void ed_mfcc2_body(const ed_mfcc_args_t &args, const 
 		{
 			re[a] = ed_mk2((float)(int16_t)(rawA[a] & 0xffffu), (float)(int16_t)(rawB[a] & 0xffffu));
 			im[a] = ed_mk2((float)(int16_t)(rawA[a] >> 16), (float)(int16_t)(rawB[a] >> 16));
+			if (WINDOW)
+			{
+				re[a] = re[a] * ed_splat(wv[a].x);
+				im[a] = im[a] * ed_splat(wv[a].y);
+			}
 		}
 		i_cur = i_next;
 		if (LIST) { g_cur = g_nxt; gi_cur = gi_nxt; }
@@ -539,6 +564,13 @@ __global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_kernel(ed_mfcc_args_t a
 	ed_mfcc2_body<ALIGNED, PLAIN, NLO, NHI, false>(args, tab, nullptr);
 }
 
+/* variant TF (windowed frames, mfcc_utils.py:201-253) on the same loop: the window multiplies the samples at the unpack, nothing else differs */
+template <bool ALIGNED, bool PLAIN, int NLO, int NHI>
+__global__ __launch_bounds__(64 * ED2_WPB) void ed_mfcc2_window_kernel(ed_mfcc_args_t args, const ed_mfcc_tables_t *__restrict__ tab)
+{
+	ed_mfcc2_body<ALIGNED, PLAIN, NLO, NHI, false, true>(args, tab, nullptr);
+}
+
 /* the same loop over a LIST of independent batches (edison_mfcc_batches_dev): one launch keeps the chip busy across them (what the
  * launch interface cannot do for separate launches: profiles/r05_mfcc_two_queues_notes.txt) */
 template <bool ALIGNED, int NLO, int NHI>
@@ -554,7 +586,7 @@ extern "C" void ed_lab_set_launch_flags(int f) { g_ed_lab_launch_flags = f; }
 /* occupancy-derived grid sizes and "dynamic-LDS limit raised" flags, per DEVICE (0 = not asked yet; the attribute belongs to
  * the function on the current device, so two contexts on different GPUs of one process must each set it) */
 static int g_mfcc_blocks_per_cu[16][2];
-static int g_mfcc2_blocks_per_cu[16][8];
+static int g_mfcc2_blocks_per_cu[16][16];
 
 template <int NLO, int NHI>
 static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables_t *dev_tab, int stages, int n_cu,
@@ -578,9 +610,9 @@ static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables
 	const bool aligned = ((reinterpret_cast<uintptr_t>(args->audio) & 3) == 0) && (args->frame_step % 2 == 0) &&
 	                     (args->group_stride % 2 == 0);
 	static const int one_frame = getenv("ED_MFCC_ONE_FRAME") ? atoi(getenv("ED_MFCC_ONE_FRAME")) : 0; /* A/B knob */
-	if (args->window)
+	if (args->window && (stages || one_frame))
 	{
-		/* variant TF (windowed frames): the one-frame kernel's WINDOW instances; the two-frame kernel has none */
+		/* variant TF (windowed frames) with stage dumps: the one-frame kernel's WINDOW instances */
 		dim3 grid((unsigned)blocks), block(64 * ED_WPB);
 		if (stages)
 		{
@@ -601,9 +633,12 @@ static int ed_launch_mfcc_shape(const ed_mfcc_args_t *args, const ed_mfcc_tables
 		const bool plain = args->frames_per_group >= args->n_frames;
 		const void *fn = aligned ? (plain ? (const void *)ed_mfcc2_kernel<true, true, NLO, NHI> : (const void *)ed_mfcc2_kernel<true, false, NLO, NHI>)
 		                         : (plain ? (const void *)ed_mfcc2_kernel<false, true, NLO, NHI> : (const void *)ed_mfcc2_kernel<false, false, NLO, NHI>);
+		if (args->window)
+			fn = aligned ? (plain ? (const void *)ed_mfcc2_window_kernel<true, true, NLO, NHI> : (const void *)ed_mfcc2_window_kernel<true, false, NLO, NHI>)
+			             : (plain ? (const void *)ed_mfcc2_window_kernel<false, true, NLO, NHI> : (const void *)ed_mfcc2_window_kernel<false, false, NLO, NHI>);
 		int dev_ = 0;
 		(void)hipGetDevice(&dev_);
-		int *bpc2 = &g_mfcc2_blocks_per_cu[dev_ & 15][(NLO == 2 ? 0 : 4) + (aligned ? 2 : 0) + (plain ? 1 : 0)];
+		int *bpc2 = &g_mfcc2_blocks_per_cu[dev_ & 15][(args->window ? 8 : 0) + (NLO == 2 ? 0 : 4) + (aligned ? 2 : 0) + (plain ? 1 : 0)];
 		if (*bpc2 <= 0)
 		{
 			/* more than 64 KB of dynamic LDS has to be asked for, once per kernel instance */

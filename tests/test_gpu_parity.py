@@ -112,9 +112,14 @@ def test_mfcc_tf_variant_against_the_float64_restatement(ctx, built_lib, oracle_
         # the window takes the leakage away, so quiet bands sit further below the strongest line than in variant A and carry
         # more of the float32 FFT's rounding floor (~1e-7 of that line) into their logarithm: 1.1e-4 measured on two_tone
         assert np.abs(st["log_mel_spectrogram"] - rst["log_mel_spectrogram"]).max() <= 5e-4
-        # the batch entry points take the same kernel: bit-identical to the stage dump, any n_coef, any hop / alignment
-        assert np.array_equal(ctx.mfcc(x, variant=_lib.MFCC_TF, n_coef=32), full["mfcc"])
-        assert np.array_equal(ctx.mfcc(x, variant=_lib.MFCC_TF, n_coef=13), full["mfcc"][:, :13])
+        # the batch entry points run the two-frame kernel's WINDOW instances (round 5; the stage dump is the one-frame kernel's): the same
+        # operations in the same order per frame, but the compiler pairs multiplies and additions into fused operations differently in the two
+        # texts, and behind a window the quiet bands' logarithms carry the float32 transform's rounding floor (above): the two kernels are held to
+        # each other, and the batch to the oracle, with variant A's bar (1.3e-4 between the kernels measured on two_tone, 8e-6 on speech)
+        b32 = ctx.mfcc(x, variant=_lib.MFCC_TF, n_coef=32)
+        _close(b32[ok], full["mfcc"][ok], "A")
+        _close(b32[ok], ref, "A")
+        assert np.array_equal(ctx.mfcc(x, variant=_lib.MFCC_TF, n_coef=13), b32[:, :13])
     x = mfcc_golden["in_noise"]
     _close(ctx.mfcc(x, frame_step=333, variant=_lib.MFCC_TF, n_coef=32), oracle_mod.mfcc(x, oracle_mod.VARIANT_TF, frame_step=333), "A")
     _close(ctx.mfcc(x[1:], variant=_lib.MFCC_TF, n_coef=32), oracle_mod.mfcc(x[1:], oracle_mod.VARIANT_TF), "A")

@@ -604,7 +604,7 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     from concurrent.futures import ThreadPoolExecutor
     from edison_amd import build as B
     want = {  # file -> (substring of the mangled kernel name, maximum VGPRs for the occupancy the launch code assumes)
-        "mfcc_kernels.hip": [("ed_mfcc2_kernel", 168), ("ed_mfcc2_list_kernel", 168)],   # 12 waves per CU; the list kernel (round 5) likewise
+        "mfcc_kernels.hip": [("ed_mfcc2_kernel", 168), ("ed_mfcc2_list_kernel", 168), ("ed_mfcc2_window_kernel", 168)],   # 12 waves per CU; the list kernel and variant TF's instances (round 5) likewise
         "mfcc_q15_kernels.hip": ("ed_mfcc_q15_kernelILb0E", 128),  # 16 waves per CU; the stage-dump instances (ILb1E) are diagnostics
         "cnn_mfma_kernels.hip": ("ed_cnn_mfma_kernel", 256),   # 8 waves per CU (LDS-bound)
         # both instances of the general network kernel, 12 waves per CU: round 4 found 33 spilled registers in its input / output stages,
