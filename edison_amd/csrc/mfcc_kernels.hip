@@ -63,7 +63,9 @@ __global__ ED_MFCC_BOUNDS void ed_mfcc_kernel(ed_mfcc_args_t args, const ed_mfcc
  * twiddles, the real-FFT split, the mel and DCT dot products) then costs one instruction for both frames; only the
  * data movement that works on 32-bit registers (int16 -> fp32, DPP / permlane exchanges, ds_bpermute, sqrt, log) is
  * issued once per frame. Same algorithm, same operation order per frame as ed_mfcc_kernel above, which stays as the
- * stage-dump kernel and as the checker of this one (tests compare the two paths bit for bit).
+ * stage-dump kernel (the two agree to the last places -- the compiler fuses multiply-adds differently in the two texts --
+ * and are held to the oracle with the same bars; the two-frame instances among themselves are bit-identical:
+ * plain / grouped / list, aligned or not, one queue or two).
  * LDS per wave: 526 transpose slots of 16 B (re A, re B, im A, im B: register pairs stay pairs), the two spectra interleaved as float2[516]
  * behind them (aliased like above), the DCT inputs of both frames.
  */
