@@ -146,13 +146,18 @@ def timed_region(step_fn, steps, warmup, world, settle_ms=0.0, settle_chunk=256,
     for i in range(warmup):
         step_fn(i)
     join()
+    e0 = e1 = None
+    if cuda:
+        # the two events exist BEFORE the clock starts: torch creates a HIP event at its first record, and the first such creation after a pause of the
+        # process (the blocking calibration, a sleep, the start of the process) costs 25-65 us -- harness time that a 20-step region of 45 us steps
+        # would carry as 3-6 % (tools/lab/region_overhead.py, profiles/r05_timed_region_overhead.txt); recorded once here, re-recorded in the region
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
     sync()
     if world > 1:
         dist.barrier()
     sync()
-    e0 = e1 = None
-    if cuda:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     if cuda:
         e0.record()
@@ -734,8 +739,16 @@ def main():
         except Exception as e:  # noqa: BLE001 -- a calibration that cannot run costs the second queue, not the line
             calibration = dict(pair=None, error=repr(e))
         torch.cuda.synchronize()
-    n_queues = 2 if ((args.queues == 2 and "error" not in (calibration or {})) or (args.queues == 0 and calibration["pair"] is not None)) else 1
-    head_step, head_kw = (q_step, dict(fork=ctx.queues_fork, join=ctx.queues_join)) if n_queues == 2 else (mfcc_step, {})
+    # a pair was kept (or --queues 2 insists): the two-queue step exists on this rank
+    pair_kept = (args.queues == 2 and "error" not in (calibration or {})) or (args.queues == 0 and calibration["pair"] is not None)
+    # ... and it pays only over a region long enough: forking the two queues from the stream and joining them back costs ~25-30 us of cross-queue
+    # signalling per timed region, the queues gain 1-2 us per step -- K = 10: -4.8 %, 20: -0.4 %, 40: +1.3 %, 80 and more: +2 ... +4 % against the
+    # serial sequence, wall clock, interleaved (tools/lab/k_sweep.py, profiles/r05_two_queues_region_length.txt). The headline uses the two queues
+    # from K = 40 on (--queues 2: always); below that it is the serial step, and `two_queues_same_wk` beside it says what two queues would have read.
+    MIN_STEPS_TWO_QUEUES = 40
+    n_queues = 2 if pair_kept and (args.queues == 2 or args.steps >= MIN_STEPS_TWO_QUEUES) else 1
+    q_kw = dict(fork=ctx.queues_fork, join=ctx.queues_join)
+    head_step, head_kw = (q_step, q_kw) if n_queues == 2 else (mfcc_step, {})
     # N > 1: every rank calibrates its own streams, so `config.queues` is rank 0's finding; how many ranks run two queues rides beside it
     ranks_two_queues = None
     if world > 1:
@@ -769,19 +782,33 @@ def main():
         sw_ms, sev1_ms = timed_region(mfcc_step, args.steps, args.warmup, world, 0.0)
         serial = dict(value=round(world * nf / (sw_ms * 1e-3), 1), unit="frames/s", ms_per_step=round(sw_ms, 4), kernel_ms=round(sev1_ms, 4),
                       roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (sev1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                      what="the same W + K steps as one call per batch on ONE queue (edison_mfcc_batch_dev), measured right after the headline (same board state)")
+                      what="the same W + K steps as one call per batch on ONE queue (edison_mfcc_batch_dev), measured right after the headline (same board state)"
+                           + ("" if n_queues == 2 else "; the headline was this same serial step: the two differ by what a W + K burst scatters from run to run"))
+    # K too small for the queues to pay although a pair was kept: the same W + K on the two queues, right after `serial` -- what the headline would have read
+    # (N > 1: every rank runs this leg or none does -- timed_region holds barriers, and whether a pair was kept is each rank's own finding; a rank without
+    # a pair runs the queue calls on one stream, which is the serial sequence)
+    two_queues_same_wk = None
+    if (pair_kept and n_queues == 1) if world == 1 else (args.queues == 0 and args.steps < MIN_STEPS_TWO_QUEUES):
+        tw_ms, tev_ms = timed_region(q_step, args.steps, args.warmup, world, 0.0, **q_kw)
+        two_queues_same_wk = dict(value=round(world * nf / (tw_ms * 1e-3), 1), unit="frames/s", ms_per_step=round(tw_ms, 4), kernel_ms=round(tev_ms, 4),
+                                  roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (tev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  what="the same W + K steps over the context's two queues (fork ... join inside the timed region): not the headline because K < %d -- "
+                                       "a fork / join pair costs ~25-30 us per region, the queues gain 1-2 us per step (profiles/r05_two_queues_region_length.txt)" % MIN_STEPS_TWO_QUEUES)
     settled = None
     if args.settle_ms > 0:
         # at least 400 timed steps here whatever K is: a 20-step block of this 45 us step scatters by +-3 % from block to block (profiles/r03_bench_repeatability.txt),
-        # and `settled` is the figure meant to be compared from run to run
+        # and `settled` is the figure meant to be compared from run to run. Over 400 steps the two queues pay whenever a pair was kept: `settled` uses them then,
+        # whatever the headline's K made it use.
         n_settled = max(args.steps, 400)
-        s_ms, sev_ms = timed_region(head_step, n_settled, args.warmup, world, args.settle_ms, **head_kw)
+        set_step, set_kw = (q_step, q_kw) if pair_kept else (mfcc_step, {})
+        s_ms, sev_ms = timed_region(set_step, n_settled, args.warmup, world, args.settle_ms, **set_kw)
         settled = dict(value=round(world * nf / (s_ms * 1e-3), 1), unit="frames/s", ms_per_step=round(s_ms, 4), kernel_ms=round(sev_ms, 4), steps=n_settled,
                        roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (sev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), settle_ms=args.settle_ms,
+                       queues=2 if pair_kept else 1,
                        what="the same workload after settle_ms of untimed repetition of the step in front of the W warm-up steps (clocks and "
-                            "power settled); a side figure, the headline is the W + K run above")
+                            "power settled), on two queues when the calibration kept a pair; a side figure, the headline is the W + K run above")
         # (N > 1: whether a pair was kept is each rank's own finding, and timed_region holds barriers -- every rank runs this leg or none does)
-        if (n_queues == 2) if world == 1 else (args.queues != 1):
+        if pair_kept if world == 1 else (args.queues != 1):
             s1_ms, s1ev_ms = timed_region(mfcc_step, n_settled, args.warmup, world, args.settle_ms)
             settled["serial"] = dict(value=round(world * nf / (s1_ms * 1e-3), 1), ms_per_step=round(s1_ms, 4), kernel_ms=round(s1ev_ms, 4),
                                      roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (s1ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
@@ -1093,6 +1120,10 @@ def main():
                 exit_code = 5
         if serial is not None:
             line["serial"] = serial
+        if two_queues_same_wk is not None:
+            line["two_queues_same_wk"] = two_queues_same_wk
+            line["config"]["queues_why"] = ("a pair of queues was kept by the calibration, but K = %d < %d: the fork / join of a timed region costs more than the queues gain over so few "
+                                            "steps; `settled` (>= 400 steps) runs on the two queues" % (args.steps, MIN_STEPS_TWO_QUEUES))
         if serial_cold is not None:
             line["serial_cold"] = serial_cold
         if calibration is not None:

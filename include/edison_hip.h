@@ -243,7 +243,9 @@ int edison_mfcc_batches_dev(edison_ctx *ctx, int n_batches, const int16_t *const
  * are bit-identical to the plain calls. From a host that keeps both queues fed (a C host, ~5 us per call) a 65 536-frame batch
  * takes 45.7 us instead of 47.7 (+4.5 %; +1 ... +2.6 % on boards that sit at their power cap); a host that needs as long per call as the
  * GPU per batch gains nothing
- * (profiles/r05_mfcc_two_queues_notes.txt). The list call above is the faster way whenever the batches are known together.
+ * (profiles/r05_mfcc_two_queues_notes.txt). A fork / join pair itself costs ~25-30 us of cross-queue signalling: keep MANY batches between
+ * them -- at 65 536 frames per batch the two queues break even near 25 batches per fork (profiles/r05_two_queues_region_length.txt).
+ * The list call above is the faster way whenever the batches are known together.
  * Which two streams: whether the next launch really backfills the CUs this one leaves depends on where runtime and driver put the two
  * streams' hardware queues, which HIP does not let a program choose -- of all pairs of nine streams in one process a third gained, a
  * third changed nothing, a third LOST 8-10 %. edison_queues_calibrate measures it: every pair of the context's five candidate streams

@@ -235,7 +235,7 @@ def test_bench_collectives_do_not_sit_under_rank_local_conditions():
     import ast
     tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
     main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
-    rank_local = {"n_queues", "calibration", "sample", "rank", "same", "same_l", "parity", "local_rank"}
+    rank_local = {"n_queues", "pair_kept", "calibration", "sample", "rank", "same", "same_l", "parity", "local_rank"}
     found = []
 
     def names(node):
