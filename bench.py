@@ -158,9 +158,9 @@ def timed_region(step_fn, steps, warmup, world, settle_ms=0.0, settle_chunk=256,
     if world > 1:
         dist.barrier()
     sync()
-    t0 = time.perf_counter()
     if cuda:
-        e0.record()
+        e0.record()        # (a host call of ~5 us on an idle GPU: recorded before the clock starts, so the event interval opens at most that much earlier than the wall interval)
+    t0 = time.perf_counter()
     fork()
     for i in range(steps):
         step_fn(warmup + i)
