@@ -924,6 +924,16 @@ def main():
                      value=round(world * nf / (a_ms * 1e-3), 1), ms_per_step=round(a_ms, 4), kernel_ms=round(aev_ms, 4),
                      roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (aev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
 
+    # ------------------------------------------------------------------ variant TF (windowed frames: the TensorFlow curve of `main.py mfcc host`), same batch
+    def mfcc_tf_step(i):
+        ctx.mfcc_t(bufs[i % len(bufs)], nf, 1024, _lib.MFCC_TF, 13, out=out)
+    t_ms, tev_ms = timed_region(mfcc_tf_step, args.steps, args.warmup, world, args.settle_ms)
+    variant_tf = dict(metric="MFCC frames/sec, variant TF (Hann window + ln + DCT, mfcc_utils.mfcc_tf)", unit="frames/s",
+                      value=round(world * nf / (t_ms * 1e-3), 1), ms_per_step=round(t_ms, 4), kernel_ms=round(tev_ms, 4),
+                      roofline_frac=round(MFCC_BYTES_PER_FRAME * nf / (tev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      parity="UNPINNED: TensorFlow is not in this image and the reference holds no output of it; checked against a float64 restatement of tf.signal's definitions only",
+                      what="the two-frame loop with the window multiplied in at the unpack (ed_mfcc2_window_kernel; round 5)")
+
     # ------------------------------------------------------------------ variant C: the firmware's Q15 MFCC, same batch
     q15 = None
     if not args.skip_q15:
@@ -1137,6 +1147,7 @@ def main():
         if two_queues is not None:
             line["two_queues"] = two_queues
         line["mfcc_variant_a"] = variant_a
+        line["mfcc_variant_tf"] = variant_tf
         if variant_d is not None:
             line["mfcc_variant_d"] = variant_d
         if q15 is not None:

@@ -45,7 +45,7 @@ def test_bench_line_is_whole_and_its_parity_object_green(built_lib, steps):
     else:
         assert (d["config"]["queues"] == 2) == (d["queue_calibration"].get("pair") is not None)
     # every side leg ran (an error object is what a failed leg leaves)
-    for k in ("serial_cold", "serial", "settled", "rows_launch", "batch_list", "two_queues", "mfcc_variant_a", "mfcc_variant_d", "mfcc_q15", "kws", "streaming"):
+    for k in ("serial_cold", "serial", "settled", "rows_launch", "batch_list", "two_queues", "mfcc_variant_a", "mfcc_variant_tf", "mfcc_variant_d", "mfcc_q15", "kws", "streaming"):
         assert k in d and "error" not in d[k], (k, d.get(k))
     assert d["batch_list"]["outputs_bit_identical_to_one_call_per_batch"] and d["two_queues"]["outputs_bit_identical_to_serial"]
     assert d["kws"]["collective_path"].startswith("none")
