@@ -1,5 +1,5 @@
 /*
- * edison_generic.hip -- entry points of the generality path: MFCC variants A / B for any geometry the reference's Python functions
+ * edison_generic.hip -- entry points of the generality path: MFCC variants A / B / TF for any geometry the reference's Python functions
  * accept (mfcc_utils.py:134-199, 255-323), kernel in mfcc_generic_kernels.hip. Tables (cos / sin of the frame length, the mel
  * matrix, the DCT matrix) are built per call on the host in float64 -- this is not a throughput path.
  */
@@ -15,9 +15,9 @@ extern "C" int ed_launch_mfcc_generic(const ed_mfcc_gen_args_t *a, int n_cu, hip
 
 struct gen_tables
 {
-	double *d;  /* one device block: tw | W | dct */
-	size_t tw_off, w_off, dct_off;
-	gen_tables() : d(NULL), tw_off(0), w_off(0), dct_off(0) {}
+	double *d;  /* one device block: tw | W | dct | window (float32, variant TF) */
+	size_t tw_off, w_off, dct_off, win_off;
+	gen_tables() : d(NULL), tw_off(0), w_off(0), dct_off(0), win_off(0) {}
 	~gen_tables() { if (d) (void)hipFree(d); }
 };
 
@@ -27,7 +27,8 @@ static int build_tables(edison_ctx *ctx, int variant, int N, int nmel, double fs
 	const int nb = v == EDISON_MFCC_A ? N / 2 : N / 2 + 1;
 	*n_bins = nb;
 	const size_t n_tw = 2 * (size_t)N, n_w = (size_t)nb * nmel, n_d = (size_t)nmel * nmel;
-	double *h = (double *)malloc(sizeof(double) * (n_tw + n_w + n_d));
+	const size_t n_win = v == EDISON_MFCC_TF ? ((size_t)N + 1) / 2 : 0; /* N floats in doubles' worth of space */
+	double *h = (double *)malloc(sizeof(double) * (n_tw + n_w + n_d + n_win));
 	if (!h) return ed_set_err(ctx, EDISON_E_NO_MEMORY, "host allocation failed");
 	for (int j = 0; j < N; j++)
 	{
@@ -42,11 +43,17 @@ static int build_tables(edison_ctx *ctx, int variant, int N, int nmel, double fs
 	double *D = W + n_w;
 	for (int c = 0; c < nmel; c++)
 		for (int n = 0; n < nmel; n++) D[(size_t)c * nmel + n] = 2.0 * cos(M_PI * (double)c * (double)(2 * n + 1) / (double)(2 * nmel));
-	hipError_t e = hipMalloc((void **)&t->d, sizeof(double) * (n_tw + n_w + n_d));
-	if (e == hipSuccess) e = hipMemcpy(t->d, h, sizeof(double) * (n_tw + n_w + n_d), hipMemcpyHostToDevice);
+	if (n_win)
+	{
+		/* tf.signal.hann_window(frame_length, periodic=True), float32: 0.5 - 0.5 cos(2 pi n / N) rounded once from float64 (as tables.c does for the fast path) */
+		float *wf = (float *)(D + n_d);
+		for (int n = 0; n < N; n++) wf[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)N));
+	}
+	hipError_t e = hipMalloc((void **)&t->d, sizeof(double) * (n_tw + n_w + n_d + n_win));
+	if (e == hipSuccess) e = hipMemcpy(t->d, h, sizeof(double) * (n_tw + n_w + n_d + n_win), hipMemcpyHostToDevice);
 	free(h);
 	ED_HIP(ctx, e);
-	t->tw_off = 0; t->w_off = n_tw; t->dct_off = n_tw + n_w;
+	t->tw_off = 0; t->w_off = n_tw; t->dct_off = n_tw + n_w; t->win_off = n_win ? n_tw + n_w + n_d : 0;
 	return EDISON_OK;
 }
 
@@ -54,8 +61,8 @@ static int check_geometry(edison_ctx *ctx, int64_t n_frames, int frame_len, int6
                           double scale, int n_coef)
 {
 	const int v = variant & 0xff;
-	if (v != EDISON_MFCC_A && v != EDISON_MFCC_B) return ed_set_err(ctx, EDISON_E_NO_IMPL, "edison_mfcc_generic: variants A and B");
-	if (v == EDISON_MFCC_A && (variant & EDISON_MFCC_USE_LOG)) return ed_set_err(ctx, EDISON_E_ARGUMENT, "variant A always takes the logarithm");
+	if (v != EDISON_MFCC_A && v != EDISON_MFCC_B && v != EDISON_MFCC_TF) return ed_set_err(ctx, EDISON_E_NO_IMPL, "edison_mfcc_generic: variants A, B and TF");
+	if (v != EDISON_MFCC_B && (variant & EDISON_MFCC_USE_LOG)) return ed_set_err(ctx, EDISON_E_ARGUMENT, "variants A and TF always take the logarithm");
 	if (n_frames < 0 || frame_step < 0) return EDISON_E_ARGUMENT;
 	if (n_frames > INT32_MAX) return ed_set_err(ctx, EDISON_E_SIZE, "edison_mfcc_generic: more than 2^31 frames in one call");
 	if (frame_len < 4 || frame_len > ED_GEN_MAX_FRAME) return ed_set_err(ctx, EDISON_E_NO_IMPL, "edison_mfcc_generic: frame_len 4 .. 4096");
@@ -69,13 +76,15 @@ static void fill_args(ed_mfcc_gen_args_t *a, const gen_tables &t, int variant, i
 {
 	const int v = variant & 0xff;
 	a->frame_len = N; a->n_bins = nb; a->n_mel = nmel;
-	a->fft_out = v == EDISON_MFCC_A ? N / 2 : N;
-	a->take_log = v == EDISON_MFCC_A || (variant & EDISON_MFCC_USE_LOG);
-	a->fft_scale = v == EDISON_MFCC_A ? 1.0 : 1.0 / 1024.0;          /* mfcc_utils.py:297: the constant 1024, whatever the frame length */
-	a->spec_scale = v == EDISON_MFCC_A ? 1.0 : 1.0 / sqrt(2.0);        /* :300 */
-	a->mel_div = v == EDISON_MFCC_A ? 1.0 : scale;                     /* :309 */
-	a->dct_div = v == EDISON_MFCC_A ? sqrt(2.0 * (double)nmel) : 64.0; /* :193, :318 */
+	const bool b = v == EDISON_MFCC_B; /* A and TF share the constants: no scales, ln, dct2 / sqrt(2 nmel) (mfcc_utils.py:193; tf.signal.mfccs_from_log_mel_spectrograms) */
+	a->fft_out = v == EDISON_MFCC_A ? N / 2 : (b ? N : N / 2 + 1);
+	a->take_log = !b || (variant & EDISON_MFCC_USE_LOG);
+	a->fft_scale = b ? 1.0 / 1024.0 : 1.0;          /* mfcc_utils.py:297: the constant 1024, whatever the frame length */
+	a->spec_scale = b ? 1.0 / sqrt(2.0) : 1.0;        /* :300 */
+	a->mel_div = b ? scale : 1.0;                     /* :309 */
+	a->dct_div = b ? 64.0 : sqrt(2.0 * (double)nmel); /* :318, :193 */
 	a->tw = t.d + t.tw_off; a->W = t.d + t.w_off; a->dct = t.d + t.dct_off;
+	a->window = t.win_off ? (const float *)(t.d + t.win_off) : NULL;
 }
 
 extern "C" int edison_mfcc_generic_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int frame_len, int64_t frame_step, int variant, int mel_nbins,
@@ -124,7 +133,7 @@ extern "C" int edison_mfcc_generic(edison_ctx *ctx, const int16_t *audio, int64_
 	if (n_frames == 0) return EDISON_OK;
 	ED_HIP(ctx, hipSetDevice(ctx->device));
 	const size_t n = (size_t)n_frames, na = ((size_t)(n_frames - 1) * (size_t)frame_step + (size_t)frame_len) * sizeof(int16_t);
-	const size_t fo = (size_t)((variant & 0xff) == EDISON_MFCC_A ? frame_len / 2 : frame_len);
+	const size_t fo = (size_t)((variant & 0xff) == EDISON_MFCC_A ? frame_len / 2 : ((variant & 0xff) == EDISON_MFCC_B ? frame_len : frame_len / 2 + 1));
 	gbuf a, f, s, m, l, c, q;
 	ED_HIP(ctx, a.alloc(na));
 	if (fft) ED_HIP(ctx, f.alloc(n * fo * 2 * sizeof(double)));

@@ -414,13 +414,13 @@ typedef struct {
 	int8_t *feat[ED_MFCC_LIST_MAX];
 } ed_mfcc_list_t;
 
-/* the generality path (mfcc_generic_kernels.hip): variants A / B for any frame length / number of mel bins, float64 */
+/* the generality path (mfcc_generic_kernels.hip): variants A / B / TF for any frame length / number of mel bins, float64 */
 #define ED_GEN_MAX_FRAME 4096
 #define ED_GEN_MAX_MEL 256
 typedef struct {
 	const int16_t *audio;
 	int64_t n_frames, frame_step;
-	int frame_len, n_bins, fft_out, n_mel; /* n_bins: spectrum bins under the mel matrix (A: N/2, B: N/2+1); fft_out: entries of the fft / spectrogram dumps (A: N/2, B: N) */
+	int frame_len, n_bins, fft_out, n_mel; /* n_bins: spectrum bins under the mel matrix (A: N/2, B and TF: N/2+1); fft_out: entries of the fft / spectrogram dumps (A: N/2, B: N, TF: N/2+1) */
 	int take_log, n_coef;
 	double fft_scale, spec_scale, mel_div, dct_div;
 	const double *tw;  /* [N][2]  cos, sin of 2 pi j / N (device) */
@@ -429,6 +429,7 @@ typedef struct {
 	double *fft, *spec, *mel, *logmel, *mfcc; /* device, each may be NULL */
 	int8_t *feat;      /* [n_frames][n_coef] int8 net input, or NULL */
 	float feat_scale;
+	const float *window; /* variant TF: [N] periodic Hann window in float32 (tf.signal.hann_window), multiplied into the float32 samples; NULL: none */
 } ed_mfcc_gen_args_t;
 
 

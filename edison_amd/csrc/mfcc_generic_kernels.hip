@@ -1,5 +1,5 @@
 /*
- * mfcc_generic_kernels.hip -- MFCC variants A and B for ANY geometry the reference's Python functions accept: frame_len (any length,
+ * mfcc_generic_kernels.hip -- MFCC variants A, B and TF for ANY geometry the reference's Python functions accept: frame_len (any length,
  * also no power of two: the reference calls numpy.fft.fft), mel_nbins, filterbank edges, sample rate
  * (audio/edison/mfcc/mfcc_utils.py:134-199 `mfcc`, :255-323 `mfcc_mcu`, :75-131 `batch_mfcc`).
  *
@@ -12,7 +12,9 @@
  *   A (:170-196)  X = fft(x)[:N/2]; s = |X|; e = s . W(N/2 bins); l = ln(e + 1e-6); mfcc = dct2(l) / sqrt(2 * mel_nbins)
  *   B (:296-319)  X = fft(x) / 1024 (the constant, whatever N is); s = |X| / sqrt(2); e = (s[:N/2+1] . (scale * W(N/2+1 bins))) / scale;
  *                 l = use_log ? ln(e + 1e-6) : e; mfcc = dct2(l) / 64 (the constant)
- * Outputs are float64 like the reference's dict entries: fft [n][N/2 (A) | N (B)][2], spectrogram [n][N/2 | N], mel / logmel / mfcc [n][mel_nbins].
+ *   TF (:201-253) x = float32(x) * hann_periodic_float32; X = rfft(x) (N/2+1 bins); s = |X|; e = s . W(N/2+1 bins); l = ln(e + 1e-6);
+ *                 mfcc = dct2(l) / sqrt(2 * mel_nbins) (tf.signal.mfccs_from_log_mel_spectrograms). fft_len == frame_len. PARITY UNPINNED (no TensorFlow here).
+ * Outputs are float64 like the reference's dict entries: fft [n][N/2 (A) | N (B) | N/2+1 (TF)][2], spectrogram likewise, mel / logmel / mfcc [n][mel_nbins].
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,7 +36,11 @@ __global__ __launch_bounds__(256) void ed_mfcc_generic_kernel(ed_mfcc_gen_args_t
 	{
 		const int16_t *fp = a.audio + f * a.frame_step;
 		__syncthreads();
-		for (int n = t; n < N; n += 256) x[n] = (double)fp[n];
+		/* variant TF: the samples become float32, the window multiplies them in float32 (tf.signal.stft on a float32 tensor), the rest is float64 */
+		if (a.window)
+			for (int n = t; n < N; n += 256) x[n] = (double)__fmul_rn((float)fp[n], a.window[n]);
+		else
+			for (int n = t; n < N; n += 256) x[n] = (double)fp[n];
 		__syncthreads();
 		/* direct DFT of the real frame, bins 0 .. N/2: X[k] = sum_n x[n] (cos(2 pi k n / N) - i sin(2 pi k n / N)); the table index
 		 * k n mod N is kept by addition */

@@ -20,7 +20,7 @@ The fast GPU kernels are specialised for the reference's shipped geometry: 1024-
 (audio/config.py:15,19) -- what every caller in the reference passes; their arrays are float32 promoted to float64 (the
 reference computes in float64; DESIGN.md has the measured tolerance). Any OTHER geometry the reference's functions accept
 (frame_len 4 .. 4096, power of two or not; mel_nbins 1 .. 256) goes through the generality kernel (`edison_mfcc_generic`:
-float64 on the GPU, one workgroup per frame, the reference's values to ~1e-12; round 5). Outside those limits:
+float64 on the GPU, one workgroup per frame, the reference's values to ~1e-12; round 5; mfcc_tf too, with fft_len == frame_len). Outside those limits:
 NotImplementedError, never another path.
 """
 import ctypes
@@ -94,7 +94,7 @@ def _generic(ctx, data, frame_count, frame_len, frame_step, variant, mel_nbins, 
     n = int(frame_count)
     if n > 0 and (n - 1) * frame_step + frame_len > x.shape[0]:
         raise ValueError("data too short for %d frames of %d samples" % (n, frame_len))
-    fo = frame_len // 2 if variant == _lib.MFCC_A else frame_len
+    fo = frame_len // 2 if variant == _lib.MFCC_A else (frame_len if variant == _lib.MFCC_B else frame_len // 2 + 1)
     fft = np.zeros((max(n, 0), fo, 2), np.float64) if stages else None
     spec = np.zeros((max(n, 0), fo), np.float64) if stages else None
     mel = np.zeros((max(n, 0), mel_nbins), np.float64) if stages else None
@@ -225,12 +225,13 @@ def mfcc_tf(data, fs, nSamples, frame_len, frame_step, frame_count, fft_len, mel
     reference does (:245-249); float32 arithmetic like TensorFlow's. Parity unpinned (see the module docstring)."""
     if fft_len != frame_len:
         raise NotImplementedError("the MI355X path implements fft_len == frame_len (audio/config.py:15-16)")
-    if not _is_fast_geometry(frame_len, mel_nbins):
-        raise NotImplementedError("variant TF (a comparison curve, mfcc.py:189 its only caller) is built for the reference configuration "
-                                  "frame_len=1024, mel_nbins=32 only; got frame_len=%r mel_nbins=%r" % (frame_len, mel_nbins))
     ctx = _prepare(fs, frame_len, mel_nbins, mel_lower_hz, mel_upper_hz)
     frame_count = _frame_count(frame_count, nSamples, frame_len, frame_step)
-    st = ctx.mfcc_stages(_as_int16(data), n_frames=frame_count, frame_step=frame_step, variant=_lib.MFCC_TF)
+    if _is_fast_geometry(frame_len, mel_nbins):
+        st = ctx.mfcc_stages(_as_int16(data), n_frames=frame_count, frame_step=frame_step, variant=_lib.MFCC_TF)
+    else:   # any other geometry: the generality kernel (float32 window product, then float64)
+        st = _generic(ctx, data, frame_count, frame_len, frame_step, _lib.MFCC_TF, mel_nbins, fs, mel_lower_hz, mel_upper_hz)
+        st = {k: (v.astype(np.float32) if k != 'fft' else v) for k, v in st.items()}   # TensorFlow's tensors are float32
     W = gen_mel_weight_matrix(num_mel_bins=mel_nbins, num_spectrogram_bins=fft_len // 2 + 1, sample_rate=fs,
                               lower_edge_hertz=mel_lower_hz, upper_edge_hertz=mel_upper_hz)
     output = []

@@ -274,7 +274,7 @@ int edison_mfcc_stages_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_fram
                            int variant, float *fft, float *spec, float *mel, float *logmel, float *mfcc32);
 
 /*
- * The generality path: variants A and B for ANY geometry the reference's Python functions accept -- frame_len (4 .. 4096, also no power
+ * The generality path: variants A, B and TF for ANY geometry the reference's Python functions accept -- frame_len (4 .. 4096, also no power
  * of two: the reference calls numpy.fft.fft), mel_nbins (1 .. 256), sample rate, filterbank edges, mel_mtx_scale (mfcc_utils.py:134-199,
  * 255-323; every caller in the reference passes audio/config.py's 1024 / 32, which the entry points above serve). Float64 on the GPU
  * (direct DFT against a host-built table, dense mel product, ln, DCT-II with the variant's constants -- for B the literal 1/1024 and
@@ -282,6 +282,9 @@ int edison_mfcc_stages_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_fram
  * throughput path. Outputs, float64, each may be NULL: fft [n][F][2] (re, im), spec [n][F] with F = frame_len/2 (A) or frame_len (B) as
  * in the reference's per-frame dict; mel, logmel, mfcc [n][mel_nbins]; feat [n][n_coef] int8 = the net-input rounding of the first
  * n_coef coefficients (kws_nnom.py:359-361). EDISON_E_NO_IMPL outside the limits above or for other variants.
+ * Variant TF (mfcc_utils.py:201-253 with fft_len == frame_len): the samples as float32 times tf.signal's periodic Hann window in float32,
+ * then float64 -- rfft, |.|, the (frame_len/2+1)-bin mel matrix, ln(x + 1e-6), DCT-II / sqrt(2 mel_nbins); F = frame_len/2 + 1 (the caller cuts the
+ * DC bin as the reference does); mel_mtx_scale is ignored. PARITY UNPINNED like the fast path's variant TF: no TensorFlow in this image.
  */
 int edison_mfcc_generic_dev(edison_ctx *ctx, const int16_t *audio, int64_t n_frames, int frame_len, int64_t frame_step, int variant, int mel_nbins,
                             double sample_rate, double lower_edge_hertz, double upper_edge_hertz, double mel_mtx_scale, double *fft, double *spec,

@@ -386,7 +386,7 @@ def mfcc(x, variant, n_frames=None, frame_len=FRAME_LEN, frame_step=FRAME_LEN, u
 
 def mfcc_numpy(x, variant, frame_len, frame_step, n_frames=None, num_mel_bins=NUM_MEL, sample_rate=FS, lower_edge_hertz=MEL_LO,
                upper_edge_hertz=MEL_HI, mel_mtx_scale=MEL_SCALE, use_log=False):
-    """Variants A / B for ANY frame length (numpy's FFT, like the reference: mfcc_utils.py:160-197, 287-322) -- the checker of the
+    """Variants A / B (and TF: unpinned) for ANY frame length (numpy's FFT, like the reference: mfcc_utils.py:160-197, 287-322) -- the checker of the
     generality kernel where the C restatement's radix-2 FFT does not go (lengths that are no power of two). Pinned on the reference's own
     outputs for six geometries (tests/golden/mfcc_geom_golden.npz, tests/test_oracle.py). The mel matrix is the C restatement's
     (oracle_mel_weight_matrix, itself pinned on the reference's gen_mel_weight_matrix)."""
@@ -395,11 +395,19 @@ def mfcc_numpy(x, variant, frame_len, frame_step, n_frames=None, num_mel_bins=NU
     if n_frames is None:
         n_frames = 1 + (x.shape[0] - N) // frame_step
     nb = N // 2 if variant == VARIANT_A else N // 2 + 1
+    if variant == VARIANT_TF:
+        # mfcc_utils.py:201-253 (fft_len == frame_len): float32 samples times tf.signal.hann_window(N, periodic=True) in float32, rfft, |.|, the
+        # (N/2+1)-bin matrix, ln(x + 1e-6), mfccs_from_log_mel_spectrograms = DCT-II * rsqrt(2 num_mel_bins). PARITY UNPINNED (no TensorFlow here).
+        win = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(N) / N)).astype(np.float32)
     W = mel_weight_matrix(num_mel_bins, nb, sample_rate, lower_edge_hertz, upper_edge_hertz)
     k = np.arange(num_mel_bins)
     D = 2.0 * np.cos(np.pi * np.outer(k, 2 * np.arange(num_mel_bins) + 1) / (2.0 * num_mel_bins))   # scipy.fftpack.dct type 2, unnormalised
     out = np.zeros((max(n_frames, 0), num_mel_bins))
     for f in range(n_frames):
+        if variant == VARIANT_TF:
+            xw = (x[f * frame_step:f * frame_step + N].astype(np.float32) * win).astype(np.float64)
+            out[f] = D @ np.log(np.abs(np.fft.rfft(xw)) @ W + 1e-6) / np.sqrt(2.0 * num_mel_bins)
+            continue
         X = np.fft.fft(x[f * frame_step:f * frame_step + N].astype(np.float64))
         if variant == VARIANT_A:
             out[f] = D @ np.log(np.abs(X[:nb]) @ W + 1e-6) / np.sqrt(2.0 * num_mel_bins)

@@ -94,3 +94,48 @@ def test_generic_entry_point_limits_and_net_input(ctx, geom):
     assert L.edison_mfcc_generic(ctx._h, y.ctypes.data, 10, 1024, 1024, _lib.MFCC_B, 32, 16000.0, 80.0, 7600.0, 128.0, None, None, None, None, m64.ctypes.data, 0, None, 1.0) == 0
     fast = ctx.mfcc(y, variant=_lib.MFCC_B, n_coef=32)
     assert np.all(np.abs(fast - m64) <= 1e-2 + 1e-5 * np.abs(m64))
+
+
+@pytest.mark.parametrize("idx", [0, 2, 5])
+def test_variant_tf_at_other_geometries(ctx, geom, oracle_mod, idx):
+    """mfcc_tf (mfcc_utils.py:201-253) for geometries other than 1024 / 32 through the generality kernel. PARITY UNPINNED -- TensorFlow is not in this
+    image and the reference holds no output of it --: held to the oracle's numpy restatement of tf.signal's definitions (float32 window product,
+    then float64), 1e-9 of the largest value like variants A / B above. At the reference geometry the generality kernel and the fast variant-TF
+    kernel (float32 throughout) are held to each other with variant A's bar."""
+    from edison_amd import _lib
+    from edison_amd.mfcc import mfcc_utils as mfu
+    N, step, nm, lo, hi, _ = geom["configs"][idx]
+    N, step, nm = int(N), int(step), int(nm)
+    fs = 16000
+    for sname in ("edison", "noise"):
+        x = geom["in_" + sname]
+        o = mfu.mfcc_tf(x, fs, len(x), N, step, 0, N, nm, lo, hi)
+        ref = oracle_mod.mfcc_numpy(x, oracle_mod.VARIANT_TF, N, step, num_mel_bins=nm, lower_edge_hertz=lo, upper_edge_hertz=hi)
+        assert len(o) == ref.shape[0] == 1 + (len(x) - N) // step
+        got = np.array([f["mfcc"] for f in o], np.float64)
+        tol = 2e-6 * max(1.0, float(np.abs(ref).max()))     # the mirror hands float32 arrays back, like TensorFlow's tensors
+        assert np.abs(got - ref).max() <= tol, (sname, float(np.abs(got - ref).max()), tol)
+        assert o[0]["fft"].shape == (N // 2,) and o[0]["spectrogram"].shape == (N // 2,) and o[0]["mel_weight_matrix"].shape == (N // 2, nm)
+        assert o[0]["mfcc"].shape == (nm,) and o[0]["mfcc"].dtype == np.float32
+        # the float64 arrays of the kernel itself, against the same restatement: 1e-9
+        st = mfu._generic(ctx, x, ref.shape[0], N, step, _lib.MFCC_TF, nm, fs, lo, hi)
+        _near(st["mfcc"], ref, "TF mfcc %d %s" % (idx, sname))
+        xw = (x[:N].astype(np.float32) * (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(N) / N)).astype(np.float32)).astype(np.float64)
+        _near(st["fft"][0], np.fft.rfft(xw), "TF fft")
+        _near(st["spectrogram"][0], np.abs(np.fft.rfft(xw)), "TF spectrogram")
+    with pytest.raises(NotImplementedError):
+        mfu.mfcc_tf(x, fs, len(x), N, step, 0, 2 * N, nm, lo, hi)     # fft_len != frame_len
+    with pytest.raises(_lib.EdisonError):
+        mfu._generic(ctx, x, 2, N, step, _lib.MFCC_TF, nm, fs, lo, hi, use_log=True)
+
+
+def test_variant_tf_generic_against_the_fast_kernel_at_the_reference_geometry(ctx, geom, oracle_mod):
+    from edison_amd import _lib
+    from edison_amd.mfcc import mfcc_utils as mfu
+    x = geom["in_noise"]
+    n = 1 + (len(x) - 1024) // 1024
+    g = mfu._generic(ctx, x, n, 1024, 1024, _lib.MFCC_TF, 32, 16000, 80.0, 7600.0)["mfcc"]
+    fast = ctx.mfcc(x, variant=_lib.MFCC_TF, n_coef=32)
+    ref = oracle_mod.mfcc(x, oracle_mod.VARIANT_TF)              # the C restatement (float64 window product)
+    assert np.abs(g - fast).max() <= 1e-3 + 1e-4 * np.abs(g).max()
+    assert np.abs(g - ref).max() <= 1e-3 + 1e-4 * np.abs(ref).max()

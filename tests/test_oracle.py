@@ -239,3 +239,15 @@ def test_numpy_restatement_for_other_geometries_equals_the_reference(oracle_mod)
                 got = oracle_mod.mfcc_numpy(x, variant, N, step, num_mel_bins=nm, lower_edge_hertz=lo, upper_edge_hertz=hi, mel_mtx_scale=scale, use_log=use_log)
                 ref = g[k + tag + "_mfcc"]
                 assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), (name, sname, tag)
+
+
+def test_mfcc_numpy_variant_tf_against_the_c_restatement(oracle_mod, mfcc_golden):
+    """The two restatements of variant TF (both unpinned: no TensorFlow here) agree at the reference geometry: oracle.mfcc_numpy (numpy's rfft, the
+    window product in float32 as tf.signal does it) and oracle/mfcc_ref.c (its own FFT, the window product in float64) -- to what one float32
+    rounding of the windowed samples moves a coefficient."""
+    for name in ("edison", "noise"):
+        x = mfcc_golden["in_" + name]
+        a = oracle_mod.mfcc_numpy(x, oracle_mod.VARIANT_TF, 1024, 1024)
+        b = oracle_mod.mfcc(x, oracle_mod.VARIANT_TF)
+        assert a.shape == b.shape
+        assert np.abs(a - b).max() <= 1e-4 + 1e-5 * np.abs(b).max(), (name, float(np.abs(a - b).max()))
