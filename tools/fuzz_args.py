@@ -31,14 +31,14 @@ def main():
             step, n = int(rng.integers(1, 2 * N + 1)), int(rng.integers(1, 12))
             fs = float(rng.choice([8000.0, 16000.0, 44100.0]))
             lo = float(rng.uniform(0.0, 0.1 * fs)); hi = float(rng.uniform(lo + 0.05 * fs, 0.5 * fs)); scale = float(rng.choice([1.0, 16.0, 128.0, 1000.0]))
-            variant = _lib.MFCC_A if rng.random() < 0.5 else _lib.MFCC_B
+            variant = [_lib.MFCC_A, _lib.MFCC_B, _lib.MFCC_TF][int(rng.integers(0, 3))]     # TF: unpinned, held to the same numpy restatement
             use_log = bool(variant == _lib.MFCC_B and rng.random() < 0.5)
             x = np.clip(rng.normal(0, 10.0 ** rng.uniform(0.5, 4.3), (n - 1) * step + N), -32768, 32767).astype(np.int16)
             got = np.zeros((n, nm))
             r_ = _lib.lib().edison_mfcc_generic(ctx._h, x.ctypes.data, n, N, step, variant | (_lib.MFCC_USE_LOG if use_log else 0), nm, fs, lo, hi, scale,
                                                 None, None, None, None, got.ctypes.data, 0, None, 1.0)
             assert r_ == 0, (kind, N, nm, r_)
-            ref = oracle.mfcc_numpy(x, oracle.VARIANT_A if variant == _lib.MFCC_A else oracle.VARIANT_B, N, step, n_frames=n, num_mel_bins=nm, sample_rate=fs,
+            ref = oracle.mfcc_numpy(x, {_lib.MFCC_A: oracle.VARIANT_A, _lib.MFCC_B: oracle.VARIANT_B, _lib.MFCC_TF: oracle.VARIANT_TF}[variant], N, step, n_frames=n, num_mel_bins=nm, sample_rate=fs,
                                     lower_edge_hertz=lo, upper_edge_hertz=hi, mel_mtx_scale=scale, use_log=use_log)   # pinned on the reference's outputs: tests/test_oracle.py
             assert np.abs(got - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max()), (kind, N, step, n, nm, variant, use_log, np.abs(got - ref).max())
             continue
